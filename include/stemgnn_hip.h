@@ -1,0 +1,128 @@
+/* stemgnn_hip.h -- C ABI of libstemgnn_hip.so: the MI355X (gfx950) implementation of StemGNN's
+ * spectral hot path (latent-correlation attention -> Laplacian -> Chebyshev/eigen basis -> GFT ->
+ * DFT/GLU/iDFT spe_seq_cell -> IGFT + forecast/backcast heads), forward and backward.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to contiguous row-major fp32 unless the name ends in _host;
+ *   - all buffers (inputs, outputs, saved activations, workspaces) are owned by the caller; the
+ *     library never allocates, frees or synchronises; every launch goes to `stream` (a hipStream_t
+ *     passed as void*), so the calls are stream-ordered and graph-capturable;
+ *   - return value: 0 on success, a negative hipError_t (-(int)err) on a launch failure, or
+ *     SG_EINVAL (-10001) for a bad argument.  No exception crosses this boundary.
+ *   - shapes: B batch, N nodes (units), W window (time_step), multi, H horizon, Wm = W*multi,
+ *     M = B*N rows.
+ *
+ * Each entry point names the reference code it replaces (paths relative to microsoft/StemGNN).
+ */
+#ifndef STEMGNN_HIP_H
+#define STEMGNN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SG_EINVAL (-10001)
+
+/* number of per-StockBlock parameter tensors, in state_dict order of one block:
+ * 0 weight[1,4,1,Wm,Wm]; 1,2 forecast.{w,b}; 3,4 forecast_result.{w,b}; 5,6 backcast.{w,b} (NULL for
+ * stack_cnt>0); 7,8 backcast_short_cut.{w,b}; then GLUs.g.linear_left.{w,b}, GLUs.g.linear_right.{w,b}
+ * for g=0..5 (9 + 4*g + {0,1,2,3}).   (models/base_model.py:23-44) */
+#define SG_BLOCK_NPARAMS 33
+
+/* library / build identification: returns a static string "stemgnn_hip <version> gfx950". */
+const char* stemgnn_version(void);
+
+/* ---- sizes (in floats) of the caller-allocated buffers ----------------------------------------- */
+size_t stemgnn_table_floats(int W, int multi);                       /* DFT / C2R tables            */
+size_t stemgnn_packed_floats(int W, int multi);                      /* packed weights of one block */
+size_t stemgnn_saved_floats(int B, int N, int W, int multi);         /* saved activations, one block fwd */
+size_t stemgnn_scratch_floats(int B, int N, int W, int multi);       /* backward scratch, one block */
+size_t stemgnn_gradpart_floats(int W, int multi, int nsplit);        /* split-M weight-grad partials */
+size_t stemgnn_attn_saved_floats(int B, int N);                      /* key,query,rowsum,A,deg      */
+size_t stemgnn_attn_scratch_floats(int B, int N, int nchunk);        /* attention backward scratch  */
+size_t stemgnn_scratch_offset_dG(int B, int N, int W, int multi);    /* float offset of dG [M,3W] inside the backward scratch */
+
+/* Fill the constant DFT tables (double-precision trig rounded to fp32) into a HOST buffer of
+ * stemgnn_table_floats() floats; the caller copies it to the device once per (W, multi).
+ * Replaces the library FFT plans behind torch.rfft/irfft (models/base_model.py:49,58). */
+int stemgnn_make_tables_host(int W, int multi, float* tables_host);
+
+/* ---- latent-correlation attention + Laplacian  (models/base_model.py:139-147, 151-162) --------
+ * h        [N, B, N]  GRU output exactly as nn.GRU returns it (seq-major; :137), h[s,b,i]
+ * wk, wq   [N]        weight_key / weight_query
+ * seed     device uint64[2] = {seed, offset} for the dropout Philox stream (ignored if !training or p==0)
+ * saved    stemgnn_attn_saved_floats(): key[B,N] | query[B,N] | rowsum[B,N] | A[N,N] (batch-mean, un-symmetrised) | deg[N]
+ * attention_out [N,N] = 0.5(A+A^T)  (the tensor Model.forward returns)
+ * mul_L    [4,N,N]: slot 0 := 0 (T0 is zeros, :129) and slot 1 := L are written here
+ */
+int stemgnn_attn_laplacian_fwd(const float* h, const float* wk, const float* wq, float alpha,
+                               float drop_p, int training, const uint64_t* seed,
+                               int B, int N, float* saved, float* attention_out, float* mul_L,
+                               void* stream);
+/* dL [N,N] = gradient w.r.t. mul_L slot 1 (total).  Outputs dh [N,B,N], dwk [N], dwq [N].
+ * scratch: stemgnn_attn_scratch_floats(B,N,nchunk). */
+int stemgnn_attn_laplacian_bwd(const float* dL, const float* h, const float* wk, const float* wq,
+                               float alpha, float drop_p, int training, const uint64_t* seed,
+                               int B, int N, const float* saved, float* scratch, int nchunk,
+                               float* dh, float* dwk, float* dwq, void* stream);
+/* test hook: write the 0/1 keep-mask [B,N,N] the kernels above generate for `seed`. */
+int stemgnn_dropout_mask(float drop_p, const uint64_t* seed, int B, int N, float* mask, void* stream);
+
+/* ---- Chebyshev basis  (models/base_model.py:121-134) --------------------------------------------
+ * in: mul_L slot 1 = L;  out: slot 2 = 2LL, slot 3 = 2L(2LL) - L  (fp32 MFMA GEMMs). */
+int stemgnn_cheb_fwd(float* mul_L, int N, void* stream);
+/* dmul_L [4,N,N] gradient of all four slots (slot 0 ignored) -> dL [N,N]; scratch 2*N*N floats. */
+int stemgnn_cheb_bwd(const float* mul_L, const float* dmul_L, float* dL, float* scratch, int N, void* stream);
+
+/* ---- weight packing (per StockBlock, once per optimizer step) -----------------------------------
+ * Folds the length-W DFT (:49-51) into the first GLU layer, drops the dead C2R bins,
+ * folds the C2R inverse DFT (:58) into the graph-conv weight (:66-67), and lays the GLU weights out
+ * as K-major "pair" panels for the MFMA kernels.  params_host: SG_BLOCK_NPARAMS device pointers
+ * (host array). */
+int stemgnn_block_pack(const float* const* params_host, const float* tables, float* packed,
+                       int W, int multi, void* stream);
+/* adjoint of the above: reduce the split partials and scatter them into the parameter gradients
+ * grads_host[SG_BLOCK_NPARAMS] (entries may be NULL to skip). */
+int stemgnn_block_unpack_grads(const float* gradpart, int nsplit, const float* tables,
+                               float* const* grads_host, int W, int multi, int has_backcast, void* stream);
+
+/* ---- GFT  (models/base_model.py:62-64)  G[b,n,(k-1)W+t] = sum_m T_k[n,m] X[b,m,t], k=1..3 -----
+ * X is addressed as X[b*xs_b + m*xs_n + t*xs_t]: block 0 reads the model input x[B,W,N] in place
+ * (xs = W*N, 1, N), block 1 reads the backcast [B,N,W] (xs = N*W, W, 1).  G [M, 3W]. */
+int stemgnn_gft_fwd(const float* mul_L, const float* X, long xs_b, long xs_n, long xs_t,
+                    float* G, int B, int N, int W, void* stream);
+/* dG [M,3W] -> dX [B,N,W] (may be NULL) and dmul_L[1..3] (+= if accumulate). */
+int stemgnn_gft_bwd(const float* mul_L, const float* X, long xs_b, long xs_n, long xs_t,
+                    const float* dG, float* dX, float* dmul_L, int accumulate,
+                    int B, int N, int W, void* stream);
+
+/* ---- spe_seq_cell: DFT -> 3x GLU on Re and Im (models/base_model.py:46-54, GLU :12-13) ----------
+ * G = saved + offset(G) is read; GLU outputs and gates are written into `saved`. */
+int stemgnn_spectral_glu_fwd(const float* packed, float* saved, int B, int N, int W, int multi, void* stream);
+/* needs d(last GLU outputs) in scratch.dact[r][0] (written by igft_heads_bwd); produces dG in
+ * scratch.dG and the GLU weight-gradient partials in gradpart. */
+int stemgnn_spectral_glu_bwd(const float* packed, const float* saved, float* scratch, float* gradpart,
+                             int nsplit, int B, int N, int W, int multi, void* stream);
+
+/* ---- C2R iDFT + graph-conv weight + forecast / backcast heads (models/base_model.py:55-58, 65-74)
+ * forecast [M,W]: written (accumulate=0) or added to (accumulate=1: result[0]+result[1], :174).
+ * backcast [M,W] (block 0 only, else NULL); X as in gft_fwd (short-cut input, :71). */
+int stemgnn_igft_heads_fwd(const float* const* params_host, const float* packed, float* saved,
+                           const float* X, long xs_b, long xs_n, long xs_t,
+                           float* forecast, int accumulate, float* backcast,
+                           int B, int N, int W, int multi, void* stream);
+/* dforecast [M,W], dbackcast [M,W] or NULL, backcast = forward output (for sigmoid').  Writes
+ * scratch.dact[r][0] (d of the last GLU outputs) and the heads' weight-gradient partials. */
+int stemgnn_igft_heads_bwd(const float* const* params_host, const float* packed, const float* saved,
+                           const float* X, long xs_b, long xs_n, long xs_t,
+                           const float* dforecast, const float* dbackcast, const float* backcast,
+                           float* scratch, float* gradpart, int nsplit,
+                           int B, int N, int W, int multi, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* STEMGNN_HIP_H */

@@ -1,0 +1,130 @@
+"""Drop-in for the reference's ``models.base_model`` (microsoft/StemGNN models/base_model.py).
+
+Same public surface -- ``Model(units, stack_cnt, time_step, multi_layer, horizon=1, dropout_rate=0.5,
+leaky_rate=0.2, device='cpu')``, ``forward(x[B,W,N]) -> (forecast[B,H,N], attention[N,N])``,
+``StockBlockLayer(time_step, unit, multi_layer, stack_cnt)``, ``GLU(in, out)`` -- the same
+``state_dict`` keys / shapes and the same parameter creation order (so a shared ``torch.manual_seed``
+gives the same initial weights, and checkpoints interchange), but the modules are only parameter
+containers: all arithmetic after the GRU runs in the hand-written HIP kernels of
+``libstemgnn_hip.so`` through :class:`stemgnn_amd.ops.SpectralHotPath`.
+
+Not on the hand-written path (stay PyTorch-ROCm library calls): the ``nn.GRU`` front
+(models/base_model.py:137) and the 2-layer ``fc`` tail (:175).
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _lib
+from .ops import SpectralHotPath
+
+_BLOCK_FIELDS = ("forecast", "forecast_result", "backcast", "backcast_short_cut")
+
+
+class GLU(nn.Module):
+    """Parameter holder for one gated linear unit (reference :6-13); arithmetic is fused into the HIP GLU kernel."""
+
+    def __init__(self, input_channel, output_channel):
+        super().__init__()
+        self.linear_left = nn.Linear(input_channel, output_channel)
+        self.linear_right = nn.Linear(input_channel, output_channel)
+
+    def forward(self, x):
+        raise _lib.StemGNNHipError(
+            "stemgnn_amd.GLU is evaluated inside the fused spectral kernel; call StockBlockLayer / Model instead")
+
+
+class StockBlockLayer(nn.Module):
+    """Parameters of one spectral block (reference :16-44), created in the reference's order."""
+
+    def __init__(self, time_step, unit, multi_layer, stack_cnt=0):
+        super().__init__()
+        self.time_step, self.unit, self.multi, self.stack_cnt = time_step, unit, multi_layer, stack_cnt
+        wide = time_step * multi_layer
+        self.weight = nn.Parameter(torch.empty(1, 4, 1, wide, wide))
+        nn.init.xavier_normal_(self.weight)
+        self.forecast = nn.Linear(wide, wide)
+        self.forecast_result = nn.Linear(wide, time_step)
+        if stack_cnt == 0:
+            self.backcast = nn.Linear(wide, time_step)
+        self.backcast_short_cut = nn.Linear(time_step, time_step)
+        self.output_channel = 4 * multi_layer
+        glu_out = time_step * self.output_channel
+        self.GLUs = nn.ModuleList(
+            GLU(time_step * 4 if layer == 0 else glu_out, glu_out) for layer in range(3) for _branch in range(2))
+
+    def hip_params(self):
+        """The 33 tensors in the order include/stemgnn_hip.h (SG_BLOCK_NPARAMS) defines; missing backcast -> None."""
+        out = [self.weight]
+        for name in _BLOCK_FIELDS:
+            lin = getattr(self, name, None)
+            out += [None, None] if lin is None else [lin.weight, lin.bias]
+        for g in self.GLUs:
+            out += [g.linear_left.weight, g.linear_left.bias, g.linear_right.weight, g.linear_right.bias]
+        return out
+
+    def forward(self, x, mul_L):
+        raise _lib.StemGNNHipError(
+            "stemgnn_amd.StockBlockLayer is driven by Model.forward (both blocks share one fused autograd node); "
+            "use stemgnn_amd.ops for stage-level access")
+
+
+class Model(nn.Module):
+    def __init__(self, units, stack_cnt, time_step, multi_layer, horizon=1, dropout_rate=0.5, leaky_rate=0.2,
+                 device='cpu'):
+        super().__init__()
+        if stack_cnt != 2:
+            # the reference hard-codes result[0] + result[1] (:174) and the driver passes 2 (handler.py:105)
+            raise ValueError("StemGNN's forward sums exactly two StockBlocks; stack_cnt must be 2")
+        self.unit, self.stack_cnt, self.alpha = units, stack_cnt, leaky_rate
+        self.time_step, self.horizon, self.multi_layer = time_step, horizon, multi_layer
+        self.dropout_rate = float(dropout_rate)
+        self.weight_key = nn.Parameter(torch.zeros(units, 1))
+        nn.init.xavier_uniform_(self.weight_key.data, gain=1.414)
+        self.weight_query = nn.Parameter(torch.zeros(units, 1))
+        nn.init.xavier_uniform_(self.weight_query.data, gain=1.414)
+        self.GRU = nn.GRU(time_step, units)
+        self.stock_block = nn.ModuleList(
+            StockBlockLayer(time_step, units, multi_layer, stack_cnt=i) for i in range(stack_cnt))
+        self.fc = nn.Sequential(nn.Linear(time_step, time_step), nn.LeakyReLU(), nn.Linear(time_step, horizon))
+        self._seed = None          # device uint64[2] {seed, offset} of the dropout Philox stream (not a parameter)
+        self.to(device)
+
+    # -- dropout stream ------------------------------------------------------------------------------
+    def _next_seed(self, device):
+        if self._seed is None or self._seed.device != device:
+            s = torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item()   # drawn from torch's CPU generator
+            self._seed = torch.tensor([s, 0], dtype=torch.int64, device=device)
+        used = self._seed.clone()
+        self._seed[1] += 1          # device-side increment: graph-capturable, no host sync
+        return used
+
+    def set_dropout_seed(self, seed, offset=0, device=None):
+        device = device or self.weight_key.device
+        self._seed = torch.tensor([int(seed), int(offset)], dtype=torch.int64, device=device)
+
+    def __getstate__(self):        # keep whole-module pickling (handler.py:24) working
+        state = self.__dict__.copy()
+        state["_seed"] = None
+        return state
+
+    # -- forward --------------------------------------------------------------------------------------
+    def hot_path(self, x):
+        """GRU (library) then the HIP hot path; returns (block forecast sum [B,N,W], attention, mul_L)."""
+        if not x.is_cuda:
+            raise _lib.StemGNNHipError(
+                f"input is on {x.device}: stemgnn_amd.Model runs only on a HIP device (no CPU fallback)")
+        x = x.contiguous()
+        h, _ = self.GRU(x.permute(2, 0, 1).contiguous())          # [N_seq, B, N_hid]  (:137)
+        use_drop = self.training and self.dropout_rate > 0.0
+        seed = self._next_seed(x.device) if use_drop else None
+        params = self.stock_block[0].hip_params() + self.stock_block[1].hip_params()
+        return SpectralHotPath.apply(h, x, self.weight_key, self.weight_query, self.multi_layer, self.alpha,
+                                     self.dropout_rate, self.training, seed, *params)
+
+    def forward(self, x):
+        fsum, attention, _ = self.hot_path(x)
+        forecast = self.fc(fsum)                                   # [B,N,H]  (:175)
+        if forecast.size(-1) == 1:                                 # (:176-177)
+            return forecast.unsqueeze(1).squeeze(-1), attention
+        return forecast.permute(0, 2, 1).contiguous(), attention   # (:178-179)

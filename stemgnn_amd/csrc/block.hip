@@ -1,0 +1,580 @@
+// StockBlockLayer on gfx950: GFT, spectral GLU stack, IGFT + heads -- forward and backward.
+// Every dense contraction runs on the exact-fp32 MFMA GEMM core (gemm_core.h) with the
+// elementwise work (bias, sigmoid, GLU gating, sigmoid', pair/dead-bin layout) fused into the
+// operand loaders / epilogues, so no [M x C] temporary other than the tensors the backward
+// pass needs is ever written.
+//
+// Reference being replaced: microsoft/StemGNN models/base_model.py
+//   GFT :62-64, spe_seq_cell :46-59, GLU :12-13, IGFT :66-67, heads :68-74; backward = autograd.
+#include <hip/hip_runtime.h>
+
+#include "../../include/stemgnn_hip.h"
+#include "gemm_core.h"
+#include "layout.h"
+
+#define SG_TRY(e)                                \
+  do {                                           \
+    hipError_t _e = (e);                         \
+    if (_e != hipSuccess) return -(int)_e;       \
+  } while (0)
+
+__device__ __forceinline__ float sg_sigmoid(float v) { return 1.f / (1.f + expf(-v)); }
+
+// generic strided view of the block input X[b, n, t]
+struct XView {
+  const float* p;
+  long sb, sn, st;
+  int N;
+  __device__ __forceinline__ float at(int b, int n, int t) const { return p[b * sb + n * sn + t * st]; }
+  __device__ __forceinline__ float row(int m, int t) const {
+    const int b = m / N;
+    return at(b, m - b * N, t);
+  }
+};
+
+// =================================================================================================
+// GFT forward:  C[(kq,n)][(b,t)] = sum_m T_{kq+1}[n][m] X[b][m][t]  ->  G[(b,n)][kq*W+t]
+// =================================================================================================
+struct GftFwdOp {
+  const float* T;  // mul_L slot 1 (slots 1..3 are contiguous: row i = kq*N + n)
+  XView X;
+  float* G;
+  int B, N, W;
+  __device__ bool setup(int, int& M, int& Nn, int& K0, int& K1) const {
+    M = 3 * N; Nn = B * W; K0 = 0; K1 = N;
+    return true;
+  }
+  __device__ float a(int, int i, int k) const { return T[(size_t)i * N + k]; }
+  __device__ float b(int, int k, int j) const {
+    const int bb = j / W;
+    return X.at(bb, k, j - bb * W);
+  }
+  __device__ void epi(int, int i, int j, float v) const {
+    const int kq = i / N, n = i - kq * N, bb = j / W, t = j - bb * W;
+    G[((size_t)bb * N + n) * (3 * W) + kq * W + t] = v;
+  }
+};
+
+// GFT backward dX[b][m][t] = sum_{kq,n} T_{kq+1}[n][m] dG[(b,n)][kq*W+t]
+struct GftBwdDxOp {
+  const float* T;
+  const float* dG;
+  float* dX;
+  int B, N, W;
+  __device__ bool setup(int, int& M, int& Nn, int& K0, int& K1) const {
+    M = N; Nn = B * W; K0 = 0; K1 = 3 * N;
+    return true;
+  }
+  __device__ float a(int, int i, int k) const { return T[(size_t)k * N + i]; }   // T_kq[n][m=i], k=(kq,n)
+  __device__ float b(int, int k, int j) const {
+    const int kq = k / N, n = k - kq * N, bb = j / W, t = j - bb * W;
+    return dG[((size_t)bb * N + n) * (3 * W) + kq * W + t];
+  }
+  __device__ void epi(int, int i, int j, float v) const {
+    const int bb = j / W, t = j - bb * W;
+    dX[((size_t)bb * N + i) * W + t] = v;
+  }
+};
+
+// GFT backward dT_{kq+1}[n][m] (+)= sum_{b,t} dG[(b,n)][kq*W+t] X[b][m][t]
+struct GftBwdDtOp {
+  const float* dG;
+  XView X;
+  float* dT;  // dmul_L slot 1
+  int B, N, W, accumulate;
+  __device__ bool setup(int, int& M, int& Nn, int& K0, int& K1) const {
+    M = 3 * N; Nn = N; K0 = 0; K1 = B * W;
+    return true;
+  }
+  __device__ float a(int, int i, int k) const {
+    const int kq = i / N, n = i - kq * N, bb = k / W, t = k - bb * W;
+    return dG[((size_t)bb * N + n) * (3 * W) + kq * W + t];
+  }
+  __device__ float b(int, int k, int j) const {
+    const int bb = k / W;
+    return X.at(bb, j, k - bb * W);
+  }
+  __device__ void epi(int, int i, int j, float v) const {
+    float* o = dT + (size_t)i * N + j;
+    *o = accumulate ? (*o + v) : v;
+  }
+};
+
+// =================================================================================================
+// GLU layer forward (both branches, z = branch):  out = (x Wl + bl) * sigmoid(x Wr + br)
+// =================================================================================================
+struct GluFwdOp {
+  const float* x[2];
+  const float* wp[2];
+  const float* bp[2];
+  float* out[2];
+  float* gate[2];
+  int np[2];
+  int ldx, kin, M;
+  __device__ bool setup(int z, int& M_, int& N_, int& K0, int& K1) const {
+    M_ = M; N_ = np[z]; K0 = 0; K1 = kin;
+    return true;
+  }
+  __device__ float a(int z, int i, int k) const { return x[z][(size_t)i * ldx + k]; }
+  __device__ float b(int z, int k, int j) const { return wp[z][(size_t)k * np[z] + j]; }
+  __device__ void epi(int, int, int, float) const {}
+  __device__ void epi2(int z, int i, int c, float u, float v) const {
+    const int q = ((c >> 4) << 5) + (c & 15);
+    u += bp[z][q];
+    v += bp[z][q + 16];
+    const float g = sg_sigmoid(v);
+    const size_t o = (size_t)i * (np[z] >> 1) + c;
+    out[z][o] = u * g;
+    gate[z][o] = g;
+  }
+};
+
+// d(pre-activation) of a GLU layer, packed "pair" column q:  left: dout*g ; right: dout*out*(1-g)
+struct GluDpre {
+  const float* dout[2];
+  const float* out[2];
+  const float* gate[2];
+  int cp[2];
+  __device__ __forceinline__ float at(int r, int m, int q) const {
+    const int c = ((q >> 5) << 4) + (q & 15);
+    const size_t o = (size_t)m * cp[r] + c;
+    const float d = dout[r][o], g = gate[r][o];
+    return (q & 16) ? d * out[r][o] * (1.f - g) : d * g;
+  }
+};
+
+// GLU data gradient, layers 1 and 2 (z = branch): dx[m][kin] = sum_q dpre[m][q] Wp[kin][q]
+struct GluDgradOp {
+  GluDpre dp;
+  const float* wp[2];
+  int np[2];
+  float* dx[2];
+  int ldd, kin, M;
+  __device__ bool setup(int z, int& M_, int& N_, int& K0, int& K1) const {
+    M_ = M; N_ = kin; K0 = 0; K1 = np[z];
+    return true;
+  }
+  __device__ float a(int z, int i, int k) const { return dp.at(z, i, k); }
+  __device__ float b(int z, int k, int j) const { return wp[z][(size_t)j * np[z] + k]; }
+  __device__ void epi(int z, int i, int j, float v) const { dx[z][(size_t)i * ldd + j] = v; }
+};
+
+// GLU data gradient of layer 0: both branches feed the same G, so K spans Re then Im columns
+struct GluDgrad0Op {
+  GluDpre dp;
+  const float* wp[2];
+  int np0;
+  float* dG;
+  int KG, M;
+  __device__ bool setup(int, int& M_, int& N_, int& K0, int& K1) const {
+    M_ = M; N_ = KG; K0 = 0; K1 = 2 * np0;
+    return true;
+  }
+  __device__ float a(int, int i, int k) const {
+    const int r = k >= np0;
+    return dp.at(r, i, k - r * np0);
+  }
+  __device__ float b(int, int k, int j) const {
+    const int r = k >= np0;
+    return wp[r][(size_t)j * np0 + (k - r * np0)];
+  }
+  __device__ void epi(int, int i, int j, float v) const { dG[(size_t)i * KG + j] = v; }
+};
+
+// GLU weight gradient (z = branch*S + split): part[q][kin|bias] = sum_{m in split} dpre[m][q] x[m][kin]
+struct GluWgradOp {
+  GluDpre dp;
+  const float* x[2];
+  float* part[2];
+  int np[2];
+  int ldx, kin, M, S, chunk;
+  __device__ bool setup(int z, int& M_, int& N_, int& K0, int& K1) const {
+    const int r = z / S, s = z - r * S;
+    M_ = np[r]; N_ = kin + 1; K0 = s * chunk; K1 = min(M, K0 + chunk);
+    return true;
+  }
+  __device__ float a(int z, int i, int k) const { return dp.at(z / S, k, i); }
+  __device__ float b(int z, int k, int j) const { return j < kin ? x[z / S][(size_t)k * ldx + j] : 1.f; }
+  __device__ void epi(int z, int i, int j, float v) const {
+    const int r = z / S, s = z - r * S;
+    part[r][((size_t)s * np[r] + i) * (kin + 1) + j] = v;
+  }
+};
+
+// =================================================================================================
+// IGFT (C2R iDFT folded into the graph-conv weight) and the heads
+// =================================================================================================
+struct IgftOp {  // ig[m][o] = sum_kk [Re3 | Im3][m][kk] Wfold[kk][o]
+  const float* a3[2];
+  int cp2[2];
+  const float* wfold;
+  float* ig;
+  int M, Wm, WmP;
+  __device__ bool setup(int, int& M_, int& N_, int& K0, int& K1) const {
+    M_ = M; N_ = Wm; K0 = 0; K1 = cp2[0] + cp2[1];
+    return true;
+  }
+  __device__ float a(int, int i, int k) const {
+    return k < cp2[0] ? a3[0][(size_t)i * cp2[0] + k] : a3[1][(size_t)i * cp2[1] + (k - cp2[0])];
+  }
+  __device__ float b(int, int k, int j) const { return wfold[(size_t)k * WmP + j]; }
+  __device__ void epi(int, int i, int j, float v) const { ig[(size_t)i * Wm + j] = v; }
+};
+
+// fs = sigmoid(ig F^T + Fb)  |  backcast = sigmoid(ig BC^T + BCb - (X BS^T + BSb))   (block 0)
+struct Head1Op {
+  const float* ig;
+  XView X;
+  const float *Fw, *Fb, *BCw, *BCb, *BSw, *BSb;
+  float* fs;
+  float* bc;
+  int M, W, Wm, has_bc;
+  __device__ bool setup(int, int& M_, int& N_, int& K0, int& K1) const {
+    M_ = M; N_ = Wm + (has_bc ? W : 0); K0 = 0; K1 = Wm + (has_bc ? W : 0);
+    return true;
+  }
+  __device__ float a(int, int i, int k) const { return k < Wm ? ig[(size_t)i * Wm + k] : X.row(i, k - Wm); }
+  __device__ float b(int, int k, int j) const {
+    if (j < Wm) return k < Wm ? Fw[(size_t)j * Wm + k] : 0.f;
+    const int t = j - Wm;
+    return k < Wm ? BCw[(size_t)t * Wm + k] : -BSw[t * W + (k - Wm)];
+  }
+  __device__ void epi(int, int i, int j, float v) const {
+    if (j < Wm) fs[(size_t)i * Wm + j] = sg_sigmoid(v + Fb[j]);
+    else { const int t = j - Wm; bc[(size_t)i * W + t] = sg_sigmoid(v + BCb[t] - BSb[t]); }
+  }
+};
+
+struct Head2Op {  // forecast (+)= fs FR^T + FRb
+  const float* fs;
+  const float *FRw, *FRb;
+  float* fo;
+  int M, W, Wm, accumulate;
+  __device__ bool setup(int, int& M_, int& N_, int& K0, int& K1) const {
+    M_ = M; N_ = W; K0 = 0; K1 = Wm;
+    return true;
+  }
+  __device__ float a(int, int i, int k) const { return fs[(size_t)i * Wm + k]; }
+  __device__ float b(int, int k, int j) const { return FRw[(size_t)j * Wm + k]; }
+  __device__ void epi(int, int i, int j, float v) const {
+    float* o = fo + (size_t)i * W + j;
+    v += FRb[j];
+    *o = accumulate ? (*o + v) : v;
+  }
+};
+
+// ---- backward of the heads -------------------------------------------------------------------------
+__global__ void sg_dsigmoid_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                   float* __restrict__ dpre, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    const float s = y[i];
+    dpre[i] = dy[i] * s * (1.f - s);
+  }
+}
+
+struct Head2BwdOp {  // dpF = (dfo FR) * fs (1 - fs)
+  const float* dfo;
+  const float* FRw;
+  const float* fs;
+  float* dpF;
+  int M, W, Wm;
+  __device__ bool setup(int, int& M_, int& N_, int& K0, int& K1) const {
+    M_ = M; N_ = Wm; K0 = 0; K1 = W;
+    return true;
+  }
+  __device__ float a(int, int i, int k) const { return dfo[(size_t)i * W + k]; }
+  __device__ float b(int, int k, int j) const { return FRw[(size_t)k * Wm + j]; }
+  __device__ void epi(int, int i, int j, float v) const {
+    const size_t o = (size_t)i * Wm + j;
+    const float s = fs[o];
+    dpF[o] = v * s * (1.f - s);
+  }
+};
+
+struct DigOp {  // dig = dpF F + dpB BC
+  const float *dpF, *dpB, *Fw, *BCw;
+  float* dig;
+  int M, W, Wm, has_bc;
+  __device__ bool setup(int, int& M_, int& N_, int& K0, int& K1) const {
+    M_ = M; N_ = Wm; K0 = 0; K1 = Wm + (has_bc ? W : 0);
+    return true;
+  }
+  __device__ float a(int, int i, int k) const {
+    return k < Wm ? dpF[(size_t)i * Wm + k] : dpB[(size_t)i * W + (k - Wm)];
+  }
+  __device__ float b(int, int k, int j) const {
+    return k < Wm ? Fw[(size_t)k * Wm + j] : BCw[(size_t)(k - Wm) * Wm + j];
+  }
+  __device__ void epi(int, int i, int j, float v) const { dig[(size_t)i * Wm + j] = v; }
+};
+
+struct Da3Op {  // z = branch: d(last GLU out)[m][c] = sum_o dig[m][o] Wfold[roff+c][o]
+  const float* dig;
+  const float* wfold;
+  float* da3[2];
+  int cp2[2];
+  int M, Wm, WmP;
+  __device__ bool setup(int z, int& M_, int& N_, int& K0, int& K1) const {
+    M_ = M; N_ = cp2[z]; K0 = 0; K1 = Wm;
+    return true;
+  }
+  __device__ float a(int, int i, int k) const { return dig[(size_t)i * Wm + k]; }
+  __device__ float b(int z, int k, int j) const { return wfold[(size_t)((z ? cp2[0] : 0) + j) * WmP + k]; }
+  __device__ void epi(int z, int i, int j, float v) const { da3[z][(size_t)i * cp2[z] + j] = v; }
+};
+
+// weight gradients of the heads + Wfold, z = which*S + split
+struct HeadsWgradOp {
+  const float *dfo, *fs, *dpF, *ig, *dpB, *dig;
+  const float* a3[2];
+  int cp2[2];
+  XView X;
+  float *pFR, *pF, *pBC, *pBS, *pWf;
+  int M, W, Wm, WmP, KF, S, chunk, has_bc;
+  __device__ bool setup(int z, int& M_, int& N_, int& K0, int& K1) const {
+    const int which = z / S, s = z - which * S;
+    K0 = s * chunk; K1 = min(M, K0 + chunk);
+    switch (which) {
+      case 0: M_ = W; N_ = Wm + 1; break;
+      case 1: M_ = Wm; N_ = Wm + 1; break;
+      case 2: M_ = W; N_ = Wm + 1; return has_bc != 0;
+      case 3: M_ = W; N_ = W + 1; return has_bc != 0;
+      default: M_ = KF; N_ = Wm; break;
+    }
+    return true;
+  }
+  __device__ float a(int z, int i, int k) const {
+    switch (z / S) {
+      case 0: return dfo[(size_t)k * W + i];
+      case 1: return dpF[(size_t)k * Wm + i];
+      case 2: return dpB[(size_t)k * W + i];
+      case 3: return -dpB[(size_t)k * W + i];
+      default:
+        return i < cp2[0] ? a3[0][(size_t)k * cp2[0] + i] : a3[1][(size_t)k * cp2[1] + (i - cp2[0])];
+    }
+  }
+  __device__ float b(int z, int k, int j) const {
+    switch (z / S) {
+      case 0: return j < Wm ? fs[(size_t)k * Wm + j] : 1.f;
+      case 1:
+      case 2: return j < Wm ? ig[(size_t)k * Wm + j] : 1.f;
+      case 3: return j < W ? X.row(k, j) : 1.f;
+      default: return dig[(size_t)k * Wm + j];
+    }
+  }
+  __device__ void epi(int z, int i, int j, float v) const {
+    const int which = z / S, s = z - which * S;
+    switch (which) {
+      case 0: pFR[((size_t)s * W + i) * (Wm + 1) + j] = v; break;
+      case 1: pF[((size_t)s * Wm + i) * (Wm + 1) + j] = v; break;
+      case 2: pBC[((size_t)s * W + i) * (Wm + 1) + j] = v; break;
+      case 3: pBS[((size_t)s * W + i) * (W + 1) + j] = v; break;
+      default: pWf[((size_t)s * KF + i) * WmP + j] = v; break;
+    }
+  }
+};
+
+// =================================================================================================
+// host side
+// =================================================================================================
+static inline int split_chunk(int M, int S) { return ((M + S - 1) / S + 15) & ~15; }
+
+extern "C" int stemgnn_gft_fwd(const float* mul_L, const float* X, long xs_b, long xs_n, long xs_t,
+                               float* G, int B, int N, int W, void* stream) {
+  if (!mul_L || !X || !G || B <= 0 || N <= 0 || W <= 0) return SG_EINVAL;
+  GftFwdOp op{mul_L + (size_t)N * N, XView{X, xs_b, xs_n, xs_t, N}, G, B, N, W};
+  hipStream_t st = (hipStream_t)stream;
+  if (xs_n == 1) SG_TRY((sg_launch_gemm<GftFwdOp, 64, 64, true, true, false>(op, 3 * N, B * W, 1, st)));
+  else SG_TRY((sg_launch_gemm<GftFwdOp, 64, 64, true, false, false>(op, 3 * N, B * W, 1, st)));
+  return 0;
+}
+
+extern "C" int stemgnn_gft_bwd(const float* mul_L, const float* X, long xs_b, long xs_n, long xs_t,
+                               const float* dG, float* dX, float* dmul_L, int accumulate,
+                               int B, int N, int W, void* stream) {
+  if (!mul_L || !X || !dG || !dmul_L || B <= 0 || N <= 0 || W <= 0) return SG_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  if (dX) {
+    GftBwdDxOp op{mul_L + (size_t)N * N, dG, dX, B, N, W};
+    SG_TRY((sg_launch_gemm<GftBwdDxOp, 64, 64, false, false, false>(op, N, B * W, 1, st)));
+  }
+  GftBwdDtOp op{dG, XView{X, xs_b, xs_n, xs_t, N}, dmul_L + (size_t)N * N, B, N, W, accumulate};
+  if (xs_t == 1) SG_TRY((sg_launch_gemm<GftBwdDtOp, 64, 64, true, true, false>(op, 3 * N, N, 1, st)));
+  else SG_TRY((sg_launch_gemm<GftBwdDtOp, 64, 64, true, false, false>(op, 3 * N, N, 1, st)));
+  return 0;
+}
+
+extern "C" int stemgnn_spectral_glu_fwd(const float* packed, float* saved, int B, int N, int W, int multi,
+                                        void* stream) {
+  if (!packed || !saved || B <= 0 || N <= 0 || W <= 0 || multi <= 0) return SG_EINVAL;
+  const SgDims d = sg_dims(B, N, W, multi);
+  const SgPackedLayout P = sg_packed_layout(d);
+  const SgSavedLayout S = sg_saved_layout(d);
+  hipStream_t st = (hipStream_t)stream;
+  for (int l = 0; l < 3; ++l) {
+    GluFwdOp op;
+    for (int r = 0; r < 2; ++r) {
+      op.x[r] = l == 0 ? saved + S.G : saved + S.out[r][l - 1];
+      op.wp[r] = packed + P.w[r][l];
+      op.bp[r] = packed + P.b[r][l];
+      op.out[r] = saved + S.out[r][l];
+      op.gate[r] = saved + S.gate[r][l];
+      op.np[r] = sg_glu_np(d, l, r);
+    }
+    op.ldx = l == 0 ? d.KG : d.CP;
+    op.kin = sg_glu_kin(d, l);
+    op.M = d.M;
+    const int maxN = op.np[0] > op.np[1] ? op.np[0] : op.np[1];
+    SG_TRY((sg_launch_gemm<GluFwdOp, 128, 64, true, false, true>(op, d.M, maxN, 2, st)));
+  }
+  return 0;
+}
+
+extern "C" int stemgnn_spectral_glu_bwd(const float* packed, const float* saved, float* scratch,
+                                        float* gradpart, int nsplit, int B, int N, int W, int multi,
+                                        void* stream) {
+  if (!packed || !saved || !scratch || !gradpart || nsplit <= 0 || B <= 0 || N <= 0 || W <= 0 || multi <= 0)
+    return SG_EINVAL;
+  const SgDims d = sg_dims(B, N, W, multi);
+  const SgPackedLayout P = sg_packed_layout(d);
+  const SgSavedLayout S = sg_saved_layout(d);
+  const SgScratchLayout C = sg_scratch_layout(d);
+  const SgGradLayout Gl = sg_grad_layout(d, nsplit);
+  hipStream_t st = (hipStream_t)stream;
+  const int chunk = split_chunk(d.M, nsplit);
+  for (int l = 2; l >= 0; --l) {
+    // d(out of layer l) lives in dact[r][(2-l)&1]: l=2 -> slot 0 (ld CP2), l=1 -> slot 1, l=0 -> slot 0
+    const int slot_in = (2 - l) & 1;
+    GluDpre dp;
+    for (int r = 0; r < 2; ++r) {
+      dp.dout[r] = scratch + C.dact[r][slot_in];
+      dp.out[r] = saved + S.out[r][l];
+      dp.gate[r] = saved + S.gate[r][l];
+      dp.cp[r] = sg_glu_cp(d, l, r);
+    }
+    {  // weight gradient
+      GluWgradOp op;
+      op.dp = dp;
+      for (int r = 0; r < 2; ++r) {
+        op.x[r] = l == 0 ? saved + S.G : saved + S.out[r][l - 1];
+        op.part[r] = gradpart + Gl.w[r][l];
+        op.np[r] = sg_glu_np(d, l, r);
+      }
+      op.ldx = l == 0 ? d.KG : d.CP;
+      op.kin = sg_glu_kin(d, l);
+      op.M = d.M; op.S = nsplit; op.chunk = chunk;
+      const int maxM = op.np[0] > op.np[1] ? op.np[0] : op.np[1];
+      SG_TRY((sg_launch_gemm<GluWgradOp, 64, 64, false, false, false>(op, maxM, op.kin + 1, 2 * nsplit, st)));
+    }
+    if (l > 0) {  // data gradient -> d(out of layer l-1)
+      GluDgradOp op;
+      op.dp = dp;
+      for (int r = 0; r < 2; ++r) {
+        op.wp[r] = packed + P.w[r][l];
+        op.np[r] = sg_glu_np(d, l, r);
+        op.dx[r] = scratch + C.dact[r][slot_in ^ 1];
+      }
+      op.ldd = d.CP; op.kin = d.CP; op.M = d.M;
+      SG_TRY((sg_launch_gemm<GluDgradOp, 128, 64, true, true, false>(op, d.M, d.CP, 2, st)));
+    } else {
+      GluDgrad0Op op;
+      op.dp = dp;
+      op.wp[0] = packed + P.w[0][0];
+      op.wp[1] = packed + P.w[1][0];
+      op.np0 = sg_glu_np(d, 0, 0);
+      op.dG = scratch + C.dG;
+      op.KG = d.KG; op.M = d.M;
+      SG_TRY((sg_launch_gemm<GluDgrad0Op, 128, 64, true, true, false>(op, d.M, d.KG, 1, st)));
+    }
+  }
+  return 0;
+}
+
+extern "C" int stemgnn_igft_heads_fwd(const float* const* params_host, const float* packed, float* saved,
+                                      const float* X, long xs_b, long xs_n, long xs_t,
+                                      float* forecast, int accumulate, float* backcast,
+                                      int B, int N, int W, int multi, void* stream) {
+  if (!params_host || !packed || !saved || !X || !forecast || B <= 0 || N <= 0 || W <= 0 || multi <= 0)
+    return SG_EINVAL;
+  const SgDims d = sg_dims(B, N, W, multi);
+  const SgPackedLayout P = sg_packed_layout(d);
+  const SgSavedLayout S = sg_saved_layout(d);
+  hipStream_t st = (hipStream_t)stream;
+  const int has_bc = backcast != nullptr;
+  if (has_bc && (!params_host[5] || !params_host[6])) return SG_EINVAL;
+  {
+    IgftOp op;
+    for (int r = 0; r < 2; ++r) { op.a3[r] = saved + S.out[r][2]; op.cp2[r] = d.CP2[r]; }
+    op.wfold = packed + P.wfold; op.ig = saved + S.ig; op.M = d.M; op.Wm = d.Wm; op.WmP = d.WmP;
+    SG_TRY((sg_launch_gemm<IgftOp, 64, 64, true, false, false>(op, d.M, d.Wm, 1, st)));
+  }
+  {
+    Head1Op op{saved + S.ig, XView{X, xs_b, xs_n, xs_t, N},
+               params_host[1], params_host[2], params_host[5], params_host[6], params_host[7], params_host[8],
+               saved + S.fs, backcast, d.M, W, d.Wm, has_bc};
+    SG_TRY((sg_launch_gemm<Head1Op, 64, 64, true, true, false>(op, d.M, d.Wm + (has_bc ? W : 0), 1, st)));
+  }
+  {
+    Head2Op op{saved + S.fs, params_host[3], params_host[4], forecast, d.M, W, d.Wm, accumulate};
+    SG_TRY((sg_launch_gemm<Head2Op, 64, 32, true, true, false>(op, d.M, W, 1, st)));
+  }
+  return 0;
+}
+
+extern "C" int stemgnn_igft_heads_bwd(const float* const* params_host, const float* packed, const float* saved,
+                                      const float* X, long xs_b, long xs_n, long xs_t,
+                                      const float* dforecast, const float* dbackcast, const float* backcast,
+                                      float* scratch, float* gradpart, int nsplit,
+                                      int B, int N, int W, int multi, void* stream) {
+  if (!params_host || !packed || !saved || !X || !dforecast || !scratch || !gradpart || nsplit <= 0 ||
+      B <= 0 || N <= 0 || W <= 0 || multi <= 0)
+    return SG_EINVAL;
+  const SgDims d = sg_dims(B, N, W, multi);
+  const SgPackedLayout P = sg_packed_layout(d);
+  const SgSavedLayout S = sg_saved_layout(d);
+  const SgScratchLayout C = sg_scratch_layout(d);
+  const SgGradLayout Gl = sg_grad_layout(d, nsplit);
+  hipStream_t st = (hipStream_t)stream;
+  const int has_bc = (dbackcast != nullptr && backcast != nullptr);
+  if (has_bc && !params_host[5]) return SG_EINVAL;
+  float* dpF = scratch + C.dpF;
+  float* dpB = scratch + C.dpB;
+  float* dig = scratch + C.dig;
+  if (has_bc) {
+    const size_t n = (size_t)d.M * W;
+    const int blocks = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+    hipLaunchKernelGGL(sg_dsigmoid_kernel, dim3(blocks), dim3(256), 0, st, dbackcast, backcast, dpB, n);
+    SG_TRY(hipGetLastError());
+  }
+  {
+    Head2BwdOp op{dforecast, params_host[3], saved + S.fs, dpF, d.M, W, d.Wm};
+    SG_TRY((sg_launch_gemm<Head2BwdOp, 64, 64, true, false, false>(op, d.M, d.Wm, 1, st)));
+  }
+  {
+    DigOp op{dpF, dpB, params_host[1], params_host[5], dig, d.M, W, d.Wm, has_bc};
+    SG_TRY((sg_launch_gemm<DigOp, 64, 64, true, false, false>(op, d.M, d.Wm, 1, st)));
+  }
+  {
+    Da3Op op;
+    op.dig = dig; op.wfold = packed + P.wfold;
+    for (int r = 0; r < 2; ++r) { op.da3[r] = scratch + C.dact[r][0]; op.cp2[r] = d.CP2[r]; }
+    op.M = d.M; op.Wm = d.Wm; op.WmP = d.WmP;
+    const int maxN = d.CP2[0] > d.CP2[1] ? d.CP2[0] : d.CP2[1];
+    SG_TRY((sg_launch_gemm<Da3Op, 64, 64, true, true, false>(op, d.M, maxN, 2, st)));
+  }
+  {
+    HeadsWgradOp op;
+    op.dfo = dforecast; op.fs = saved + S.fs; op.dpF = dpF; op.ig = saved + S.ig; op.dpB = dpB; op.dig = dig;
+    for (int r = 0; r < 2; ++r) { op.a3[r] = saved + S.out[r][2]; op.cp2[r] = d.CP2[r]; }
+    op.X = XView{X, xs_b, xs_n, xs_t, N};
+    op.pFR = gradpart + Gl.fr; op.pF = gradpart + Gl.fc; op.pBC = gradpart + Gl.bc; op.pBS = gradpart + Gl.bs;
+    op.pWf = gradpart + Gl.wfold;
+    op.M = d.M; op.W = W; op.Wm = d.Wm; op.WmP = d.WmP; op.KF = d.KF; op.S = nsplit;
+    op.chunk = split_chunk(d.M, nsplit); op.has_bc = has_bc;
+    const int maxM = d.KF > d.Wm ? d.KF : d.Wm;
+    SG_TRY((sg_launch_gemm<HeadsWgradOp, 64, 64, false, false, false>(op, maxM, d.Wm + 1, 5 * nsplit, st)));
+  }
+  return 0;
+}

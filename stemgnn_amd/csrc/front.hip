@@ -1,0 +1,437 @@
+// Latent-correlation front on gfx950: key/query projections, fused leaky-relu + softmax + dropout
+// + batch-mean (the [B,N,N] attention tensor is never materialised), degree / symmetrise /
+// normalised Laplacian, the Chebyshev basis, and the closed-form backward of all of it.
+//
+// Reference being replaced: microsoft/StemGNN models/base_model.py
+//   self_graph_attention :151-162, latent_correlation_layer :139-148, cheb_polynomial :121-134.
+// These stages are HBM/LDS-bound (O(B N^2) exp + O(N^2) elementwise); only the two N^3 Chebyshev
+// products run on MFMA.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/stemgnn_hip.h"
+#include "gemm_core.h"
+#include "layout.h"
+
+#define SG_TRY(e)                                \
+  do {                                           \
+    hipError_t _e = (e);                         \
+    if (_e != hipSuccess) return -(int)_e;       \
+  } while (0)
+
+// ---- Philox4x32-10, one counter per attention element ---------------------------------------------
+__device__ __forceinline__ uint32_t sg_philox_u32(uint64_t seed, uint64_t offset, uint64_t idx) {
+  uint32_t c0 = (uint32_t)idx, c1 = (uint32_t)(idx >> 32), c2 = (uint32_t)offset, c3 = (uint32_t)(offset >> 32);
+  uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+    const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    c0 = hi1 ^ c1 ^ k0; c1 = lo1; c2 = hi0 ^ c3 ^ k1; c3 = lo0;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  return c0;
+}
+__device__ __forceinline__ bool sg_keep(uint64_t seed, uint64_t offset, uint64_t idx, float p) {
+  return (float)sg_philox_u32(seed, offset, idx) * 2.3283064365386963e-10f >= p;
+}
+
+__device__ __forceinline__ float sg_wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float sg_wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ float sg_lrelu(float v, float alpha) { return v > 0.f ? v : alpha * v; }
+
+// key[b,i] = sum_s h[s,b,i] wk[s], query likewise (:154-155).  grid (B, ceil(N/64)), 4 waves split s.
+__global__ __launch_bounds__(256) void sg_keyquery_kernel(const float* __restrict__ h, const float* __restrict__ wk,
+                                                          const float* __restrict__ wq, float* __restrict__ key,
+                                                          float* __restrict__ query, int B, int N) {
+  __shared__ float red[4][64][2];
+  const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = blockIdx.y * 64 + lane;
+  float ak = 0.f, aq = 0.f;
+  if (i < N) {
+    const float* hp = h + (size_t)b * N + i;
+    const size_t stride = (size_t)B * N;
+#pragma unroll 4
+    for (int s = wave; s < N; s += 4) {
+      const float v = hp[s * stride];
+      ak = fmaf(v, wk[s], ak);
+      aq = fmaf(v, wq[s], aq);
+    }
+  }
+  red[wave][lane][0] = ak;
+  red[wave][lane][1] = aq;
+  __syncthreads();
+  if (wave == 0 && i < N) {
+    key[(size_t)b * N + i] = (red[0][lane][0] + red[1][lane][0]) + (red[2][lane][0] + red[3][lane][0]);
+    query[(size_t)b * N + i] = (red[0][lane][1] + red[1][lane][1]) + (red[2][lane][1] + red[3][lane][1]);
+  }
+}
+
+// One wave per adjacency row i: loops the batch, softmax over j in registers/LDS, accumulates the
+// batch mean (and the dropout mask, regenerated in backward from the same Philox stream).
+// dynamic LDS: qmax[B] + acc[4][N].
+__global__ __launch_bounds__(256) void sg_attention_fwd_kernel(
+    const float* __restrict__ key, const float* __restrict__ query, float alpha, float drop_p, int training,
+    const uint64_t* __restrict__ seedp, int B, int N, float* __restrict__ rowsum, float* __restrict__ A,
+    float* __restrict__ deg) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* qmax = smem;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float* acc = smem + B + wave * N;
+  for (int b = wave; b < B; b += 4) {
+    float m = -INFINITY;
+    for (int j = lane; j < N; j += 64) m = fmaxf(m, query[(size_t)b * N + j]);
+    m = sg_wave_max(m);
+    if (lane == 0) qmax[b] = m;
+  }
+  __syncthreads();
+  const int i = blockIdx.x * 4 + wave;
+  if (i >= N) return;
+  const bool drop = training && drop_p > 0.f;
+  uint64_t seed = 0, offset = 0;
+  if (drop) { seed = seedp[0]; offset = seedp[1]; }
+  const float keep_scale = drop ? 1.f / (1.f - drop_p) : 1.f;
+  for (int j = lane; j < N; j += 64) acc[j] = 0.f;
+  for (int b = 0; b < B; ++b) {
+    const float kv = key[(size_t)b * N + i];
+    const float mx = sg_lrelu(kv + qmax[b], alpha);      // leaky-relu is monotone: row max is at max_j query
+    const float* q = query + (size_t)b * N;
+    float s = 0.f;
+    for (int j = lane; j < N; j += 64) s += expf(sg_lrelu(kv + q[j], alpha) - mx);
+    s = sg_wave_sum(s);
+    if (lane == 0) rowsum[(size_t)b * N + i] = s;
+    const float inv = 1.f / s;
+    for (int j = lane; j < N; j += 64) {
+      float p = expf(sg_lrelu(kv + q[j], alpha) - mx) * inv;
+      if (drop) p = sg_keep(seed, offset, ((uint64_t)b * N + i) * N + j, drop_p) ? p * keep_scale : 0.f;
+      acc[j] += p;
+    }
+  }
+  const float invB = 1.f / (float)B;
+  float d = 0.f;
+  for (int j = lane; j < N; j += 64) {
+    const float a = acc[j] * invB;
+    A[(size_t)i * N + j] = a;
+    d += a;
+  }
+  d = sg_wave_sum(d);
+  if (lane == 0) deg[i] = d;
+}
+
+// attention_out = 0.5 (A + A^T);  L = D^ (diag(deg) - attention_out) D^ ; mul_L slot0 = 0, slot1 = L.
+// 32x32 tiles, transposed partner tile through LDS.
+__global__ __launch_bounds__(256) void sg_laplacian_fwd_kernel(const float* __restrict__ A, const float* __restrict__ deg,
+                                                               float* __restrict__ att, float* __restrict__ mulL, int N) {
+  __shared__ float tT[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  const int i0 = blockIdx.y * 32, j0 = blockIdx.x * 32;
+  for (int r = ty; r < 32; r += 8) {
+    const int gi = j0 + r, gj = i0 + tx;  // partner tile (rows j0.., cols i0..)
+    tT[r][tx] = (gi < N && gj < N) ? A[(size_t)gi * N + gj] : 0.f;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const int i = i0 + r, j = j0 + tx;
+    if (i < N && j < N) {
+      const float s = 0.5f * (A[(size_t)i * N + j] + tT[tx][r]);
+      const float di = deg[i], dj = deg[j];
+      const float dhi = 1.f / (sqrtf(di) + 1e-7f), dhj = 1.f / (sqrtf(dj) + 1e-7f);
+      const float qv = (i == j ? di : 0.f) - s;
+      const size_t o = (size_t)i * N + j;
+      att[o] = s;
+      mulL[o] = 0.f;
+      mulL[(size_t)N * N + o] = dhi * (qv * dhj);
+    }
+  }
+}
+
+// ---- backward -----------------------------------------------------------------------------------------
+// Laplacian backward: one wave per row i.  dAB = dA / B.
+__global__ __launch_bounds__(256) void sg_laplacian_bwd_kernel(const float* __restrict__ dL, const float* __restrict__ A,
+                                                               const float* __restrict__ deg, float* __restrict__ dAB,
+                                                               int B, int N) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = blockIdx.x * 4 + wave;
+  if (i >= N) return;
+  const float di = deg[i];
+  const float sq = sqrtf(di);
+  const float dhi = 1.f / (sq + 1e-7f);
+  float ddh = 0.f;
+  for (int j = lane; j < N; j += 64) {
+    const float s = 0.5f * (A[(size_t)i * N + j] + A[(size_t)j * N + i]);
+    const float qv = (i == j ? di : 0.f) - s;
+    const float dhj = 1.f / (sqrtf(deg[j]) + 1e-7f);
+    ddh += (dL[(size_t)i * N + j] + dL[(size_t)j * N + i]) * qv * dhj;
+  }
+  ddh = sg_wave_sum(ddh);
+  const float dd = -ddh * dhi * dhi / (2.f * sq) + dL[(size_t)i * N + i] * dhi * dhi;
+  const float invB = 1.f / (float)B;
+  for (int j = lane; j < N; j += 64) {
+    const float dhj = 1.f / (sqrtf(deg[j]) + 1e-7f);
+    const float dq = (dL[(size_t)i * N + j] + dL[(size_t)j * N + i]) * dhi * dhj;
+    dAB[(size_t)i * N + j] = (dd - 0.5f * dq) * invB;
+  }
+}
+
+// softmax / leaky-relu / dropout backward.  grid (B, nchunk); wave per row inside the chunk.
+// dynamic LDS: dq[4][N] + 1.
+__global__ __launch_bounds__(256) void sg_attention_bwd_kernel(
+    const float* __restrict__ dAB, const float* __restrict__ key, const float* __restrict__ query,
+    const float* __restrict__ rowsum, float alpha, float drop_p, int training, const uint64_t* __restrict__ seedp,
+    int B, int N, int nchunk, float* __restrict__ dkey, float* __restrict__ dqpart) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  __shared__ float wred[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.x, chunk = blockIdx.y;
+  const float* q = query + (size_t)b * N;
+  float m = -INFINITY;
+  for (int j = threadIdx.x; j < N; j += 256) m = fmaxf(m, q[j]);
+  m = sg_wave_max(m);
+  if (lane == 0) wred[wave] = m;
+  float* dq = smem + wave * N;
+  for (int j = lane; j < N; j += 64) dq[j] = 0.f;
+  __syncthreads();
+  const float qmax = fmaxf(fmaxf(wred[0], wred[1]), fmaxf(wred[2], wred[3]));
+  const bool drop = training && drop_p > 0.f;
+  uint64_t seed = 0, offset = 0;
+  if (drop) { seed = seedp[0]; offset = seedp[1]; }
+  const float keep_scale = drop ? 1.f / (1.f - drop_p) : 1.f;
+  const int rows = (N + nchunk - 1) / nchunk;
+  const int i_end = min(N, (chunk + 1) * rows);
+  for (int i = chunk * rows + wave; i < i_end; i += 4) {
+    const float kv = key[(size_t)b * N + i];
+    const float mx = sg_lrelu(kv + qmax, alpha);
+    const float inv = 1.f / rowsum[(size_t)b * N + i];
+    const float* dA = dAB + (size_t)i * N;
+    float dot = 0.f;
+    for (int j = lane; j < N; j += 64) {
+      const float p = expf(sg_lrelu(kv + q[j], alpha) - mx) * inv;
+      float dp = dA[j];
+      if (drop) dp = sg_keep(seed, offset, ((uint64_t)b * N + i) * N + j, drop_p) ? dp * keep_scale : 0.f;
+      dot += dp * p;
+    }
+    dot = sg_wave_sum(dot);
+    float dk = 0.f;
+    for (int j = lane; j < N; j += 64) {
+      const float pre = kv + q[j];
+      const float p = expf(sg_lrelu(pre, alpha) - mx) * inv;
+      float dp = dA[j];
+      if (drop) dp = sg_keep(seed, offset, ((uint64_t)b * N + i) * N + j, drop_p) ? dp * keep_scale : 0.f;
+      const float de = p * (dp - dot);
+      const float dpre = pre > 0.f ? de : alpha * de;
+      dk += dpre;
+      dq[j] += dpre;
+    }
+    dk = sg_wave_sum(dk);
+    if (lane == 0) dkey[(size_t)b * N + i] = dk;
+  }
+  __syncthreads();
+  float* out = dqpart + ((size_t)b * nchunk + chunk) * N;
+  for (int j = threadIdx.x; j < N; j += 256)
+    out[j] = (smem[j] + smem[N + j]) + (smem[2 * N + j] + smem[3 * N + j]);
+}
+
+__global__ void sg_dquery_reduce_kernel(const float* __restrict__ dqpart, float* __restrict__ dquery, int B, int N,
+                                        int nchunk) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (size_t)B * N) return;
+  const int b = (int)(idx / N), j = (int)(idx - (size_t)b * N);
+  float s = 0.f;
+  for (int c = 0; c < nchunk; ++c) s += dqpart[((size_t)b * nchunk + c) * N + j];
+  dquery[idx] = s;
+}
+
+// dh[s,b,i] = dkey[b,i] wk[s] + dquery[b,i] wq[s];  dwk[s] = sum_{b,i} dkey h ; dwq likewise.  One WG per s.
+__global__ __launch_bounds__(256) void sg_keyquery_bwd_kernel(const float* __restrict__ h, const float* __restrict__ wk,
+                                                              const float* __restrict__ wq, const float* __restrict__ dkey,
+                                                              const float* __restrict__ dquery, float* __restrict__ dh,
+                                                              float* __restrict__ dwk, float* __restrict__ dwq, int B, int N) {
+  __shared__ float red[4][2];
+  const int s = blockIdx.x;
+  const size_t BN = (size_t)B * N;
+  const float wks = wk[s], wqs = wq[s];
+  float ak = 0.f, aq = 0.f;
+  for (size_t e = threadIdx.x; e < BN; e += 256) {
+    const float dk = dkey[e], dqv = dquery[e];
+    const float hv = h[(size_t)s * BN + e];
+    dh[(size_t)s * BN + e] = dk * wks + dqv * wqs;
+    ak = fmaf(dk, hv, ak);
+    aq = fmaf(dqv, hv, aq);
+  }
+  ak = sg_wave_sum(ak);
+  aq = sg_wave_sum(aq);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) { red[wave][0] = ak; red[wave][1] = aq; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    dwk[s] = (red[0][0] + red[1][0]) + (red[2][0] + red[3][0]);
+    dwq[s] = (red[0][1] + red[1][1]) + (red[2][1] + red[3][1]);
+  }
+}
+
+__global__ void sg_dropout_mask_kernel(float drop_p, const uint64_t* __restrict__ seedp, size_t n, float* __restrict__ mask) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n) return;
+  mask[idx] = sg_keep(seedp[0], seedp[1], idx, drop_p) ? 1.f : 0.f;
+}
+
+// ---- Chebyshev basis on MFMA ----------------------------------------------------------------------------
+struct ChebFwdOp {  // out = 2 * L * Bm - (sub ? L : 0)
+  const float* L;
+  const float* Bm;
+  float* out;
+  int N, sub;
+  __device__ bool setup(int, int& M, int& Nn, int& K0, int& K1) const {
+    M = N; Nn = N; K0 = 0; K1 = N;
+    return true;
+  }
+  __device__ float a(int, int i, int k) const { return L[(size_t)i * N + k]; }
+  __device__ float b(int, int k, int j) const { return Bm[(size_t)k * N + j]; }
+  __device__ void epi(int, int i, int j, float v) const {
+    const size_t o = (size_t)i * N + j;
+    out[o] = sub ? 2.f * v - L[o] : 2.f * v;
+  }
+};
+
+// z=0: dLp = dT1 - dT3 + 2 dT3 T2^T ; z=1: dT2p = dT2 + 2 L^T dT3     
+struct ChebBwd1Op {
+  const float *L, *T2, *dT1, *dT2, *dT3;
+  float *dLp, *dT2p;
+  int N;
+  __device__ bool setup(int, int& M, int& Nn, int& K0, int& K1) const {
+    M = N; Nn = N; K0 = 0; K1 = N;
+    return true;
+  }
+  __device__ float a(int z, int i, int k) const { return z == 0 ? dT3[(size_t)i * N + k] : L[(size_t)k * N + i]; }
+  __device__ float b(int z, int k, int j) const { return z == 0 ? T2[(size_t)j * N + k] : dT3[(size_t)k * N + j]; }
+  __device__ void epi(int z, int i, int j, float v) const {
+    const size_t o = (size_t)i * N + j;
+    if (z == 0) dLp[o] = dT1[o] - dT3[o] + 2.f * v;
+    else dT2p[o] = dT2[o] + 2.f * v;
+  }
+};
+// dL = dLp + 2 (dT2p L^T + L^T dT2p)  as one GEMM with K = 2N
+struct ChebBwd2Op {
+  const float *L, *dT2p, *dLp;
+  float* dL;
+  int N;
+  __device__ bool setup(int, int& M, int& Nn, int& K0, int& K1) const {
+    M = N; Nn = N; K0 = 0; K1 = 2 * N;
+    return true;
+  }
+  __device__ float a(int, int i, int k) const { return k < N ? dT2p[(size_t)i * N + k] : L[(size_t)(k - N) * N + i]; }
+  __device__ float b(int, int k, int j) const { return k < N ? L[(size_t)j * N + k] : dT2p[(size_t)(k - N) * N + j]; }
+  __device__ void epi(int, int i, int j, float v) const {
+    const size_t o = (size_t)i * N + j;
+    dL[o] = dLp[o] + 2.f * v;
+  }
+};
+
+// =================================================================================================
+// host side
+// =================================================================================================
+extern "C" size_t stemgnn_attn_saved_floats(int B, int N) { return (size_t)3 * B * N + (size_t)N * N + N; }
+extern "C" size_t stemgnn_attn_scratch_floats(int B, int N, int nchunk) {
+  return (size_t)N * N + (size_t)2 * B * N + (size_t)B * nchunk * N;
+}
+
+extern "C" int stemgnn_attn_laplacian_fwd(const float* h, const float* wk, const float* wq, float alpha,
+                                          float drop_p, int training, const uint64_t* seed, int B, int N,
+                                          float* saved, float* attention_out, float* mul_L, void* stream) {
+  if (!h || !wk || !wq || !saved || !attention_out || !mul_L || B <= 0 || N <= 0) return SG_EINVAL;
+  if (training && drop_p > 0.f && !seed) return SG_EINVAL;
+  if (drop_p < 0.f || drop_p >= 1.f) return SG_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  float* key = saved;
+  float* query = key + (size_t)B * N;
+  float* rowsum = query + (size_t)B * N;
+  float* A = rowsum + (size_t)B * N;
+  float* deg = A + (size_t)N * N;
+  hipLaunchKernelGGL(sg_keyquery_kernel, dim3(B, (N + 63) / 64), dim3(256), 0, st, h, wk, wq, key, query, B, N);
+  SG_TRY(hipGetLastError());
+  const size_t lds = (size_t)(B + 4 * N) * sizeof(float);
+  if (lds > 150 * 1024) return SG_EINVAL;
+  hipLaunchKernelGGL(sg_attention_fwd_kernel, dim3((N + 3) / 4), dim3(256), lds, st, key, query, alpha, drop_p,
+                     training, seed, B, N, rowsum, A, deg);
+  SG_TRY(hipGetLastError());
+  hipLaunchKernelGGL(sg_laplacian_fwd_kernel, dim3((N + 31) / 32, (N + 31) / 32), dim3(256), 0, st, A, deg,
+                     attention_out, mul_L, N);
+  SG_TRY(hipGetLastError());
+  return 0;
+}
+
+extern "C" int stemgnn_attn_laplacian_bwd(const float* dL, const float* h, const float* wk, const float* wq,
+                                          float alpha, float drop_p, int training, const uint64_t* seed, int B, int N,
+                                          const float* saved, float* scratch, int nchunk, float* dh, float* dwk,
+                                          float* dwq, void* stream) {
+  if (!dL || !h || !wk || !wq || !saved || !scratch || !dh || !dwk || !dwq || B <= 0 || N <= 0 || nchunk <= 0)
+    return SG_EINVAL;
+  if (training && drop_p > 0.f && !seed) return SG_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const float* key = saved;
+  const float* query = key + (size_t)B * N;
+  const float* rowsum = query + (size_t)B * N;
+  const float* A = rowsum + (size_t)B * N;
+  const float* deg = A + (size_t)N * N;
+  float* dAB = scratch;
+  float* dkey = dAB + (size_t)N * N;
+  float* dquery = dkey + (size_t)B * N;
+  float* dqpart = dquery + (size_t)B * N;
+  hipLaunchKernelGGL(sg_laplacian_bwd_kernel, dim3((N + 3) / 4), dim3(256), 0, st, dL, A, deg, dAB, B, N);
+  SG_TRY(hipGetLastError());
+  const size_t lds = (size_t)(4 * N) * sizeof(float);
+  if (lds > 150 * 1024) return SG_EINVAL;
+  hipLaunchKernelGGL(sg_attention_bwd_kernel, dim3(B, nchunk), dim3(256), lds, st, dAB, key, query, rowsum, alpha,
+                     drop_p, training, seed, B, N, nchunk, dkey, dqpart);
+  SG_TRY(hipGetLastError());
+  const size_t bn = (size_t)B * N;
+  hipLaunchKernelGGL(sg_dquery_reduce_kernel, dim3((unsigned)((bn + 255) / 256)), dim3(256), 0, st, dqpart, dquery, B,
+                     N, nchunk);
+  SG_TRY(hipGetLastError());
+  hipLaunchKernelGGL(sg_keyquery_bwd_kernel, dim3(N), dim3(256), 0, st, h, wk, wq, dkey, dquery, dh, dwk, dwq, B, N);
+  SG_TRY(hipGetLastError());
+  return 0;
+}
+
+extern "C" int stemgnn_dropout_mask(float drop_p, const uint64_t* seed, int B, int N, float* mask, void* stream) {
+  if (!seed || !mask || B <= 0 || N <= 0) return SG_EINVAL;
+  const size_t n = (size_t)B * N * N;
+  hipLaunchKernelGGL(sg_dropout_mask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     drop_p, seed, n, mask);
+  SG_TRY(hipGetLastError());
+  return 0;
+}
+
+extern "C" int stemgnn_cheb_fwd(float* mul_L, int N, void* stream) {
+  if (!mul_L || N <= 0) return SG_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const size_t nn = (size_t)N * N;
+  float* L = mul_L + nn;
+  ChebFwdOp op2{L, L, mul_L + 2 * nn, N, 0};
+  SG_TRY((sg_launch_gemm<ChebFwdOp, 64, 64, true, false, false>(op2, N, N, 1, st)));
+  ChebFwdOp op3{L, mul_L + 2 * nn, mul_L + 3 * nn, N, 1};
+  SG_TRY((sg_launch_gemm<ChebFwdOp, 64, 64, true, false, false>(op3, N, N, 1, st)));
+  return 0;
+}
+
+extern "C" int stemgnn_cheb_bwd(const float* mul_L, const float* dmul_L, float* dL, float* scratch, int N,
+                                void* stream) {
+  if (!mul_L || !dmul_L || !dL || !scratch || N <= 0) return SG_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const size_t nn = (size_t)N * N;
+  float* dLp = scratch;
+  float* dT2p = scratch + nn;
+  ChebBwd1Op op1{mul_L + nn, mul_L + 2 * nn, dmul_L + nn, dmul_L + 2 * nn, dmul_L + 3 * nn, dLp, dT2p, N};
+  SG_TRY((sg_launch_gemm<ChebBwd1Op, 64, 64, true, true, false>(op1, N, N, 2, st)));
+  ChebBwd2Op op2{mul_L + nn, dT2p, dLp, dL, N};
+  SG_TRY((sg_launch_gemm<ChebBwd2Op, 64, 64, true, true, false>(op2, N, N, 1, st)));
+  return 0;
+}

@@ -1,0 +1,170 @@
+// Shared shape/layout arithmetic for the StemGNN spectral hot path (host + device).
+//
+// Notation: B batch, N nodes, W window (time_step), multi, Wm = W*multi,
+// C = 4*Wm (GLU width), M = B*N rows ("series"), KG = 3*W (GFT output width, Chebyshev
+// orders k=1..3; order 0 is identically zero, reference models/base_model.py:129).
+#pragma once
+#include <stddef.h>
+
+#ifdef __HIPCC__
+#define SG_HD __host__ __device__ __forceinline__
+#else
+#define SG_HD inline
+#endif
+
+SG_HD int sg_ceil16(int x) { return (x + 15) & ~15; }
+SG_HD int sg_ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+struct SgDims {
+  int B, N, W, multi;
+  int Wm;       // W*multi
+  int WmP;      // ceil16(Wm)
+  int C;        // 4*Wm
+  int CP;       // ceil16(C): padded channel count of GLU layers 0/1 outputs (= K of layers 1/2)
+  int KG;       // 3*W
+  int M;        // B*N
+  int nf[2];    // useful C2R bins per Chebyshev order: Re: floor(Wm/2)+1 (f=0..h); Im: ceil(Wm/2)-1 (f=1..)
+  int U[2];     // useful channels of the last GLU layer: 4*nf[r]
+  int CP2[2];   // ceil16(U[r])
+  int KF;       // CP2[0]+CP2[1]: K of the folded IGFT GEMM
+};
+
+SG_HD SgDims sg_dims(int B, int N, int W, int multi) {
+  SgDims d;
+  d.B = B; d.N = N; d.W = W; d.multi = multi;
+  d.Wm = W * multi;
+  d.WmP = sg_ceil16(d.Wm);
+  d.C = 4 * d.Wm;
+  d.CP = sg_ceil16(d.C);
+  d.KG = 3 * W;
+  d.M = B * N;
+  d.nf[0] = d.Wm / 2 + 1;
+  d.nf[1] = (d.Wm + 1) / 2 - 1;
+  for (int r = 0; r < 2; ++r) { d.U[r] = 4 * d.nf[r]; d.CP2[r] = sg_ceil16(d.U[r] > 0 ? d.U[r] : 1); }
+  d.KF = d.CP2[0] + d.CP2[1];
+  return d;
+}
+
+// ---- GLU layer geometry -------------------------------------------------------------------
+// layer l of branch r:  K_in(l) x NP(l,r) packed weight panel, "pair" column order:
+// packed column q = (c/16)*32 + (c%16)        holds linear_left  output channel cmap(c)
+//               q = (c/16)*32 + 16 + (c%16)   holds linear_right output channel cmap(c)
+SG_HD int sg_glu_kin(const SgDims& d, int l) { return l == 0 ? d.KG : d.CP; }
+SG_HD int sg_glu_cp(const SgDims& d, int l, int r) { return l < 2 ? d.CP : d.CP2[r]; }   // padded out channels
+SG_HD int sg_glu_cu(const SgDims& d, int l, int r) { return l < 2 ? d.C : d.U[r]; }      // useful out channels
+SG_HD int sg_glu_np(const SgDims& d, int l, int r) { return 2 * sg_glu_cp(d, l, r); }
+
+// last-layer useful channel c (0..U[r]) -> original channel k'*Wm + f of GLUs[4+r]
+SG_HD int sg_l2_orig_channel(const SgDims& d, int r, int c) {
+  int kq = c / d.nf[r], f = c % d.nf[r] + (r == 1 ? 1 : 0);
+  return kq * d.Wm + f;
+}
+
+// ---- packed-weights buffer of one StockBlock (floats) -----------------------------------------
+// [r=0..1][l=0..2]: Wp (K_in x NP) then bias (NP)   ;  then Wfold (KF x WmP)
+struct SgPackedLayout {
+  size_t w[2][3], b[2][3], wfold, total;
+};
+SG_HD SgPackedLayout sg_packed_layout(const SgDims& d) {
+  SgPackedLayout L;
+  size_t off = 0;
+  for (int r = 0; r < 2; ++r)
+    for (int l = 0; l < 3; ++l) {
+      L.w[r][l] = off; off += (size_t)sg_glu_kin(d, l) * sg_glu_np(d, l, r);
+      L.b[r][l] = off; off += (size_t)sg_glu_np(d, l, r);
+    }
+  L.wfold = off; off += (size_t)d.KF * d.WmP;
+  L.total = off;
+  return L;
+}
+
+// ---- gradient partial sums (split over the M rows; reduced by the unpack kernel) -------------
+// every weight gradient is produced as  rows = the weight's OUT channels, cols = IN channels + 1
+// (the extra column is the bias gradient), one slab per split:
+//   GLU (r,l): nsplit x NP(l,r) x (K_in(l)+1)       (rows follow the packed "pair" column order)
+//   FR: nsplit x W x (Wm+1)   F: nsplit x Wm x (Wm+1)   BC: nsplit x W x (Wm+1)   BS: nsplit x W x (W+1)
+//   Wfold: nsplit x KF x WmP  ([k][o] orientation, unfolded through the C2R table by the unpack kernel)
+struct SgGradLayout {
+  size_t w[2][3];
+  size_t wfold, fr, fc, bc, bs;
+  size_t total;
+  int nsplit;
+};
+SG_HD SgGradLayout sg_grad_layout(const SgDims& d, int nsplit) {
+  SgGradLayout L;
+  L.nsplit = nsplit;
+  size_t off = 0, S = (size_t)nsplit;
+  for (int r = 0; r < 2; ++r)
+    for (int l = 0; l < 3; ++l) {
+      L.w[r][l] = off; off += S * sg_glu_np(d, l, r) * (sg_glu_kin(d, l) + 1);
+    }
+  L.wfold = off; off += S * d.KF * d.WmP;
+  L.fr = off; off += S * d.W * (d.Wm + 1);
+  L.fc = off; off += S * d.Wm * (d.Wm + 1);
+  L.bc = off; off += S * d.W * (d.Wm + 1);
+  L.bs = off; off += S * d.W * (d.W + 1);
+  L.total = off;
+  return L;
+}
+
+// ---- saved activations of one StockBlock forward (floats) ------------------------------------
+struct SgSavedLayout {
+  size_t G;              // M x KG
+  size_t out[2][3];      // M x CP(l,r)   GLU output (= next layer's input)
+  size_t gate[2][3];     // M x CP(l,r)   sigmoid(right)
+  size_t ig;             // M x Wm
+  size_t fs;             // M x Wm
+  size_t total;
+};
+SG_HD SgSavedLayout sg_saved_layout(const SgDims& d) {
+  SgSavedLayout L;
+  size_t off = 0, M = (size_t)d.M;
+  L.G = off; off += M * d.KG;
+  for (int r = 0; r < 2; ++r)
+    for (int l = 0; l < 3; ++l) {
+      L.out[r][l] = off; off += M * sg_glu_cp(d, l, r);
+      L.gate[r][l] = off; off += M * sg_glu_cp(d, l, r);
+    }
+  L.ig = off; off += M * d.Wm;
+  L.fs = off; off += M * d.Wm;
+  L.total = off;
+  return L;
+}
+
+// ---- backward scratch of one StockBlock (floats) ------------------------------------------------
+struct SgScratchLayout {
+  size_t dpF;            // M x Wm
+  size_t dpB;            // M x W
+  size_t dig;            // M x Wm
+  size_t dact[2][2];     // ping-pong M x CP per branch: d(out of layer l)
+  size_t dG;             // M x KG
+  size_t total;
+};
+SG_HD SgScratchLayout sg_scratch_layout(const SgDims& d) {
+  SgScratchLayout L;
+  size_t off = 0, M = (size_t)d.M;
+  L.dpF = off; off += M * d.Wm;
+  L.dpB = off; off += M * d.W;
+  L.dig = off; off += M * d.Wm;
+  for (int r = 0; r < 2; ++r)
+    for (int p = 0; p < 2; ++p) { L.dact[r][p] = off; off += M * d.CP; }
+  L.dG = off; off += M * d.KG;
+  L.total = off;
+  return L;
+}
+
+// ---- constant DFT tables (floats), built on the host in double precision -----------------------
+// cosW[t*W+f], sinW[t*W+f] (f,t < W); cinvR[f*Wm+tau] (f < nf[0]); cinvI[f*Wm+tau] (f < nf[1], bin f+1)
+struct SgTableLayout {
+  size_t cosW, sinW, cinvR, cinvI, total;
+};
+SG_HD SgTableLayout sg_table_layout(const SgDims& d) {
+  SgTableLayout L;
+  size_t off = 0;
+  L.cosW = off; off += (size_t)d.W * d.W;
+  L.sinW = off; off += (size_t)d.W * d.W;
+  L.cinvR = off; off += (size_t)d.nf[0] * d.Wm;
+  L.cinvI = off; off += (size_t)(d.nf[1] > 0 ? d.nf[1] : 0) * d.Wm;
+  L.total = off;
+  return L;
+}

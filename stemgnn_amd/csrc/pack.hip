@@ -1,0 +1,305 @@
+// Weight packing / gradient un-packing for one StockBlock, constant DFT tables, size queries.
+//
+// pack   : reference parameter tensors -> K-major "pair" GLU panels with
+//            * the length-W forward DFT (models/base_model.py:49-51) folded into GLU layer 0,
+//            * the dead C2R bins of the last GLU layer dropped,
+//            * the C2R inverse DFT (:58) folded into the graph-conv weight (:66-67)  -> Wfold.
+// unpack : the exact adjoint -- reduces the split-M partial slabs and scatters them into tensors
+//          shaped like the reference parameters (dead rows / k=0 columns get exact zeros, as the
+//          reference's autograd gives them).
+#include <hip/hip_runtime.h>
+#include <math.h>
+
+#include "../../include/stemgnn_hip.h"
+#include "layout.h"
+
+#define SG_TRY(e)                                \
+  do {                                           \
+    hipError_t _e = (e);                         \
+    if (_e != hipSuccess) return -(int)_e;       \
+  } while (0)
+
+struct SgBlockParams { const float* p[SG_BLOCK_NPARAMS]; };
+struct SgBlockGrads { float* p[SG_BLOCK_NPARAMS]; };
+
+__host__ __device__ inline int sg_pidx_glu(int g, int side, int bias) { return 9 + 4 * g + 2 * side + bias; }
+
+// ---- tables -------------------------------------------------------------------------------------------
+static void exact_cos_sin(long idx, long n, double* c, double* s) {
+  idx %= n;
+  if ((4 * idx) % n == 0) {
+    static const double cs[4] = {1, 0, -1, 0}, sn[4] = {0, 1, 0, -1};
+    const long qd = 4 * idx / n;
+    *c = cs[qd]; *s = sn[qd];
+    return;
+  }
+  const double ang = 2.0 * M_PI * (double)idx / (double)n;
+  *c = cos(ang); *s = sin(ang);
+}
+
+extern "C" int stemgnn_make_tables_host(int W, int multi, float* t) {
+  if (W <= 0 || multi <= 0 || !t) return SG_EINVAL;
+  const SgDims d = sg_dims(1, 1, W, multi);
+  const SgTableLayout L = sg_table_layout(d);
+  for (int tt = 0; tt < W; ++tt)
+    for (int f = 0; f < W; ++f) {
+      double c, s;
+      exact_cos_sin((long)tt * f, W, &c, &s);
+      t[L.cosW + tt * W + f] = (float)c;
+      t[L.sinW + tt * W + f] = (float)s;
+    }
+  const int Wm = d.Wm, h = Wm / 2;
+  // C2R inverse: y_tau = (1/Wm)[sum_f c_f Re_f cos - sum_f s_f Im_f sin]
+  for (int f = 0; f < d.nf[0]; ++f) {
+    const double cf = (f == 0 || (Wm % 2 == 0 && f == h)) ? 1.0 : 2.0;
+    for (int tau = 0; tau < Wm; ++tau) {
+      double c, s;
+      exact_cos_sin((long)f * tau, Wm, &c, &s);
+      t[L.cinvR + (size_t)f * Wm + tau] = (float)(cf * c / Wm);
+    }
+  }
+  for (int fi = 0; fi < d.nf[1]; ++fi) {
+    const int f = fi + 1;
+    for (int tau = 0; tau < Wm; ++tau) {
+      double c, s;
+      exact_cos_sin((long)f * tau, Wm, &c, &s);
+      t[L.cinvI + (size_t)fi * Wm + tau] = (float)(-2.0 * s / Wm);
+    }
+  }
+  return 0;
+}
+
+// ---- sizes ------------------------------------------------------------------------------------------------
+extern "C" const char* stemgnn_version(void) { return "stemgnn_hip 0.1 gfx950"; }
+extern "C" size_t stemgnn_table_floats(int W, int multi) { return sg_table_layout(sg_dims(1, 1, W, multi)).total; }
+extern "C" size_t stemgnn_packed_floats(int W, int multi) { return sg_packed_layout(sg_dims(1, 1, W, multi)).total; }
+extern "C" size_t stemgnn_saved_floats(int B, int N, int W, int multi) { return sg_saved_layout(sg_dims(B, N, W, multi)).total; }
+extern "C" size_t stemgnn_scratch_floats(int B, int N, int W, int multi) { return sg_scratch_layout(sg_dims(B, N, W, multi)).total; }
+extern "C" size_t stemgnn_scratch_offset_dG(int B, int N, int W, int multi) { return sg_scratch_layout(sg_dims(B, N, W, multi)).dG; }
+extern "C" size_t stemgnn_gradpart_floats(int W, int multi, int nsplit) {
+  return sg_grad_layout(sg_dims(1, 1, W, multi), nsplit).total;
+}
+
+// ---- pack ---------------------------------------------------------------------------------------------------
+__global__ void sg_pack_kernel(SgBlockParams prm, const float* __restrict__ tab, float* __restrict__ packed, SgDims d,
+                               SgPackedLayout P, SgTableLayout T) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= P.total) return;
+  const int W = d.W, Wm = d.Wm, C = d.C;
+  float val = 0.f;
+  if (idx >= P.wfold) {
+    const size_t e = idx - P.wfold;
+    const int kk = (int)(e / d.WmP), o = (int)(e - (size_t)kk * d.WmP);
+    const int r = kk >= d.CP2[0];
+    const int c = kk - (r ? d.CP2[0] : 0);
+    if (c < d.U[r] && o < Wm) {
+      const int kq = c / d.nf[r], fi = c - kq * d.nf[r];
+      const float* cinv = tab + (r ? T.cinvI : T.cinvR) + (size_t)fi * Wm;
+      const float* wt = prm.p[0] + (size_t)kq * Wm * Wm + o;
+      float s = 0.f;
+      for (int tau = 0; tau < Wm; ++tau) s = fmaf(cinv[tau], wt[(size_t)tau * Wm], s);
+      val = s;
+    }
+    packed[idx] = val;
+    return;
+  }
+  for (int r = 0; r < 2; ++r)
+    for (int l = 0; l < 3; ++l) {
+      const int np = sg_glu_np(d, l, r), kin = sg_glu_kin(d, l), cu = sg_glu_cu(d, l, r);
+      const int g = 2 * l + r;
+      if (idx >= P.w[r][l] && idx < P.w[r][l] + (size_t)kin * np) {
+        const size_t e = idx - P.w[r][l];
+        const int kk = (int)(e / np), q = (int)(e - (size_t)kk * np);
+        const int c = ((q >> 5) << 4) + (q & 15), side = (q >> 4) & 1;
+        if (c < cu) {
+          const int ch = l < 2 ? c : sg_l2_orig_channel(d, r, c);
+          const float* w = prm.p[sg_pidx_glu(g, side, 0)];
+          if (l == 0) {
+            const int kq = kk / W + 1, t = kk - (kq - 1) * W;
+            const float* row = w + (size_t)ch * (4 * W) + kq * W;
+            const float* dt = tab + (r ? T.sinW : T.cosW) + t * W;
+            float s = 0.f;
+            for (int f = 0; f < W; ++f) s = fmaf(dt[f], row[f], s);
+            val = r ? -s : s;
+          } else if (kk < C) {
+            val = w[(size_t)ch * C + kk];
+          }
+        }
+        packed[idx] = val;
+        return;
+      }
+      if (idx >= P.b[r][l] && idx < P.b[r][l] + (size_t)np) {
+        const int q = (int)(idx - P.b[r][l]);
+        const int c = ((q >> 5) << 4) + (q & 15), side = (q >> 4) & 1;
+        if (c < cu) {
+          const int ch = l < 2 ? c : sg_l2_orig_channel(d, r, c);
+          val = prm.p[sg_pidx_glu(g, side, 1)][ch];
+        }
+        packed[idx] = val;
+        return;
+      }
+    }
+}
+
+extern "C" int stemgnn_block_pack(const float* const* params_host, const float* tables, float* packed, int W,
+                                  int multi, void* stream) {
+  if (!params_host || !tables || !packed || W <= 0 || multi <= 0) return SG_EINVAL;
+  SgBlockParams prm;
+  for (int i = 0; i < SG_BLOCK_NPARAMS; ++i) prm.p[i] = params_host[i];
+  for (int i = 0; i < SG_BLOCK_NPARAMS; ++i)
+    if (!prm.p[i] && i != 5 && i != 6) return SG_EINVAL;
+  const SgDims d = sg_dims(1, 1, W, multi);
+  const SgPackedLayout P = sg_packed_layout(d);
+  const SgTableLayout T = sg_table_layout(d);
+  const unsigned blocks = (unsigned)((P.total + 255) / 256);
+  hipLaunchKernelGGL(sg_pack_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, prm, tables, packed, d, P, T);
+  SG_TRY(hipGetLastError());
+  return 0;
+}
+
+// ---- unpack -------------------------------------------------------------------------------------------------
+struct SgRegions {   // slab table for the split reduction
+  size_t off[11];
+  size_t slab[11];
+  size_t prefix[12];
+  int n;
+};
+
+// slab 0 += sum_{s>=1} slab s, for every region (deterministic order)
+__global__ void sg_reduce_splits_kernel(float* __restrict__ part, SgRegions R, int nsplit) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= R.prefix[R.n]) return;
+  int g = 0;
+  while (g + 1 < R.n && idx >= R.prefix[g + 1]) ++g;
+  const size_t e = idx - R.prefix[g];
+  float* base = part + R.off[g] + e;
+  float s = base[0];
+  for (int k = 1; k < nsplit; ++k) s += base[(size_t)k * R.slab[g]];
+  base[0] = s;
+}
+
+struct SgParamOffsets { size_t prefix[SG_BLOCK_NPARAMS + 1]; };
+
+__global__ void sg_unpack_kernel(const float* __restrict__ part, const float* __restrict__ tab, SgBlockGrads gr,
+                                 SgParamOffsets PO, SgDims d, SgGradLayout G, SgTableLayout T, int has_bc) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= PO.prefix[SG_BLOCK_NPARAMS]) return;
+  int pi = 0;
+  while (pi + 1 < SG_BLOCK_NPARAMS && idx >= PO.prefix[pi + 1]) ++pi;
+  float* out = gr.p[pi];
+  if (!out) return;
+  const size_t e = idx - PO.prefix[pi];
+  const int W = d.W, Wm = d.Wm, C = d.C;
+  float val = 0.f;
+  if (pi == 0) {  // graph-conv weight [4][Wm][Wm]: adjoint of the C2R fold
+    const int kq = (int)(e / ((size_t)Wm * Wm));
+    const int rem = (int)(e - (size_t)kq * Wm * Wm);
+    const int tau = rem / Wm, o = rem - tau * Wm;
+    const float* wf = part + G.wfold;
+    float s = 0.f;
+    for (int f = 0; f < d.nf[0]; ++f)
+      s = fmaf(tab[T.cinvR + (size_t)f * Wm + tau], wf[(size_t)(kq * d.nf[0] + f) * d.WmP + o], s);
+    for (int f = 0; f < d.nf[1]; ++f)
+      s = fmaf(tab[T.cinvI + (size_t)f * Wm + tau], wf[(size_t)(d.CP2[0] + kq * d.nf[1] + f) * d.WmP + o], s);
+    val = s;
+  } else if (pi <= 8) {
+    const int isb = (pi - 1) & 1;             // 1,3,5,7 weights; 2,4,6,8 biases
+    const int which = (pi - 1) >> 1;          // 0 forecast, 1 forecast_result, 2 backcast, 3 short-cut
+    if (which >= 2 && !has_bc) { out[e] = 0.f; return; }
+    const float* p; int in;
+    switch (which) {
+      case 0: p = part + G.fc; in = Wm; break;
+      case 1: p = part + G.fr; in = Wm; break;
+      case 2: p = part + G.bc; in = Wm; break;
+      default: p = part + G.bs; in = W; break;
+    }
+    if (isb) val = p[e * (in + 1) + in];
+    else { const size_t o = e / in; val = p[o * (in + 1) + (e - o * in)]; }
+  } else {
+    const int gq = (pi - 9) >> 2, rem = (pi - 9) & 3, side = rem >> 1, isb = rem & 1;
+    const int l = gq >> 1, r = gq & 1;
+    const int kin = sg_glu_kin(d, l), cin = l == 0 ? 4 * W : C;
+    const int ch = isb ? (int)e : (int)(e / cin);
+    const int ki = isb ? 0 : (int)(e - (size_t)ch * cin);
+    int c = ch;
+    bool live = true;
+    if (l == 2) {
+      const int kq = ch / Wm, f = ch - kq * Wm;
+      const int fi = f - (r ? 1 : 0);
+      live = fi >= 0 && fi < d.nf[r];
+      c = kq * d.nf[r] + fi;
+    }
+    if (live) {
+      const int q = ((c >> 4) << 5) + (c & 15) + (side ? 16 : 0);
+      const float* row = part + G.w[r][l] + (size_t)q * (kin + 1);
+      if (isb) val = row[kin];
+      else if (l == 0) {
+        const int kq = ki / W, f = ki - kq * W;
+        if (kq > 0) {
+          const float* dt = tab + (r ? T.sinW : T.cosW);
+          float s = 0.f;
+          for (int t = 0; t < W; ++t) s = fmaf(dt[t * W + f], row[(kq - 1) * W + t], s);
+          val = r ? -s : s;
+        }
+      } else {
+        val = row[ki];
+      }
+    }
+  }
+  out[e] = val;
+}
+
+extern "C" int stemgnn_block_unpack_grads(const float* gradpart, int nsplit, const float* tables,
+                                          float* const* grads_host, int W, int multi, int has_backcast,
+                                          void* stream) {
+  if (!gradpart || !tables || !grads_host || nsplit <= 0 || W <= 0 || multi <= 0) return SG_EINVAL;
+  const SgDims d = sg_dims(1, 1, W, multi);
+  const SgGradLayout G = sg_grad_layout(d, nsplit);
+  const SgTableLayout T = sg_table_layout(d);
+  hipStream_t st = (hipStream_t)stream;
+  if (nsplit > 1) {
+    SgRegions R;
+    int n = 0;
+    for (int r = 0; r < 2; ++r)
+      for (int l = 0; l < 3; ++l) {
+        R.off[n] = G.w[r][l];
+        R.slab[n] = (size_t)sg_glu_np(d, l, r) * (sg_glu_kin(d, l) + 1);
+        ++n;
+      }
+    R.off[n] = G.wfold; R.slab[n] = (size_t)d.KF * d.WmP; ++n;
+    R.off[n] = G.fr; R.slab[n] = (size_t)d.W * (d.Wm + 1); ++n;
+    R.off[n] = G.fc; R.slab[n] = (size_t)d.Wm * (d.Wm + 1); ++n;
+    if (has_backcast) {
+      R.off[n] = G.bc; R.slab[n] = (size_t)d.W * (d.Wm + 1); ++n;
+      R.off[n] = G.bs; R.slab[n] = (size_t)d.W * (d.W + 1); ++n;
+    }
+    R.n = n;
+    R.prefix[0] = 0;
+    for (int i = 0; i < n; ++i) R.prefix[i + 1] = R.prefix[i] + R.slab[i];
+    const unsigned blocks = (unsigned)((R.prefix[n] + 255) / 256);
+    hipLaunchKernelGGL(sg_reduce_splits_kernel, dim3(blocks), dim3(256), 0, st, const_cast<float*>(gradpart), R, nsplit);
+    SG_TRY(hipGetLastError());
+  }
+  SgBlockGrads gr;
+  for (int i = 0; i < SG_BLOCK_NPARAMS; ++i) gr.p[i] = grads_host[i];
+  SgParamOffsets PO;
+  size_t sizes[SG_BLOCK_NPARAMS];
+  const size_t Wm = d.Wm, Wz = d.W, C = d.C;
+  sizes[0] = 4 * Wm * Wm;
+  sizes[1] = Wm * Wm; sizes[2] = Wm;
+  sizes[3] = Wz * Wm; sizes[4] = Wz;
+  sizes[5] = Wz * Wm; sizes[6] = Wz;
+  sizes[7] = Wz * Wz; sizes[8] = Wz;
+  for (int g = 0; g < 6; ++g)
+    for (int side = 0; side < 2; ++side) {
+      sizes[sg_pidx_glu(g, side, 0)] = C * (g < 2 ? 4 * Wz : C);
+      sizes[sg_pidx_glu(g, side, 1)] = C;
+    }
+  PO.prefix[0] = 0;
+  for (int i = 0; i < SG_BLOCK_NPARAMS; ++i) PO.prefix[i + 1] = PO.prefix[i] + sizes[i];
+  const unsigned blocks = (unsigned)((PO.prefix[SG_BLOCK_NPARAMS] + 255) / 256);
+  hipLaunchKernelGGL(sg_unpack_kernel, dim3(blocks), dim3(256), 0, st, gradpart, tables, gr, PO, d, G, T,
+                     has_backcast);
+  SG_TRY(hipGetLastError());
+  return 0;
+}

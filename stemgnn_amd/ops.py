@@ -1,0 +1,171 @@
+"""Host-side composition of the HIP stages into one autograd function.
+
+PyTorch is plumbing here: it owns device memory (torch.empty), the current HIP stream and the
+autograd graph; every number on the hot path is produced by libstemgnn_hip.so.
+
+Stage order (reference models/base_model.py): attention+Laplacian (:139-147) -> Chebyshev (:148)
+-> per StockBlock: pack, GFT (:62-64), spectral GLU (:46-54), IGFT+heads (:55-58, :65-74).
+"""
+import os
+
+import torch
+
+from . import _lib
+
+_NSPLIT = int(os.environ.get("STEMGNN_NSPLIT", "8"))      # split-M factor of the weight-gradient GEMMs
+_NCHUNK = int(os.environ.get("STEMGNN_ATTN_CHUNKS", "4"))  # row chunks of the attention backward
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _require_gpu(t, name):
+    if not t.is_cuda:
+        raise _lib.StemGNNHipError(
+            f"{name} is on {t.device}: stemgnn_amd runs only on a HIP device (no CPU fallback)")
+    if t.dtype != torch.float32:
+        raise _lib.StemGNNHipError(f"{name} must be float32, got {t.dtype}")
+
+
+_table_cache = {}
+
+
+def dft_tables(W, multi, device):
+    """Constant DFT / C2R tables for (W, multi), built once on the host by the library."""
+    key = (W, multi, str(device))
+    t = _table_cache.get(key)
+    if t is None:
+        lib = _lib.load()
+        n = lib.stemgnn_table_floats(W, multi)
+        host = torch.empty(n, dtype=torch.float32)
+        _lib.check(lib.stemgnn_make_tables_host(W, multi, host.data_ptr()), "make_tables_host")
+        t = host.to(device)
+        _table_cache[key] = t
+    return t
+
+
+def dropout_mask(drop_p, seed, B, N):
+    """Test hook: the 0/1 keep mask [B,N,N] the attention kernels regenerate from `seed` (uint64[2])."""
+    lib = _lib.load()
+    mask = torch.empty(B, N, N, device=seed.device, dtype=torch.float32)
+    _lib.check(lib.stemgnn_dropout_mask(float(drop_p), seed.data_ptr(), B, N, mask.data_ptr(), _stream()),
+               "dropout_mask")
+    return mask
+
+
+class SpectralHotPath(torch.autograd.Function):
+    """(h, x, weight_key, weight_query, 33 params of block 0, 33 params of block 1) ->
+    (sum of the two block forecasts [B,N,W], attention [N,N], mul_L [4,N,N]).
+
+    h is the GRU output [N_seq, B, N_hid] exactly as nn.GRU returns it; x is the model input [B,W,N].
+    """
+
+    @staticmethod
+    def forward(ctx, h, x, wk, wq, multi, alpha, drop_p, training, seed, *block_params):
+        lib = _lib.load()
+        for name, t in (("gru output", h), ("x", x), ("weight_key", wk), ("weight_query", wq)):
+            _require_gpu(t, name)
+        assert len(block_params) == 2 * _lib.SG_BLOCK_NPARAMS
+        h = h.contiguous()
+        x = x.contiguous()
+        B, W, N = x.shape
+        if h.shape != (N, B, N):
+            raise _lib.StemGNNHipError(f"gru output must be [N,B,N]=({N},{B},{N}), got {tuple(h.shape)}")
+        dev, f32 = x.device, torch.float32
+        st = _stream()
+        M = B * N
+        blocks = [list(block_params[:33]), list(block_params[33:])]
+        blocks = [[None if p is None else p.contiguous() for p in blk] for blk in blocks]
+        tables = dft_tables(W, multi, dev)
+
+        mul_L = torch.empty(4, N, N, device=dev, dtype=f32)
+        attention = torch.empty(N, N, device=dev, dtype=f32)
+        attn_saved = torch.empty(lib.stemgnn_attn_saved_floats(B, N), device=dev, dtype=f32)
+        use_drop = bool(training) and drop_p > 0.0
+        _lib.check(lib.stemgnn_attn_laplacian_fwd(
+            h.data_ptr(), wk.data_ptr(), wq.data_ptr(), float(alpha), float(drop_p), int(bool(training)),
+            seed.data_ptr() if use_drop else None, B, N, attn_saved.data_ptr(), attention.data_ptr(),
+            mul_L.data_ptr(), st), "attn_laplacian_fwd")
+        _lib.check(lib.stemgnn_cheb_fwd(mul_L.data_ptr(), N, st), "cheb_fwd")
+
+        fsum = torch.empty(B, N, W, device=dev, dtype=f32)
+        backcast = torch.empty(B, N, W, device=dev, dtype=f32)
+        packed, saved = [], []
+        n_packed = lib.stemgnn_packed_floats(W, multi)
+        n_saved = lib.stemgnn_saved_floats(B, N, W, multi)
+        xviews = [(x, W * N, 1, N), (backcast, N * W, W, 1)]   # X[b,n,t] strides of block 0 / block 1
+        for s in range(2):
+            pk = torch.empty(n_packed, device=dev, dtype=f32)
+            sv = torch.empty(n_saved, device=dev, dtype=f32)
+            parr = _lib.ptr_array(blocks[s])
+            X, sb, sn, stt = xviews[s]
+            _lib.check(lib.stemgnn_block_pack(parr, tables.data_ptr(), pk.data_ptr(), W, multi, st), "block_pack")
+            _lib.check(lib.stemgnn_gft_fwd(mul_L.data_ptr(), X.data_ptr(), sb, sn, stt, sv.data_ptr(), B, N, W, st),
+                       "gft_fwd")
+            _lib.check(lib.stemgnn_spectral_glu_fwd(pk.data_ptr(), sv.data_ptr(), B, N, W, multi, st),
+                       "spectral_glu_fwd")
+            _lib.check(lib.stemgnn_igft_heads_fwd(
+                parr, pk.data_ptr(), sv.data_ptr(), X.data_ptr(), sb, sn, stt, fsum.data_ptr(), int(s == 1),
+                backcast.data_ptr() if s == 0 else None, B, N, W, multi, st), "igft_heads_fwd")
+            packed.append(pk)
+            saved.append(sv)
+
+        ctx.dims = (B, N, W, multi, float(alpha), float(drop_p), bool(training))
+        ctx.blocks = blocks
+        ctx.aux = (h, x, wk, wq, seed, tables, mul_L, attn_saved, backcast, packed, saved)
+        ctx.mark_non_differentiable(attention, mul_L)
+        return fsum, attention, mul_L
+
+    @staticmethod
+    def backward(ctx, dfsum, _datt, _dmulL):
+        lib = _lib.load()
+        B, N, W, multi, alpha, drop_p, training = ctx.dims
+        h, x, wk, wq, seed, tables, mul_L, attn_saved, backcast, packed, saved = ctx.aux
+        blocks = ctx.blocks
+        dev, f32 = x.device, torch.float32
+        st = _stream()
+        dfsum = dfsum.contiguous()
+        nsplit = _NSPLIT
+        scratch = torch.empty(lib.stemgnn_scratch_floats(B, N, W, multi), device=dev, dtype=f32)
+        dG = scratch[lib.stemgnn_scratch_offset_dG(B, N, W, multi):]
+        gradpart = torch.empty(lib.stemgnn_gradpart_floats(W, multi, nsplit), device=dev, dtype=f32)
+        dmul_L = torch.empty(4, N, N, device=dev, dtype=f32)
+        dbackcast = torch.empty(B, N, W, device=dev, dtype=f32)
+        xviews = [(x, W * N, 1, N), (backcast, N * W, W, 1)]
+        grads = [[None] * 33, [None] * 33]
+        for s in (1, 0):
+            parr = _lib.ptr_array(blocks[s])
+            X, sb, sn, stt = xviews[s]
+            has_bc = s == 0
+            _lib.check(lib.stemgnn_igft_heads_bwd(
+                parr, packed[s].data_ptr(), saved[s].data_ptr(), X.data_ptr(), sb, sn, stt, dfsum.data_ptr(),
+                dbackcast.data_ptr() if has_bc else None, backcast.data_ptr() if has_bc else None,
+                scratch.data_ptr(), gradpart.data_ptr(), nsplit, B, N, W, multi, st), "igft_heads_bwd")
+            _lib.check(lib.stemgnn_spectral_glu_bwd(
+                packed[s].data_ptr(), saved[s].data_ptr(), scratch.data_ptr(), gradpart.data_ptr(), nsplit,
+                B, N, W, multi, st), "spectral_glu_bwd")
+            _lib.check(lib.stemgnn_gft_bwd(
+                mul_L.data_ptr(), X.data_ptr(), sb, sn, stt, dG.data_ptr(),
+                dbackcast.data_ptr() if s == 1 else None, dmul_L.data_ptr(), int(s == 0), B, N, W, st), "gft_bwd")
+            for i, p in enumerate(blocks[s]):
+                if p is None or (not has_bc and i in (7, 8)):   # block 1's short-cut is unused (:73-74) -> grad None
+                    continue
+                grads[s][i] = torch.empty_like(p)
+            _lib.check(lib.stemgnn_block_unpack_grads(
+                gradpart.data_ptr(), nsplit, tables.data_ptr(), _lib.ptr_array(grads[s]), W, multi, int(has_bc), st),
+                "block_unpack_grads")
+        dL = torch.empty(N, N, device=dev, dtype=f32)
+        cheb_scratch = torch.empty(2 * N * N, device=dev, dtype=f32)
+        _lib.check(lib.stemgnn_cheb_bwd(mul_L.data_ptr(), dmul_L.data_ptr(), dL.data_ptr(), cheb_scratch.data_ptr(),
+                                        N, st), "cheb_bwd")
+        dh = torch.empty_like(h)
+        dwk = torch.empty_like(wk)
+        dwq = torch.empty_like(wq)
+        attn_scratch = torch.empty(lib.stemgnn_attn_scratch_floats(B, N, _NCHUNK), device=dev, dtype=f32)
+        use_drop = training and drop_p > 0.0
+        _lib.check(lib.stemgnn_attn_laplacian_bwd(
+            dL.data_ptr(), h.data_ptr(), wk.data_ptr(), wq.data_ptr(), alpha, drop_p, int(training),
+            seed.data_ptr() if use_drop else None, B, N, attn_saved.data_ptr(), attn_scratch.data_ptr(), _NCHUNK,
+            dh.data_ptr(), dwk.data_ptr(), dwq.data_ptr(), st), "attn_laplacian_bwd")
+        return (dh, None, dwk, dwq, None, None, None, None, None, *grads[0], *grads[1])

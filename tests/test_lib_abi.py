@@ -1,0 +1,104 @@
+"""CPU: the C-ABI library builds for gfx950, loads, and exports every symbol include/stemgnn_hip.h declares.
+No compute is launched (there is no GPU in the build container)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "stemgnn_hip.h")
+
+
+def declared_symbols():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(stemgnn_[a-zA-Z0-9_]+)\s*\(", src)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from stemgnn_amd import _lib
+
+    if not os.path.isfile(_lib.LIB_PATH):
+        import __graft_entry__
+
+        __graft_entry__.build()
+    return _lib.load()
+
+
+def test_header_symbols_exported(lib):
+    from stemgnn_amd import _lib
+
+    names = declared_symbols()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/stemgnn_hip.h but not exported"
+        assert n in _lib.SIGNATURES, f"{n} has no ctypes signature in stemgnn_amd/_lib.py"
+    assert set(_lib.SIGNATURES) == set(names)
+
+
+def test_version_and_sizes(lib):
+    assert b"gfx950" in lib.stemgnn_version()
+    # PEMS07 shape: W=12, multi=5 -> GLU panels 36x480, 240x480, 240x480, 240x256 ... (layout.h)
+    n = lib.stemgnn_packed_floats(12, 5)
+    expect = 2 * (36 * 480 + 480 + 240 * 480 + 480) + (240 * 256 + 256) * 2 + 256 * 64
+    assert n == expect
+    assert lib.stemgnn_table_floats(12, 5) == 2 * 144 + 31 * 60 + 29 * 60
+    assert lib.stemgnn_saved_floats(32, 228, 12, 5) == 7296 * (36 + 2 * 2 * (240 + 240 + 128) + 120)
+
+
+def test_tables_host_math(lib):
+    import numpy as np
+    import torch
+
+    W, multi = 12, 5
+    Wm = W * multi
+    n = lib.stemgnn_table_floats(W, multi)
+    buf = torch.empty(n, dtype=torch.float32)
+    assert lib.stemgnn_make_tables_host(W, multi, buf.data_ptr()) == 0
+    t = buf.numpy().astype(np.float64)
+    cosW = t[: W * W].reshape(W, W)
+    sinW = t[W * W: 2 * W * W].reshape(W, W)
+    cinvR = t[2 * W * W: 2 * W * W + 31 * Wm].reshape(31, Wm)
+    cinvI = t[2 * W * W + 31 * Wm:].reshape(29, Wm)
+    # forward DFT == torch.fft.fft on a random real signal
+    g = torch.randn(5, W, dtype=torch.float64)
+    ff = torch.fft.fft(g, dim=-1)
+    assert np.abs(g.numpy() @ cosW - ff.real.numpy()).max() < 1e-6
+    assert np.abs(-(g.numpy() @ sinW) - ff.imag.numpy()).max() < 1e-6
+    # C2R inverse == torch.fft.irfft on the first Wm/2+1 bins of an arbitrary (non-Hermitian) spectrum
+    re, im = torch.randn(3, Wm, dtype=torch.float64), torch.randn(3, Wm, dtype=torch.float64)
+    y = torch.fft.irfft(torch.complex(re, im)[..., : Wm // 2 + 1], n=Wm, dim=-1).numpy()
+    mine = re.numpy()[:, :31] @ cinvR + im.numpy()[:, 1:30] @ cinvI
+    assert np.abs(mine - y).max() < 1e-6
+    assert sinW[:, 0].max() == 0.0 and np.abs(sinW[:, W // 2]).max() == 0.0   # exact zeros at DC / Nyquist
+
+
+def test_invalid_args_return_einval(lib):
+    assert lib.stemgnn_cheb_fwd(None, 8, None) == -10001
+    assert lib.stemgnn_make_tables_host(0, 5, None) == -10001
+
+
+def test_model_refuses_cpu():
+    import torch
+
+    from stemgnn_amd import Model
+    from stemgnn_amd._lib import StemGNNHipError
+
+    m = Model(6, 2, 4, 2, horizon=2)
+    with pytest.raises(StemGNNHipError):
+        m(torch.randn(2, 4, 6))
+
+
+def test_state_dict_contract_matches_reference_order():
+    import torch
+
+    from oracle import stemgnn_oracle as O
+    from stemgnn_amd import Model
+
+    m = Model(10, 2, 12, 5, horizon=3)
+    shapes = O.param_shapes(10, 12, 5, 3)
+    got = [(k, tuple(v.shape)) for k, v in m.state_dict().items()]
+    assert got == list(shapes.items())
+    assert [k for k, _ in m.named_parameters()] == list(shapes.keys())
