@@ -1,0 +1,246 @@
+#!/usr/bin/env python
+"""bench.py -- forecast-steps/sec (train) of the StemGNN hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
+
+A "step" is one optimizer step of the drop-in model on one synthetic PEMS07-shaped batch
+(N=228, W=12, H=3, multi=5, per-GPU batch 32 -- BASELINE.json configs[1]): zero_grad -> forward ->
+MSELoss -> backward -> (flat grad all-reduce over RCCL when N>1) -> RMSprop(lr=1e-4, eps=1e-8) step,
+exactly the reference's loop body (models/handler.py:157-165), with the batch already resident in HBM.
+Weak scaling: every rank trains on its own 32-sample batch ("replicas with a local graph").
+
+Rank 0 prints ONE JSON line with the throughput, a `roofline` object for the dominant kernel
+(timed live with HIP events on the launch stream) and, at N=1, a `cpu_baseline` object: the CPU oracle
+port of the same train step timed on this box's host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+WORKLOAD = dict(N=228, W=12, H=3, multi=5, B=32)      # PEMS07 shape, BASELINE.json configs[1]
+FP32_MFMA_PEAK_TFLOPS = 157.3                          # MI355X_MICROARCH.md: v_mfma_f32_* dense peak
+
+
+def glu_fwd_flops(B, N, W, multi):
+    """Algorithmic FLOPs of one stemgnn_spectral_glu_fwd call (3 GEMM launches, both branches), dense count
+    of SURVEY 8d: 2*M*(C0*2C + 2C*C + 2C*C) per branch with C0 = 4W, C = 4*W*multi."""
+    M, C0, C = B * N, 4 * W, 4 * W * multi
+    return 2 * (2.0 * M * (C0 * 2 * C + C * 2 * C + C * 2 * C))
+
+
+def build_step(model, opt, bucket, x, y, world):
+    loss_fn = torch.nn.MSELoss(reduction="mean")
+    loss_buf = torch.zeros((), device=x.device)
+
+    def fwd_bwd():
+        bucket.zero()
+        forecast, _ = model(x)
+        loss = loss_fn(forecast, y)
+        loss.backward()
+        loss_buf.copy_(loss.detach())
+
+    def sync_grads():
+        bucket.all_reduce_mean()
+
+    def opt_step():
+        opt.step()
+
+    return fwd_bwd, sync_grads, opt_step, loss_buf
+
+
+def try_capture(fn, stream_warmups=3):
+    """Capture fn into a hipGraph (torch.cuda.CUDAGraph); returns a replay callable or None."""
+    try:
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(stream_warmups):
+                fn()
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            fn()
+        torch.cuda.synchronize()
+        return g.replay
+    except Exception as e:  # noqa: BLE001
+        print(f"[bench] graph capture unavailable ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
+        torch.cuda.synchronize()
+        return None
+
+
+def time_dominant_kernel(cfg, iters=20):
+    """Average launch duration of the dominant kernel (sg_gemm_f32<GluFwdOp>), HIP events on the launch stream."""
+    from stemgnn_amd import _lib
+
+    lib = _lib.load()
+    B, N, W, multi = cfg["B"], cfg["N"], cfg["W"], cfg["multi"]
+    dev = torch.device("cuda")
+    packed = torch.randn(lib.stemgnn_packed_floats(W, multi), device=dev) * 0.05
+    saved = torch.randn(lib.stemgnn_saved_floats(B, N, W, multi), device=dev)
+    st = torch.cuda.current_stream()
+
+    def run():
+        _lib.check(lib.stemgnn_spectral_glu_fwd(packed.data_ptr(), saved.data_ptr(), B, N, W, multi, st.cuda_stream),
+                   "spectral_glu_fwd")
+
+    for _ in range(3):
+        run()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(st)
+    for _ in range(iters):
+        run()
+    e1.record(st)
+    e1.synchronize()
+    launches = 3 * iters
+    avg_s = e0.elapsed_time(e1) * 1e-3 / launches
+    flops_per_launch = glu_fwd_flops(B, N, W, multi) / 3.0
+    return avg_s, flops_per_launch
+
+
+def cpu_baseline(cfg, budget_s=20.0):
+    """The CPU oracle port of the same train step on this box's host cores (kind='port')."""
+    from oracle.stemgnn_oracle import OracleTrainer
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    tr = OracleTrainer(cfg["N"], cfg["W"], cfg["multi"], cfg["H"], lr=1e-4, seed=0, dropout_rate=0.5)
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(cfg["B"], cfg["W"], cfg["N"], generator=g)
+    y = torch.randn(cfg["B"], cfg["H"], cfg["N"], generator=g)
+    for _ in range(2):
+        tr.step(x, y)
+    n, t0 = 0, time.perf_counter()
+    while True:
+        tr.step(x, y)
+        n += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or n >= 200:
+            break
+    sps = n / el
+    return {"value": cfg["B"] * cfg["H"] * sps, "unit": "forecast-steps/s", "cores": cores, "kind": "port",
+            "ms_per_step": 1e3 / sps,
+            "sample": f"{n} train steps of the torch-CPU oracle port (same shape, batch {cfg['B']}, fp32, "
+                      f"RMSprop, dropout 0.5) after 2 warm-up steps, {cores} threads"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from stemgnn_amd import Model
+    from stemgnn_amd.distributed import FlatGradBucket, broadcast_parameters
+
+    cfg = dict(WORKLOAD)
+    torch.manual_seed(0)
+    model = Model(cfg["N"], 2, cfg["W"], cfg["multi"], horizon=cfg["H"])      # defaults: dropout 0.5, leaky 0.2
+    model.to(dev).train()
+    broadcast_parameters(model)
+    bucket = FlatGradBucket(model.parameters())
+    opt = torch.optim.RMSprop(model.parameters(), lr=1e-4, eps=1e-8, capturable=True, foreach=True)
+    g = torch.Generator().manual_seed(1234 + rank)
+    x = torch.randn(cfg["B"], cfg["W"], cfg["N"], generator=g).to(dev)
+    y = torch.randn(cfg["B"], cfg["H"], cfg["N"], generator=g).to(dev)
+
+    fwd_bwd, sync_grads, opt_step, loss_buf = build_step(model, opt, bucket, x, y, world)
+    # one eager step first (lazy init of tables, seed, RMSprop state)
+    fwd_bwd(); sync_grads(); opt_step()
+    torch.cuda.synchronize()
+    mode = "eager"
+    if not args.no_graph:
+        if world == 1:
+            def whole():
+                fwd_bwd(); opt_step()
+            rep = try_capture(whole)
+            if rep is not None:
+                step, mode = rep, "hipgraph(whole step)"
+            else:
+                def step():
+                    fwd_bwd(); opt_step()
+        else:
+            rep_a, rep_b = try_capture(fwd_bwd), None
+            if rep_a is not None:
+                rep_b = try_capture(opt_step)
+            if rep_a is not None and rep_b is not None:
+                mode = "hipgraph(fwd+bwd) + rccl all-reduce + hipgraph(optimizer)"
+
+                def step():
+                    rep_a(); sync_grads(); rep_b()
+            else:
+                def step():
+                    fwd_bwd(); sync_grads(); opt_step()
+    else:
+        def step():
+            fwd_bwd(); sync_grads(); opt_step()
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    final_loss = float(loss_buf.item())
+    if not (final_loss == final_loss) or final_loss > 1e6:
+        raise SystemExit(f"training diverged: loss={final_loss}")
+
+    ms_per_step = elapsed / args.steps * 1e3
+    value = world * cfg["B"] * cfg["H"] / (elapsed / args.steps)
+    out = {
+        "metric": "forecast-steps/sec (train)", "value": value, "unit": "forecast-steps/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "PEMS07-shape N=228 W=12 H=3 multi=5 stack=2, batch 32 per GPU, train step "
+                               "(fwd+MSE+bwd+RMSprop), dropout 0.5", "global_batch": world * cfg["B"],
+                   "per_gpu_batch": cfg["B"], "parallelism": f"dp{world}", "launch": mode},
+        "final_loss": final_loss,
+    }
+    if rank == 0:
+        avg_s, flops = time_dominant_kernel(cfg)
+        ach = flops / avg_s / 1e12
+        out["roofline"] = {"kernel": "sg_gemm_f32<GluFwdOp,128,64> (spectral GLU forward GEMM, exact-fp32 MFMA)",
+                           "bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                           "frac": ach / FP32_MFMA_PEAK_TFLOPS, "avg_launch_us": avg_s * 1e6,
+                           "flops_per_launch": flops, "traffic": None}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
