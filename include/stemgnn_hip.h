@@ -77,6 +77,30 @@ int stemgnn_cheb_fwd(float* mul_L, int N, void* stream);
 /* dmul_L [4,N,N] gradient of all four slots (slot 0 ignored) -> dL [N,N]; scratch 2*N*N floats. */
 int stemgnn_cheb_bwd(const float* mul_L, const float* dmul_L, float* dL, float* scratch, int N, void* stream);
 
+/* ---- Laplacian eigendecomposition route (north-star; same function of L as stemgnn_cheb_fwd) --------
+ * Symmetric N x N eigensolver L = U^T diag(lam) U: parallel one-sided Jacobi (one launch per tournament
+ * round, fp64 rotation parameters), one Newton-Schulz re-orthogonalisation on MFMA, Rayleigh-quotient
+ * eigenvalues; then slot k := sum_e p_k(lam_e) u_e u_e^T for k = 2,3 with p = (2 l^2, 4 l^3 - l)
+ * (slot 0 = zeros and slot 1 = L are left as attn_laplacian_fwd wrote them).
+ * lam [N]; U [N,N] with the eigenvectors in ROWS; scratch: stemgnn_eigh_scratch_floats(N); nsweeps ~ 9. */
+size_t stemgnn_eigh_scratch_floats(int N);
+int stemgnn_eigh_fwd(float* mul_L, float* lam, float* U, float* scratch, int N, int nsweeps, void* stream);
+
+/* ---- GRU front (models/base_model.py:92,137: nn.GRU(time_step, units) over the node axis) ------------
+ * seq_len S (= N nodes), batch B, input size W, hidden size Hd (= N).  PyTorch gate order (r,z,n).
+ * x [B,W,S] is the model input read in place (x_s[b,t] = x[b,t,s]); w_ih [3Hd,W], w_hh [3Hd,Hd],
+ * b_ih, b_hh [3Hd]; h_all [S,B,Hd] is exactly nn.GRU's output; reserve keeps r,z,n,gh_n for backward.
+ * One persistent workgroup per batch row runs all S steps (no inter-workgroup sync). */
+size_t stemgnn_gru_reserve_floats(int B, int S, int Hd);
+size_t stemgnn_gru_fwd_scratch_floats(int B, int S, int Hd);
+size_t stemgnn_gru_bwd_scratch_floats(int B, int S, int Hd, int W);
+int stemgnn_gru_fwd(const float* x, const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh,
+                    int B, int S, int Hd, int W, float* scratch, float* h_all, float* reserve, void* stream);
+/* dh_all [S,B,Hd] = gradient of every output step -> dw_ih, dw_hh, db_ih, db_hh (x gets no gradient). */
+int stemgnn_gru_bwd(const float* dh_all, const float* x, const float* w_hh, const float* h_all,
+                    const float* reserve, int B, int S, int Hd, int W, float* scratch,
+                    float* dw_ih, float* dw_hh, float* db_ih, float* db_hh, void* stream);
+
 /* ---- weight packing (per StockBlock, once per optimizer step) -----------------------------------
  * Folds the length-W DFT (:49-51) into the first GLU layer, drops the dead C2R bins,
  * folds the C2R inverse DFT (:58) into the graph-conv weight (:66-67), and lays the GLU weights out

@@ -264,4 +264,4 @@ class OracleTrainer:
         loss = F.mse_loss(forecast, y)
         loss.backward()
         self.opt.step()
-        return float(loss)
+        return float(loss.detach())

@@ -8,15 +8,18 @@ gives the same initial weights, and checkpoints interchange), but the modules ar
 containers: all arithmetic after the GRU runs in the hand-written HIP kernels of
 ``libstemgnn_hip.so`` through :class:`stemgnn_amd.ops.SpectralHotPath`.
 
-Not on the hand-written path (stay PyTorch-ROCm library calls): the ``nn.GRU`` front
-(models/base_model.py:137) and the 2-layer ``fc`` tail (:175).
+The ``nn.GRU`` module (models/base_model.py:92,137) is kept as the parameter container; its recurrence
+runs in the persistent HIP kernels of ``csrc/gru.hip`` (``STEMGNN_GRU=miopen`` selects the library GRU for
+A/B runs).  The 2-layer ``fc`` tail (:175) stays a PyTorch-ROCm library call (negligible work).
 """
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
 from . import _lib
-from .ops import SpectralHotPath
+from .ops import GruFront, SpectralHotPath
 
 _BLOCK_FIELDS = ("forecast", "forecast_result", "backcast", "backcast_short_cut")
 
@@ -115,7 +118,11 @@ class Model(nn.Module):
             raise _lib.StemGNNHipError(
                 f"input is on {x.device}: stemgnn_amd.Model runs only on a HIP device (no CPU fallback)")
         x = x.contiguous()
-        h, _ = self.GRU(x.permute(2, 0, 1).contiguous())          # [N_seq, B, N_hid]  (:137)
+        if os.environ.get("STEMGNN_GRU", "hip") == "miopen":       # library GRU (MIOpen) -- A/B and debugging only
+            h, _ = self.GRU(x.permute(2, 0, 1).contiguous())      # [N_seq, B, N_hid]  (:137)
+        else:                                                      # persistent HIP recurrence (csrc/gru.hip)
+            g = self.GRU
+            h = GruFront.apply(x, g.weight_ih_l0, g.weight_hh_l0, g.bias_ih_l0, g.bias_hh_l0)
         use_drop = self.training and self.dropout_rate > 0.0
         seed = self._next_seed(x.device) if use_drop else None
         params = self.stock_block[0].hip_params() + self.stock_block[1].hip_params()

@@ -54,6 +54,49 @@ def dropout_mask(drop_p, seed, B, N):
     return mask
 
 
+class GruFront(torch.autograd.Function):
+    """nn.GRU(time_step, units) over the node axis (reference models/base_model.py:137) as two persistent HIP
+    recurrence kernels.  (x [B,W,N], weight_ih_l0, weight_hh_l0, bias_ih_l0, bias_hh_l0) -> h [N,B,N]."""
+
+    @staticmethod
+    def forward(ctx, x, w_ih, w_hh, b_ih, b_hh):
+        lib = _lib.load()
+        for name, t in (("x", x), ("GRU.weight_ih_l0", w_ih), ("GRU.weight_hh_l0", w_hh)):
+            _require_gpu(t, name)
+        x = x.contiguous()
+        B, W, S = x.shape
+        Hd = w_hh.shape[1]
+        dev, f32 = x.device, torch.float32
+        w_ih, w_hh, b_ih, b_hh = (t.contiguous() for t in (w_ih, w_hh, b_ih, b_hh))
+        h_all = torch.empty(S, B, Hd, device=dev, dtype=f32)
+        reserve = torch.empty(lib.stemgnn_gru_reserve_floats(B, S, Hd), device=dev, dtype=f32)
+        scratch = torch.empty(lib.stemgnn_gru_fwd_scratch_floats(B, S, Hd), device=dev, dtype=f32)
+        _lib.check(lib.stemgnn_gru_fwd(x.data_ptr(), w_ih.data_ptr(), w_hh.data_ptr(), b_ih.data_ptr(), b_hh.data_ptr(),
+                                       B, S, Hd, W, scratch.data_ptr(), h_all.data_ptr(), reserve.data_ptr(), _stream()),
+                   "gru_fwd")
+        # save_for_backward (not ctx attributes): h_all is an OUTPUT -- holding it on ctx would form a
+        # ctx <-> grad_fn reference cycle that never frees the step's buffers
+        ctx.save_for_backward(x, w_ih, w_hh, h_all, reserve)
+        return h_all
+
+    @staticmethod
+    def backward(ctx, dh_all):
+        lib = _lib.load()
+        x, w_ih, w_hh, h_all, reserve = ctx.saved_tensors
+        B, W, S = x.shape
+        Hd = w_hh.shape[1]
+        dev, f32 = x.device, torch.float32
+        dh_all = dh_all.contiguous()
+        scratch = torch.empty(lib.stemgnn_gru_bwd_scratch_floats(B, S, Hd, W), device=dev, dtype=f32)
+        dw_ih, dw_hh = torch.empty_like(w_ih), torch.empty_like(w_hh)
+        db_ih = torch.empty(3 * Hd, device=dev, dtype=f32)
+        db_hh = torch.empty(3 * Hd, device=dev, dtype=f32)
+        _lib.check(lib.stemgnn_gru_bwd(dh_all.data_ptr(), x.data_ptr(), w_hh.data_ptr(), h_all.data_ptr(),
+                                       reserve.data_ptr(), B, S, Hd, W, scratch.data_ptr(), dw_ih.data_ptr(),
+                                       dw_hh.data_ptr(), db_ih.data_ptr(), db_hh.data_ptr(), _stream()), "gru_bwd")
+        return None, dw_ih, dw_hh, db_ih, db_hh
+
+
 class SpectralHotPath(torch.autograd.Function):
     """(h, x, weight_key, weight_query, 33 params of block 0, 33 params of block 1) ->
     (sum of the two block forecasts [B,N,W], attention [N,N], mul_L [4,N,N]).
@@ -87,7 +130,16 @@ class SpectralHotPath(torch.autograd.Function):
             h.data_ptr(), wk.data_ptr(), wq.data_ptr(), float(alpha), float(drop_p), int(bool(training)),
             seed.data_ptr() if use_drop else None, B, N, attn_saved.data_ptr(), attention.data_ptr(),
             mul_L.data_ptr(), st), "attn_laplacian_fwd")
-        _lib.check(lib.stemgnn_cheb_fwd(mul_L.data_ptr(), N, st), "cheb_fwd")
+        if os.environ.get("STEMGNN_SPECTRAL", "cheb") == "eig":
+            # north-star eigen route: L = U^T diag(lam) U, T_k = sum_e p_k(lam_e) u_e u_e^T (same function of L;
+            # the backward below is the polynomial one either way -- never differentiates through eigenvectors)
+            lam = torch.empty(N, device=dev, dtype=f32)
+            U = torch.empty(N, N, device=dev, dtype=f32)
+            escr = torch.empty(lib.stemgnn_eigh_scratch_floats(N), device=dev, dtype=f32)
+            _lib.check(lib.stemgnn_eigh_fwd(mul_L.data_ptr(), lam.data_ptr(), U.data_ptr(), escr.data_ptr(), N,
+                                            int(os.environ.get("STEMGNN_EIG_SWEEPS", "9")), st), "eigh_fwd")
+        else:
+            _lib.check(lib.stemgnn_cheb_fwd(mul_L.data_ptr(), N, st), "cheb_fwd")
 
         fsum = torch.empty(B, N, W, device=dev, dtype=f32)
         backcast = torch.empty(B, N, W, device=dev, dtype=f32)

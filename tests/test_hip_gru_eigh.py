@@ -1,0 +1,97 @@
+"""GPU parity of the two stages added around the spectral blocks: the persistent-kernel GRU front
+(reference nn.GRU, models/base_model.py:92,137) and the Laplacian eigensolver route (north-star a-4)."""
+import pytest
+import torch
+
+from oracle import stemgnn_oracle as O
+from tests.util import relerr
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+@pytest.mark.parametrize("B,S,W", [(32, 228, 12), (5, 33, 7), (3, 140, 12), (2, 300, 4)])
+def test_gru_fwd_bwd_vs_torch_cpu(B, S, W):
+    from stemgnn_amd.ops import GruFront
+
+    torch.manual_seed(S + B)
+    gru = torch.nn.GRU(W, S)                              # hidden size = number of nodes = sequence length
+    x = torch.randn(B, W, S)
+    dh = torch.randn(S, B, S)
+    out, _ = gru(x.permute(2, 0, 1).contiguous())
+    out.backward(dh)
+    params = [p.detach().clone().cuda().requires_grad_(True)
+              for p in (gru.weight_ih_l0, gru.weight_hh_l0, gru.bias_ih_l0, gru.bias_hh_l0)]
+    h = GruFront.apply(x.cuda(), *params)
+    h.backward(dh.cuda())
+    torch.cuda.synchronize()
+    assert relerr(h, out.detach()) < TOL
+    for mine, ref in zip(params, (gru.weight_ih_l0, gru.weight_hh_l0, gru.bias_ih_l0, gru.bias_hh_l0)):
+        assert relerr(mine.grad, ref.grad) < TOL
+
+
+def _laplacian(N, B=6, seed=0):
+    sd = O.det_state_dict(N, 12, 5, 3, seed=seed)
+    torch.manual_seed(seed)
+    x = torch.randn(B, 12, N)
+    att = O.self_graph_attention(O.gru_front(x, sd), sd["weight_key"], sd["weight_query"])
+    return O.laplacian_from_attention(att)[0]
+
+
+@pytest.mark.parametrize("N", [228, 33, 64, 140])
+def test_eigh_stage_reproduces_chebyshev_basis(N):
+    from stemgnn_amd import _lib
+
+    lib = _lib.load()
+    L = _laplacian(N)
+    mul_L = torch.zeros(4, N, N, device="cuda")
+    mul_L[1] = L.cuda()
+    lam = torch.empty(N, device="cuda")
+    U = torch.empty(N, N, device="cuda")
+    scratch = torch.empty(lib.stemgnn_eigh_scratch_floats(N), device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    assert lib.stemgnn_eigh_fwd(mul_L.data_ptr(), lam.data_ptr(), U.data_ptr(), scratch.data_ptr(), N, 9, st) == 0
+    torch.cuda.synchronize()
+    ref = O.cheb_polynomial(L.double())
+    assert relerr(mul_L[2], ref[2]) < TOL and relerr(mul_L[3], ref[3]) < TOL
+    assert torch.equal(mul_L[1].cpu(), L) and float(mul_L[0].abs().max()) == 0.0
+    Ud = U.cpu().double()
+    assert float((Ud @ Ud.T - torch.eye(N, dtype=torch.float64)).abs().max()) < 1e-5            # orthogonality
+    assert relerr((Ud.T * lam.cpu().double()) @ Ud, L.double()) < 1e-5                           # L = U^T diag(lam) U
+    ev = torch.linalg.eigvalsh(L.double())
+    assert float((torch.sort(lam.cpu().double()).values - ev).abs().max()) < 1e-5
+
+
+def test_model_eig_route_matches_oracle(monkeypatch):
+    from stemgnn_amd import Model
+
+    monkeypatch.setenv("STEMGNN_SPECTRAL", "eig")
+    N, W, multi, H, B = 60, 12, 5, 3, 8
+    sd = O.det_state_dict(N, W, multi, H, seed=4)
+    model = Model(N, 2, W, multi, horizon=H, dropout_rate=0.0)
+    model.load_state_dict(sd)
+    model.cuda().train()
+    torch.manual_seed(5)
+    x, y = torch.randn(B, W, N), torch.randn(B, H, N)
+    forecast, att = model(x.cuda())
+    torch.nn.functional.mse_loss(forecast, y.cuda()).backward()
+    o_loss, o_forecast, o_att, o_grads = O.loss_and_grads(x, y, sd)
+    assert relerr(forecast, o_forecast) < TOL and relerr(att, o_att) < TOL
+    for k, p in model.named_parameters():
+        if o_grads[k] is not None:
+            assert relerr(p.grad, o_grads[k]) < TOL, k
+
+
+def test_miopen_gru_switch_gives_same_result(monkeypatch):
+    from stemgnn_amd import Model
+
+    N, W, multi, H, B = 40, 12, 5, 3, 4
+    sd = O.det_state_dict(N, W, multi, H, seed=6)
+    model = Model(N, 2, W, multi, horizon=H, dropout_rate=0.0)
+    model.load_state_dict(sd)
+    model.cuda().train()
+    x = torch.randn(B, W, N).cuda()
+    f_hip, _ = model(x)
+    monkeypatch.setenv("STEMGNN_GRU", "miopen")
+    f_lib, _ = model(x)
+    assert relerr(f_hip, f_lib.detach().cpu()) < TOL
