@@ -138,8 +138,8 @@ struct GluDpre {
   __device__ __forceinline__ float at(int r, int m, int q) const {
     const int c = ((q >> 5) << 4) + (q & 15);
     const size_t o = (size_t)m * cp[r] + c;
-    const float d = dout[r][o], g = gate[r][o];
-    return (q & 16) ? d * out[r][o] * (1.f - g) : d * g;
+    const float d = dout[r][o], g = gate[r][o], y = out[r][o];     // all three loads unconditional
+    return (q & 16) ? d * y * (1.f - g) : d * g;
   }
 };
 
@@ -194,7 +194,10 @@ struct GluWgradOp {
     return true;
   }
   __device__ float a(int z, int i, int k) const { return dp.at(z / S, k, i); }
-  __device__ float b(int z, int k, int j) const { return j < kin ? x[z / S][(size_t)k * ldx + j] : 1.f; }
+  __device__ float b(int z, int k, int j) const {
+    const float v = x[z / S][(size_t)k * ldx + (j < kin ? j : kin - 1)];     // branch-free: load, then select
+    return j < kin ? v : 1.f;
+  }
   __device__ void epi(int z, int i, int j, float v) const {
     const int r = z / S, s = z - r * S;
     part[r][((size_t)s * np[r] + i) * (kin + 1) + j] = v;
@@ -215,7 +218,8 @@ struct IgftOp {  // ig[m][o] = sum_kk [Re3 | Im3][m][kk] Wfold[kk][o]
     return true;
   }
   __device__ float a(int, int i, int k) const {
-    return k < cp2[0] ? a3[0][(size_t)i * cp2[0] + k] : a3[1][(size_t)i * cp2[1] + (k - cp2[0])];
+    const float* p = k < cp2[0] ? a3[0] + (size_t)i * cp2[0] + k : a3[1] + (size_t)i * cp2[1] + (k - cp2[0]);
+    return *p;
   }
   __device__ float b(int, int k, int j) const { return wfold[(size_t)k * WmP + j]; }
   __device__ void epi(int, int i, int j, float v) const { ig[(size_t)i * Wm + j] = v; }
@@ -233,11 +237,18 @@ struct Head1Op {
     M_ = M; N_ = Wm + (has_bc ? W : 0); K0 = 0; K1 = Wm + (has_bc ? W : 0);
     return true;
   }
-  __device__ float a(int, int i, int k) const { return k < Wm ? ig[(size_t)i * Wm + k] : X.row(i, k - Wm); }
+  __device__ float a(int, int i, int k) const {
+    const int b = i / X.N;
+    const float* p = k < Wm ? ig + (size_t)i * Wm + k : X.p + b * X.sb + (i - b * X.N) * X.sn + (k - Wm) * X.st;
+    return *p;
+  }
   __device__ float b(int, int k, int j) const {
-    if (j < Wm) return k < Wm ? Fw[(size_t)j * Wm + k] : 0.f;
-    const int t = j - Wm;
-    return k < Wm ? BCw[(size_t)t * Wm + k] : -BSw[t * W + (k - Wm)];
+    // one unconditional load through a selected pointer; the (j < Wm, k >= Wm) corner is a structural zero
+    const int t = j < Wm ? 0 : j - Wm;
+    const float* p = j < Wm ? Fw + (size_t)j * Wm + (k < Wm ? k : 0)
+                            : (k < Wm ? BCw + (size_t)t * Wm + k : BSw + t * W + (k - Wm));
+    const float v = *p;
+    return j < Wm ? (k < Wm ? v : 0.f) : (k < Wm ? v : -v);
   }
   __device__ void epi(int, int i, int j, float v) const {
     if (j < Wm) fs[(size_t)i * Wm + j] = sg_sigmoid(v + Fb[j]);
@@ -302,10 +313,12 @@ struct DigOp {  // dig = dpF F + dpB BC
     return true;
   }
   __device__ float a(int, int i, int k) const {
-    return k < Wm ? dpF[(size_t)i * Wm + k] : dpB[(size_t)i * W + (k - Wm)];
+    const float* p = k < Wm ? dpF + (size_t)i * Wm + k : dpB + (size_t)i * W + (k - Wm);
+    return *p;
   }
   __device__ float b(int, int k, int j) const {
-    return k < Wm ? Fw[(size_t)k * Wm + j] : BCw[(size_t)(k - Wm) * Wm + j];
+    const float* p = k < Wm ? Fw + (size_t)k * Wm + j : BCw + (size_t)(k - Wm) * Wm + j;
+    return *p;
   }
   __device__ void epi(int, int i, int j, float v) const { dig[(size_t)i * Wm + j] = v; }
 };
@@ -351,16 +364,18 @@ struct HeadsWgradOp {
       case 1: return dpF[(size_t)k * Wm + i];
       case 2: return dpB[(size_t)k * W + i];
       case 3: return -dpB[(size_t)k * W + i];
-      default:
-        return i < cp2[0] ? a3[0][(size_t)k * cp2[0] + i] : a3[1][(size_t)k * cp2[1] + (i - cp2[0])];
+      default: {
+        const float* p = i < cp2[0] ? a3[0] + (size_t)k * cp2[0] + i : a3[1] + (size_t)k * cp2[1] + (i - cp2[0]);
+        return *p;
+      }
     }
   }
   __device__ float b(int z, int k, int j) const {
     switch (z / S) {
-      case 0: return j < Wm ? fs[(size_t)k * Wm + j] : 1.f;
+      case 0: { const float v = fs[(size_t)k * Wm + (j < Wm ? j : Wm - 1)]; return j < Wm ? v : 1.f; }
       case 1:
-      case 2: return j < Wm ? ig[(size_t)k * Wm + j] : 1.f;
-      case 3: return j < W ? X.row(k, j) : 1.f;
+      case 2: { const float v = ig[(size_t)k * Wm + (j < Wm ? j : Wm - 1)]; return j < Wm ? v : 1.f; }
+      case 3: { const float v = X.row(k, j < W ? j : W - 1); return j < W ? v : 1.f; }
       default: return dig[(size_t)k * Wm + j];
     }
   }
@@ -486,7 +501,7 @@ extern "C" int stemgnn_spectral_glu_bwd(const float* packed, const float* saved,
       op.np0 = sg_glu_np(d, 0, 0);
       op.dG = scratch + C.dG;
       op.KG = d.KG; op.M = d.M;
-      SG_TRY((sg_launch_gemm<GluDgrad0Op, 128, 64, true, true, false>(op, d.M, d.KG, 1, st)));
+      SG_TRY((sg_launch_gemm<GluDgrad0Op, 32, 64, true, true, false>(op, d.M, d.KG, 1, st)));
     }
   }
   return 0;

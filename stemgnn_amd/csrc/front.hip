@@ -327,8 +327,14 @@ struct ChebBwd2Op {
     M = N; Nn = N; K0 = 0; K1 = 2 * N;
     return true;
   }
-  __device__ float a(int, int i, int k) const { return k < N ? dT2p[(size_t)i * N + k] : L[(size_t)(k - N) * N + i]; }
-  __device__ float b(int, int k, int j) const { return k < N ? L[(size_t)j * N + k] : dT2p[(size_t)(k - N) * N + j]; }
+  __device__ float a(int, int i, int k) const {
+    const float* p = k < N ? dT2p + (size_t)i * N + k : L + (size_t)(k - N) * N + i;
+    return *p;
+  }
+  __device__ float b(int, int k, int j) const {
+    const float* p = k < N ? L + (size_t)j * N + k : dT2p + (size_t)(k - N) * N + j;
+    return *p;
+  }
   __device__ void epi(int, int i, int j, float v) const {
     const size_t o = (size_t)i * N + j;
     dL[o] = dLp[o] + 2.f * v;

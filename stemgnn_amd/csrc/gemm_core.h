@@ -61,7 +61,10 @@ __global__ __launch_bounds__(256) void sg_gemm_f32(const Op op) {
       const int k = A_KFAST ? (e & 15) : (e / BM);
       const int i = A_KFAST ? (e >> 4) : (e % BM);
       const int gi = m0 + i, gk = kbase + k;
-      ra[r] = (gi < M && gk < K1) ? op.a(z, gi, gk) : 0.f;
+      // unconditional load from a clamped (always valid) index, then select: a branch around each load would
+      // make hipcc wait vmcnt(0) per element and serialise the tile's loads (cdna guide, ".s-level traps" (c))
+      const float v = op.a(z, gi < M ? gi : M - 1, gk < K1 ? gk : K1 - 1);
+      ra[r] = (gi < M && gk < K1) ? v : 0.f;
     }
 #pragma unroll
     for (int r = 0; r < RB; ++r) {
@@ -69,7 +72,8 @@ __global__ __launch_bounds__(256) void sg_gemm_f32(const Op op) {
       const int k = B_KFAST ? (e & 15) : (e / BN);
       const int j = B_KFAST ? (e >> 4) : (e % BN);
       const int gj = n0 + j, gk = kbase + k;
-      rb[r] = (gj < N && gk < K1) ? op.b(z, gk, gj) : 0.f;
+      const float v = op.b(z, gk < K1 ? gk : K1 - 1, gj < N ? gj : N - 1);
+      rb[r] = (gj < N && gk < K1) ? v : 0.f;
     }
   };
   auto lstore = [&]() {
@@ -92,7 +96,7 @@ __global__ __launch_bounds__(256) void sg_gemm_f32(const Op op) {
   const int fi = lane & 15;       // fragment row (A) / col (B)
   const int fk = lane >> 4;       // fragment k within the k-step of 4
 
-  gload(K0);
+  if (K0 < K1) gload(K0);          // an empty split range still writes its (zero) slab in the epilogue
   for (int kb = K0; kb < K1; kb += BK) {
     lstore();
     __syncthreads();

@@ -184,11 +184,13 @@ struct GruWhhGradOp {
     return true;
   }
   __device__ float a(int, int i, int k) const {
-    return i < 2 * Hd ? dgi[(size_t)k * 3 * Hd + i] : dghn[(size_t)k * Hd + (i - 2 * Hd)];
+    const float* p = i < 2 * Hd ? dgi + (size_t)k * 3 * Hd + i : dghn + (size_t)k * Hd + (i - 2 * Hd);
+    return *p;
   }
   __device__ float b(int, int k, int j) const {
-    if (j >= Hd) return 1.f;
-    return k >= B ? h_all[(size_t)(k - B) * Hd + j] : 0.f;
+    // h_{s-1} of row k=(s,b) is row k-B; rows of step 0 see h = 0; column Hd is the bias (ones) column
+    const float v = h_all[(size_t)(k >= B ? k - B : 0) * Hd + (j < Hd ? j : Hd - 1)];
+    return j >= Hd ? 1.f : (k >= B ? v : 0.f);
   }
   __device__ void epi(int z, int i, int j, float v) const { part[((size_t)z * 3 * Hd + i) * (Hd + 1) + j] = v; }
 };
@@ -202,9 +204,9 @@ struct GruWihGradOp {
   }
   __device__ float a(int, int i, int k) const { return dgi[(size_t)k * 3 * Hd + i]; }
   __device__ float b(int, int k, int j) const {
-    if (j >= W) return 1.f;
     const int s = k / B, bb = k - s * B;
-    return x[((size_t)bb * W + j) * S + s];
+    const float v = x[((size_t)bb * W + (j < W ? j : W - 1)) * S + s];
+    return j < W ? v : 1.f;
   }
   __device__ void epi(int z, int i, int j, float v) const { part[((size_t)z * 3 * Hd + i) * (W + 1) + j] = v; }
 };
