@@ -90,16 +90,20 @@ int stemgnn_eigh_fwd(float* mul_L, float* lam, float* U, float* scratch, int N, 
  * seq_len S (= N nodes), batch B, input size W, hidden size Hd (= N).  PyTorch gate order (r,z,n).
  * x [B,W,S] is the model input read in place (x_s[b,t] = x[b,t,s]); w_ih [3Hd,W], w_hh [3Hd,Hd],
  * b_ih, b_hh [3Hd]; h_all [S,B,Hd] is exactly nn.GRU's output; reserve keeps r,z,n,gh_n for backward.
- * One persistent workgroup per batch row runs all S steps (no inter-workgroup sync). */
+ * Recurrence: P = 1..8 persistent workgroups per batch row keep their slice of w_hh resident in registers
+ * for all S steps and exchange h (forward) / the gate gradients (backward) once per step through tagged
+ * 8-byte granules (bounded spins; a timeout sets *status = 1, a device int the caller owns and zeroes);
+ * very wide hidden states fall back to one workgroup per row streaming w_hh from L2. */
 size_t stemgnn_gru_reserve_floats(int B, int S, int Hd);
 size_t stemgnn_gru_fwd_scratch_floats(int B, int S, int Hd);
 size_t stemgnn_gru_bwd_scratch_floats(int B, int S, int Hd, int W);
 int stemgnn_gru_fwd(const float* x, const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh,
-                    int B, int S, int Hd, int W, float* scratch, float* h_all, float* reserve, void* stream);
+                    int B, int S, int Hd, int W, float* scratch, float* h_all, float* reserve, int* status,
+                    void* stream);
 /* dh_all [S,B,Hd] = gradient of every output step -> dw_ih, dw_hh, db_ih, db_hh (x gets no gradient). */
 int stemgnn_gru_bwd(const float* dh_all, const float* x, const float* w_hh, const float* h_all,
                     const float* reserve, int B, int S, int Hd, int W, float* scratch,
-                    float* dw_ih, float* dw_hh, float* db_ih, float* db_hh, void* stream);
+                    float* dw_ih, float* dw_hh, float* db_ih, float* db_hh, int* status, void* stream);
 
 /* ---- weight packing (per StockBlock, once per optimizer step) -----------------------------------
  * Folds the length-W DFT (:49-51) into the first GLU layer, drops the dead C2R bins,

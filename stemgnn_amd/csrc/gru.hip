@@ -173,6 +173,229 @@ __global__ __launch_bounds__(1024) void gru_bwd_kernel(const float* __restrict__
   }
 }
 
+// =================================================================================================
+// Cluster recurrence: P workgroups (one per CU) per batch row with the recurrent weights RESIDENT in registers.
+//
+// The single-workgroup kernels above re-stream W_hh from L2 every step and are bound by the ~100 GB/s one CU can
+// pull (624 KB -> ~6.4 us per step at Hd=228).  A CU cannot hold W_hh (624 KB > 512 KB VGPR + 160 KB LDS minus
+// bookkeeping), but P=4 CUs can hold a quarter each entirely in VGPRs (<= KC registers per lane).  Workgroup
+// (b, p) owns the units [p*U, p*U+U) of batch row b: its 3*U gate columns (forward) / its U output columns
+// (backward).  The price is one small exchange per step: every workgroup publishes its slice of h_s (forward)
+// or of dgh_s (backward) as 8-byte {value, tag} granules with write-through stores and polls its partners'
+// granules (cdna_hip_programming.md guideline 16, form R2: the data is the flag, relaxed agent-scope 8-byte
+// atomics both sides).  tag = step+1 (never 0), the granule buffer is zeroed by a memset node before every
+// launch, two parities alternate so a fast workgroup can never overwrite a granule its partner has not read
+// (it needs that partner's next value first), every spin is bounded and reports through `status`.
+// The 4 partners of a row are given block ids that are equal mod 8, i.e. the same XCD (speed only).
+// =================================================================================================
+typedef unsigned long long gru_u64;
+__device__ __forceinline__ void gru_publish(gru_u64* g, unsigned tag, float v) {
+  __hip_atomic_store(g, ((gru_u64)tag << 32) | (gru_u64)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float gru_consume(const gru_u64* g, unsigned tag, int* status) {
+  gru_u64 x = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  unsigned spins = 0;
+  while ((unsigned)(x >> 32) != tag) {
+    __builtin_amdgcn_s_sleep(1);
+    x = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (++spins > (1u << 22)) { atomicExch(status, 1); break; }   // partner not resident / lost: give up, flag it
+  }
+  return __uint_as_float((unsigned)x);
+}
+
+struct GruCluster {   // geometry shared by host and device
+  int P, U, ncb, ksf, kcf, ksb, kcb;
+};
+__host__ __device__ inline GruCluster gru_cluster_geom(int Hd, int P) {
+  GruCluster c;
+  c.P = P;
+  c.U = (Hd + P - 1) / P;
+  c.ncb = (c.U + 63) / 64;
+  c.ksf = 16 / (3 * c.ncb);                       // forward: 3*ncb column blocks x ksf k-slices <= 16 waves
+  c.kcf = c.ksf > 0 ? (Hd + c.ksf - 1) / c.ksf : 1 << 30;
+  c.ksb = 16 / c.ncb;                             // backward: ncb column blocks x ksb slices of the 3*Hd reduction
+  c.kcb = c.ksb > 0 ? (3 * Hd + c.ksb - 1) / c.ksb : 1 << 30;
+  return c;
+}
+__device__ __forceinline__ void gru_cluster_ids(int B, int P, int& b, int& p) {
+  const int id = blockIdx.x;                      // id = bl + 8*(bh*P + p): partners share id mod 8 (same XCD)
+  const int bl = id & 7, r = id >> 3;
+  p = r % P;
+  b = (r / P) * 8 + bl;
+  (void)B;
+}
+
+// forward.  dynamic LDS: hs[Hd] | part[ksf][3][U]
+template <int KC>
+__global__ __launch_bounds__(1024) void gru_fwd_cluster_kernel(const float* __restrict__ gi, const float* __restrict__ w_hh,
+                                                               const float* __restrict__ b_hh, int B, int S, int Hd, int P,
+                                                               gru_u64* __restrict__ xbuf, int* __restrict__ status,
+                                                               float* __restrict__ h_all, float* __restrict__ reserve) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  int b, p;
+  gru_cluster_ids(B, P, b, p);
+  if (b >= B) return;
+  const GruCluster c = gru_cluster_geom(Hd, P);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int u0 = p * c.U;
+  const int un = max(0, min(Hd, u0 + c.U) - u0);
+  const int H3 = 3 * Hd;
+  float* hs = smem;                  // [Hd + KC], zero padded: the unrolled loops read hs[k0 .. k0+KC) unguarded
+  float* part = smem + Hd + KC;
+  for (int i = tid; i < Hd + KC; i += 1024) hs[i] = 0.f;
+  // this wave's resident weights: gate g, unit sub-block, k-slice
+  const int ncol = 3 * c.ncb;
+  const bool has = wave < ncol * c.ksf;
+  const int cb = has ? wave % ncol : 0, kq = has ? wave / ncol : 0;
+  const int g = cb / c.ncb, ul = (cb % c.ncb) * 64 + lane;     // ul = unit index inside the workgroup's slice
+  const int k0 = kq * c.kcf, kn = has ? max(0, min(Hd, k0 + c.kcf) - k0) : 0;
+  float wr[KC];
+  {
+    const bool lane_ok = has && ul < un;
+    const float* wrow = w_hh + ((size_t)g * Hd + (lane_ok ? u0 + ul : 0)) * Hd + (kn > 0 ? k0 : 0);
+#pragma unroll
+    for (int kk = 0; kk < KC; ++kk) {
+      const float v = wrow[kk < kn ? kk : 0];
+      wr[kk] = (lane_ok && kk < kn) ? v : 0.f;
+    }
+  }
+  const int iu = tid < un ? tid : 0;                 // gate-phase unit (local) of this thread
+  const int gu = u0 + iu;
+  const float bh0 = b_hh[gu], bh1 = b_hh[Hd + gu], bh2 = b_hh[2 * Hd + gu];
+  __syncthreads();
+
+  for (int s = 0; s < S; ++s) {
+    const size_t row = (size_t)s * B + b;
+    const float* gip = gi + row * H3;
+    const float gp0 = gip[gu], gp1 = gip[Hd + gu], gp2 = gip[2 * Hd + gu];     // prefetch for the gate phase
+    if (s > 0 && P > 1) {                               // gather the partners' slices of h_{s-1}
+      const gru_u64* xb = xbuf + ((size_t)(s & 1) * B + b) * Hd;
+      for (int i = tid; i < Hd; i += 1024)
+        if (i < u0 || i >= u0 + un) hs[i] = gru_consume(xb + i, (unsigned)s, status);
+    }
+    __syncthreads();
+    if (has) {
+      float a0 = 0.f, a1 = 0.f;
+      const float* hk = hs + k0;
+#pragma unroll
+      for (int kk = 0; kk < KC; kk += 2) {
+        if ((kk & 15) == 0) __builtin_amdgcn_sched_barrier(0);     // keep the LDS reads from all being hoisted
+        a0 = fmaf(wr[kk], hk[kk], a0);                               // wr is 0 beyond the slice, hs is zero padded
+        a1 = fmaf(wr[kk + 1], hk[kk + 1], a1);
+      }
+      if (ul < un) part[(kq * 3 + g) * c.U + ul] = a0 + a1;
+    }
+    __syncthreads();
+    if (tid < un) {
+      float g0 = bh0, g1 = bh1, g2 = bh2;
+      for (int q = 0; q < c.ksf; ++q) {
+        g0 += part[(q * 3 + 0) * c.U + iu];
+        g1 += part[(q * 3 + 1) * c.U + iu];
+        g2 += part[(q * 3 + 2) * c.U + iu];
+      }
+      const float r = gru_sigmoid(gp0 + g0);
+      const float z = gru_sigmoid(gp1 + g1);
+      const float n = tanhf(gp2 + r * g2);
+      const float hn = (1.f - z) * n + z * hs[gu];
+      float* rs = reserve + row * 4 * Hd;
+      rs[gu] = r; rs[Hd + gu] = z; rs[2 * Hd + gu] = n; rs[3 * Hd + gu] = g2;
+      h_all[row * Hd + gu] = hn;
+      hs[gu] = hn;
+      if (P > 1 && s + 1 < S) gru_publish(xbuf + ((size_t)((s + 1) & 1) * B + b) * Hd + gu, (unsigned)(s + 1), hn);
+    }
+    // no barrier here: the next gather only writes hs[i] of OTHER units, and every mat-vec read of this step is done
+  }
+}
+
+// backward.  dynamic LDS: dgh[3*Hd] | dhz[U] | part[ksb][U]
+template <int KC>
+__global__ __launch_bounds__(1024) void gru_bwd_cluster_kernel(const float* __restrict__ dout, const float* __restrict__ w_hh,
+                                                               const float* __restrict__ h_all, const float* __restrict__ reserve,
+                                                               int B, int S, int Hd, int P, gru_u64* __restrict__ xbuf,
+                                                               int* __restrict__ status, float* __restrict__ dgi,
+                                                               float* __restrict__ dghn) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  int b, p;
+  gru_cluster_ids(B, P, b, p);
+  if (b >= B) return;
+  const GruCluster c = gru_cluster_geom(Hd, P);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int u0 = p * c.U;
+  const int un = max(0, min(Hd, u0 + c.U) - u0);
+  const int H3 = 3 * Hd;
+  float* dgh = smem;                 // flat j = g*Hd + k, [3*Hd + KC] zero padded
+  float* dhz = smem + H3 + KC;
+  float* part = dhz + c.U;
+  for (int i = tid; i < H3 + KC; i += 1024) dgh[i] = 0.f;
+  for (int i = tid; i < c.U; i += 1024) dhz[i] = 0.f;
+  for (int i = tid; i < c.ksb * c.U; i += 1024) part[i] = 0.f;
+  const bool has = wave < c.ncb * c.ksb;
+  const int cb = has ? wave % c.ncb : 0, jq = has ? wave / c.ncb : 0;
+  const int ul = cb * 64 + lane;
+  const int j0 = jq * c.kcb, jn = has ? max(0, min(H3, j0 + c.kcb) - j0) : 0;
+  float wr[KC];
+  {
+    const bool lane_ok = has && ul < un;
+    const float* wcol = w_hh + (size_t)(jn > 0 ? j0 : 0) * Hd + (lane_ok ? u0 + ul : 0);
+#pragma unroll
+    for (int jj = 0; jj < KC; ++jj) {
+      const float v = wcol[(size_t)(jj < jn ? jj : 0) * Hd];
+      wr[jj] = (lane_ok && jj < jn) ? v : 0.f;
+    }
+  }
+  const int iu = tid < un ? tid : 0;
+  const int gu = u0 + iu;
+  __syncthreads();
+
+  for (int s = S - 1; s >= 0; --s) {
+    const size_t row = (size_t)s * B + b;
+    const unsigned tag = (unsigned)(S - s);
+    gru_u64* xb = xbuf + ((size_t)(tag & 1) * B + b) * H3;
+    if (tid < un) {
+      float dh = dout[row * Hd + gu] + dhz[iu];
+      for (int q = 0; q < c.ksb; ++q) dh += part[q * c.U + iu];
+      const float* rs = reserve + row * 4 * Hd;
+      const float r = rs[gu], z = rs[Hd + gu], n = rs[2 * Hd + gu], ghn = rs[3 * Hd + gu];
+      const float hp = h_all[(s > 0 ? row - B : row) * Hd + gu];
+      const float hprev = s > 0 ? hp : 0.f;
+      const float dn = dh * (1.f - z) * (1.f - n * n);
+      const float dz = dh * (hprev - n) * z * (1.f - z);
+      const float dr = dn * ghn * r * (1.f - r);
+      const float dnr = dn * r;
+      dgh[gu] = dr; dgh[Hd + gu] = dz; dgh[2 * Hd + gu] = dnr;
+      dhz[iu] = dh * z;
+      float* go = dgi + row * H3;
+      go[gu] = dr; go[Hd + gu] = dz; go[2 * Hd + gu] = dn;
+      dghn[row * Hd + gu] = dnr;
+      if (P > 1 && s > 0) {           // the last step's (s == 0) mat-vec result is never used
+        gru_publish(xb + gu, tag, dr);
+        gru_publish(xb + Hd + gu, tag, dz);
+        gru_publish(xb + 2 * Hd + gu, tag, dnr);
+      }
+    }
+    if (s == 0) break;
+    if (P > 1) {
+      for (int j = tid; j < H3; j += 1024) {
+        const int k = j % Hd;
+        if (k < u0 || k >= u0 + un) dgh[j] = gru_consume(xb + j, tag, status);
+      }
+    }
+    __syncthreads();
+    if (has) {
+      float a0 = 0.f, a1 = 0.f;
+      const float* gk = dgh + j0;
+#pragma unroll
+      for (int jj = 0; jj < KC; jj += 2) {
+        if ((jj & 15) == 0) __builtin_amdgcn_sched_barrier(0);
+        a0 = fmaf(wr[jj], gk[jj], a0);
+        a1 = fmaf(wr[jj + 1], gk[jj + 1], a1);
+      }
+      if (ul < un) part[jq * c.U + ul] = a0 + a1;
+    }
+    __syncthreads();
+  }
+}
+
 // ---- weight gradients: reductions over all (s,b) rows as split-K GEMMs ----------------------------------------
 // z = split: part[z][j][k | bias] = sum_{rows in split} dgh[row][j] * hprev[row][k]
 struct GruWhhGradOp {
@@ -228,30 +451,59 @@ __global__ void gru_reduce_grad_kernel(const float* __restrict__ part, int nspli
 static const int GRU_NSPLIT = 16;
 
 extern "C" size_t stemgnn_gru_reserve_floats(int B, int S, int Hd) { return (size_t)4 * S * B * Hd; }
+#include <stdlib.h>
+// cluster size: smallest P in {1,2,4,8} whose per-lane weight slice fits the register budget; 0 = use the
+// single-workgroup streaming kernels (very wide hidden states, or STEMGNN_GRU_CLUSTER=0)
+#define GRU_KC 48       // resident weights per lane (registers); the per-step loops are fully unrolled over it
+static int gru_pick_P(int B, int Hd) {
+  const char* e = getenv("STEMGNN_GRU_CLUSTER");
+  if (e && atoi(e) == 0) return 0;
+  for (int P = 1; P <= 8; P *= 2) {
+    const GruCluster c = gru_cluster_geom(Hd, P);
+    if (c.ksf >= 1 && c.ksb >= 1 && c.kcf <= GRU_KC && c.kcb <= GRU_KC && (size_t)B * P <= 224) return P;
+  }
+  return 0;
+}
+static size_t gru_xbuf_floats(int B, int Hd) { return (size_t)2 * 2 * B * 3 * Hd + 2; }   // u64 granules, 2 parities
+
 extern "C" size_t stemgnn_gru_fwd_scratch_floats(int B, int S, int Hd) {
-  return (size_t)3 * Hd * Hd + (size_t)3 * S * B * Hd;   // W_hh^T | gi
+  return (size_t)3 * Hd * Hd + (size_t)3 * S * B * Hd + gru_xbuf_floats(B, Hd);   // W_hh^T | gi | granules
 }
 extern "C" size_t stemgnn_gru_bwd_scratch_floats(int B, int S, int Hd, int W) {
-  return (size_t)4 * S * B * Hd + (size_t)GRU_NSPLIT * 3 * Hd * (Hd + 1) + (size_t)GRU_NSPLIT * 3 * Hd * (W + 1);
+  return (size_t)4 * S * B * Hd + (size_t)GRU_NSPLIT * 3 * Hd * (Hd + 1) + (size_t)GRU_NSPLIT * 3 * Hd * (W + 1) +
+         gru_xbuf_floats(B, Hd);
 }
 
 extern "C" int stemgnn_gru_fwd(const float* x, const float* w_ih, const float* w_hh, const float* b_ih,
                                const float* b_hh, int B, int S, int Hd, int W, float* scratch, float* h_all,
-                               float* reserve, void* stream) {
-  if (!x || !w_ih || !w_hh || !b_ih || !b_hh || !scratch || !h_all || !reserve || B <= 0 || S <= 0 || Hd <= 0 || W <= 0)
+                               float* reserve, int* status, void* stream) {
+  if (!x || !w_ih || !w_hh || !b_ih || !b_hh || !scratch || !h_all || !reserve || !status || B <= 0 || S <= 0 ||
+      Hd <= 0 || W <= 0)
     return SG_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   float* w_hhT = scratch;
   float* gi = scratch + (size_t)3 * Hd * Hd;
+  GruGiOp op{x, w_ih, b_ih, gi, B, S, Hd, W};
+  SG_TRY((sg_launch_gemm<GruGiOp, 64, 64, true, true, false>(op, S * B, 3 * Hd, 1, st)));
+  const int P = gru_pick_P(B, Hd);
+  if (P > 0) {
+    const GruCluster c = gru_cluster_geom(Hd, P);
+    gru_u64* xbuf = (gru_u64*)(scratch + ((((size_t)3 * Hd * Hd + (size_t)3 * S * B * Hd) + 1) & ~(size_t)1));   // 8-B aligned
+    if (P > 1) SG_TRY(hipMemsetAsync(xbuf, 0, (size_t)2 * B * Hd * sizeof(gru_u64), st));   // tags := 0 every launch
+    const size_t lds = (size_t)(Hd + GRU_KC + c.ksf * 3 * c.U) * sizeof(float);
+    const dim3 grid(8 * ((B + 7) / 8) * P);
+    hipLaunchKernelGGL(gru_fwd_cluster_kernel<GRU_KC>, grid, dim3(1024), lds, st, gi, w_hh, b_hh, B, S, Hd, P, xbuf,
+                       status, h_all, reserve);
+    SG_TRY(hipGetLastError());
+    return 0;
+  }
   hipLaunchKernelGGL(gru_transpose_kernel, dim3((Hd + 31) / 32, (3 * Hd + 31) / 32), dim3(256), 0, st, w_hh, w_hhT,
                      3 * Hd, Hd);
   SG_TRY(hipGetLastError());
-  GruGiOp op{x, w_ih, b_ih, gi, B, S, Hd, W};
-  SG_TRY((sg_launch_gemm<GruGiOp, 64, 64, true, true, false>(op, S * B, 3 * Hd, 1, st)));
   const int nub = (Hd + 63) / 64;
   const int ks = nub >= 16 ? 1 : 16 / nub;
   const size_t lds = (size_t)(Hd + ks * 3 * Hd) * sizeof(float);
-  if (lds > 150 * 1024) return SG_EINVAL;
+  if (lds > 64 * 1024) return SG_EINVAL;
   hipLaunchKernelGGL(gru_fwd_kernel, dim3(B), dim3(1024), lds, st, gi, w_hhT, b_hh, B, S, Hd, h_all, reserve);
   SG_TRY(hipGetLastError());
   return 0;
@@ -259,21 +511,33 @@ extern "C" int stemgnn_gru_fwd(const float* x, const float* w_ih, const float* w
 
 extern "C" int stemgnn_gru_bwd(const float* dh_all, const float* x, const float* w_hh, const float* h_all,
                                const float* reserve, int B, int S, int Hd, int W, float* scratch, float* dw_ih,
-                               float* dw_hh, float* db_ih, float* db_hh, void* stream) {
-  if (!dh_all || !x || !w_hh || !h_all || !reserve || !scratch || !dw_ih || !dw_hh || !db_ih || !db_hh || B <= 0 ||
-      S <= 0 || Hd <= 0 || W <= 0)
+                               float* dw_hh, float* db_ih, float* db_hh, int* status, void* stream) {
+  if (!dh_all || !x || !w_hh || !h_all || !reserve || !scratch || !dw_ih || !dw_hh || !db_ih || !db_hh || !status ||
+      B <= 0 || S <= 0 || Hd <= 0 || W <= 0)
     return SG_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   float* dgi = scratch;
   float* dghn = dgi + (size_t)3 * S * B * Hd;
   float* p_hh = dghn + (size_t)S * B * Hd;
   float* p_ih = p_hh + (size_t)GRU_NSPLIT * 3 * Hd * (Hd + 1);
-  const int nub = (Hd + 63) / 64;
-  const int js = nub >= 16 ? 1 : 16 / nub;
-  const size_t lds = (size_t)(4 * Hd + js * Hd) * sizeof(float);
-  if (lds > 150 * 1024) return SG_EINVAL;
-  hipLaunchKernelGGL(gru_bwd_kernel, dim3(B), dim3(1024), lds, st, dh_all, w_hh, h_all, reserve, B, S, Hd, dgi, dghn);
-  SG_TRY(hipGetLastError());
+  const int P = gru_pick_P(B, Hd);
+  if (P > 0) {
+    const GruCluster c = gru_cluster_geom(Hd, P);
+    gru_u64* xbuf = (gru_u64*)(scratch + ((((size_t)(p_ih - scratch) + (size_t)GRU_NSPLIT * 3 * Hd * (W + 1)) + 1) & ~(size_t)1));
+    if (P > 1) SG_TRY(hipMemsetAsync(xbuf, 0, (size_t)2 * B * 3 * Hd * sizeof(gru_u64), st));
+    const size_t lds = (size_t)(3 * Hd + GRU_KC + c.U + c.ksb * c.U) * sizeof(float);
+    const dim3 grid(8 * ((B + 7) / 8) * P);
+    hipLaunchKernelGGL(gru_bwd_cluster_kernel<GRU_KC>, grid, dim3(1024), lds, st, dh_all, w_hh, h_all, reserve, B, S, Hd, P,
+                       xbuf, status, dgi, dghn);
+    SG_TRY(hipGetLastError());
+  } else {
+    const int nub = (Hd + 63) / 64;
+    const int js = nub >= 16 ? 1 : 16 / nub;
+    const size_t lds = (size_t)(4 * Hd + js * Hd) * sizeof(float);
+    if (lds > 64 * 1024) return SG_EINVAL;
+    hipLaunchKernelGGL(gru_bwd_kernel, dim3(B), dim3(1024), lds, st, dh_all, w_hh, h_all, reserve, B, S, Hd, dgi, dghn);
+    SG_TRY(hipGetLastError());
+  }
   const int rows = S * B;
   const int chunk = ((rows + GRU_NSPLIT - 1) / GRU_NSPLIT + 15) & ~15;
   GruWhhGradOp o1{dgi, dghn, h_all, p_hh, B, S, Hd, GRU_NSPLIT, chunk};

@@ -54,6 +54,26 @@ def dropout_mask(drop_p, seed, B, N):
     return mask
 
 
+_gru_status = {}
+
+
+def gru_status(device):
+    """Device int32 the cluster GRU kernels set to 1 if an inter-workgroup wait timed out (never expected)."""
+    key = str(device)
+    t = _gru_status.get(key)
+    if t is None:
+        t = torch.zeros(1, dtype=torch.int32, device=device)
+        _gru_status[key] = t
+    return t
+
+
+def check_gru_status(device):
+    """Host sync + raise if a GRU exchange timed out (call outside timed regions / in tests)."""
+    if int(gru_status(device).item()) != 0:
+        raise _lib.StemGNNHipError("GRU cluster exchange timed out (partner workgroup not resident?); "
+                                   "set STEMGNN_GRU_CLUSTER=0 to use the single-workgroup kernels")
+
+
 class GruFront(torch.autograd.Function):
     """nn.GRU(time_step, units) over the node axis (reference models/base_model.py:137) as two persistent HIP
     recurrence kernels.  (x [B,W,N], weight_ih_l0, weight_hh_l0, bias_ih_l0, bias_hh_l0) -> h [N,B,N]."""
@@ -72,8 +92,8 @@ class GruFront(torch.autograd.Function):
         reserve = torch.empty(lib.stemgnn_gru_reserve_floats(B, S, Hd), device=dev, dtype=f32)
         scratch = torch.empty(lib.stemgnn_gru_fwd_scratch_floats(B, S, Hd), device=dev, dtype=f32)
         _lib.check(lib.stemgnn_gru_fwd(x.data_ptr(), w_ih.data_ptr(), w_hh.data_ptr(), b_ih.data_ptr(), b_hh.data_ptr(),
-                                       B, S, Hd, W, scratch.data_ptr(), h_all.data_ptr(), reserve.data_ptr(), _stream()),
-                   "gru_fwd")
+                                       B, S, Hd, W, scratch.data_ptr(), h_all.data_ptr(), reserve.data_ptr(),
+                                       gru_status(dev).data_ptr(), _stream()), "gru_fwd")
         # save_for_backward (not ctx attributes): h_all is an OUTPUT -- holding it on ctx would form a
         # ctx <-> grad_fn reference cycle that never frees the step's buffers
         ctx.save_for_backward(x, w_ih, w_hh, h_all, reserve)
@@ -93,7 +113,8 @@ class GruFront(torch.autograd.Function):
         db_hh = torch.empty(3 * Hd, device=dev, dtype=f32)
         _lib.check(lib.stemgnn_gru_bwd(dh_all.data_ptr(), x.data_ptr(), w_hh.data_ptr(), h_all.data_ptr(),
                                        reserve.data_ptr(), B, S, Hd, W, scratch.data_ptr(), dw_ih.data_ptr(),
-                                       dw_hh.data_ptr(), db_ih.data_ptr(), db_hh.data_ptr(), _stream()), "gru_bwd")
+                                       dw_hh.data_ptr(), db_ih.data_ptr(), db_hh.data_ptr(),
+                                       gru_status(dev).data_ptr(), _stream()), "gru_bwd")
         return None, dw_ih, dw_hh, db_ih, db_hh
 
 

@@ -10,8 +10,10 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-4
 
 
-@pytest.mark.parametrize("B,S,W", [(32, 228, 12), (5, 33, 7), (3, 140, 12), (2, 300, 4)])
-def test_gru_fwd_bwd_vs_torch_cpu(B, S, W):
+@pytest.mark.parametrize("cluster", ["1", "0"])
+@pytest.mark.parametrize("B,S,W", [(32, 228, 12), (5, 33, 7), (3, 140, 12), (2, 300, 4), (9, 358, 12), (1, 64, 3)])
+def test_gru_fwd_bwd_vs_torch_cpu(B, S, W, cluster, monkeypatch):
+    monkeypatch.setenv("STEMGNN_GRU_CLUSTER", cluster)      # 1: multi-CU register-resident kernels, 0: streaming
     from stemgnn_amd.ops import GruFront
 
     torch.manual_seed(S + B)
@@ -25,6 +27,8 @@ def test_gru_fwd_bwd_vs_torch_cpu(B, S, W):
     h = GruFront.apply(x.cuda(), *params)
     h.backward(dh.cuda())
     torch.cuda.synchronize()
+    from stemgnn_amd.ops import check_gru_status
+    check_gru_status(torch.device("cuda:0"))
     assert relerr(h, out.detach()) < TOL
     for mine, ref in zip(params, (gru.weight_ih_l0, gru.weight_hh_l0, gru.bias_ih_l0, gru.bias_hh_l0)):
         assert relerr(mine.grad, ref.grad) < TOL
