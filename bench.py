@@ -167,8 +167,10 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    from stemgnn_amd import Model
+    from stemgnn_amd import Model, ops
     from stemgnn_amd.distributed import FlatGradBucket, broadcast_parameters
+
+    ops.set_direct_grad(True)      # the step zeroes the flat bucket first, so overwrite == accumulate (one fewer launch per parameter)
 
     cfg = dict(WORKLOAD)
     torch.manual_seed(0)

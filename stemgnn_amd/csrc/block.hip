@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 
 #include "../../include/stemgnn_hip.h"
+#include "gemm2.h"
 #include "gemm_core.h"
 #include "layout.h"
 
@@ -101,106 +102,108 @@ struct GftBwdDtOp {
 };
 
 // =================================================================================================
-// GLU layer forward (both branches, z = branch):  out = (x Wl + bl) * sigmoid(x Wr + br)
+// GLU layers on the 128x128 MFMA GEMM (gemm2.h).  Epilogues:
 // =================================================================================================
-struct GluFwdOp {
-  const float* x[2];
-  const float* wp[2];
+// forward: out = (x Wl + bl) * sigmoid(x Wr + br).  Packed "pair" columns: within a 32-column MFMA tile lanes
+// 0-15 hold the linear_left result and lanes 16-31 the linear_right result of the SAME 16 channels, so one
+// cross-lane exchange (lane ^ 16) brings u and v together; left lanes store `out`, right lanes store the gate.
+struct GluFwdEpi {
   const float* bp[2];
   float* out[2];
   float* gate[2];
-  int np[2];
-  int ldx, kin, M;
-  __device__ bool setup(int z, int& M_, int& N_, int& K0, int& K1) const {
-    M_ = M; N_ = np[z]; K0 = 0; K1 = kin;
-    return true;
-  }
-  __device__ float a(int z, int i, int k) const { return x[z][(size_t)i * ldx + k]; }
-  __device__ float b(int z, int k, int j) const { return wp[z][(size_t)k * np[z] + j]; }
-  __device__ void epi(int, int, int, float) const {}
-  __device__ void epi2(int z, int i, int c, float u, float v) const {
-    const int q = ((c >> 4) << 5) + (c & 15);
-    u += bp[z][q];
-    v += bp[z][q + 16];
-    const float g = sg_sigmoid(v);
-    const size_t o = (size_t)i * (np[z] >> 1) + c;
-    out[z][o] = u * g;
-    gate[z][o] = g;
+  int cp[2];
+  __device__ void tile(int r, int, int row0, int col0, int M, int N, const sg_f32x16& acc, int lane) const {
+    const bool right = (lane & 16) != 0;
+    const int c = (col0 >> 1) + (lane & 15);
+    const bool live = col0 < N;
+    const float bl = live ? bp[r][col0 + (lane & 15)] : 0.f, br = live ? bp[r][col0 + 16 + (lane & 15)] : 0.f;
+    float* dst = right ? gate[r] : out[r];
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      const float mine = acc[reg];
+      const float other = __shfl_xor(mine, 16, 64);
+      const float u = (right ? other : mine) + bl, v = (right ? mine : other) + br;
+      const float g = sg_sigmoid(v);
+      const int row = row0 + g2_row_of(reg, lane);
+      if (live && row < M) dst[(size_t)row * cp[r] + c] = right ? g : u * g;
+    }
   }
 };
 
-// d(pre-activation) of a GLU layer, packed "pair" column q:  left: dout*g ; right: dout*out*(1-g)
-struct GluDpre {
-  const float* dout[2];
+// data gradient of layer l -> d(pre-activation) of layer l-1 in pair order:
+//   d = dX[row][c];  left: d * gate ; right: d * out * (1 - gate)       (GLU backward)
+struct GluDpreEpi {
   const float* out[2];
   const float* gate[2];
-  int cp[2];
-  __device__ __forceinline__ float at(int r, int m, int q) const {
-    const int c = ((q >> 5) << 4) + (q & 15);
-    const size_t o = (size_t)m * cp[r] + c;
-    const float d = dout[r][o], g = gate[r][o], y = out[r][o];     // all three loads unconditional
-    return (q & 16) ? d * y * (1.f - g) : d * g;
+  float* dpre[2];
+  int cp;      // channels of layer l-1 (= N), its pair panel is 2*cp wide
+  __device__ void tile(int r, int, int row0, int col0, int M, int N, const sg_f32x16& acc, int lane) const {
+    const int c = col0 + (lane & 31);
+    if (c >= N) return;
+    const int q = ((c >> 4) << 5) + (c & 15);
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      const int row = row0 + g2_row_of(reg, lane);
+      if (row < M) {
+        const size_t o = (size_t)row * cp + c;
+        const float d = acc[reg], g = gate[r][o], y = out[r][o];
+        float* dp = dpre[r] + (size_t)row * 2 * cp + q;
+        dp[0] = d * g;
+        dp[16] = d * y * (1.f - g);
+      }
+    }
   }
 };
 
-// GLU data gradient, layers 1 and 2 (z = branch): dx[m][kin] = sum_q dpre[m][q] Wp[kin][q]
-struct GluDgradOp {
-  GluDpre dp;
-  const float* wp[2];
-  int np[2];
-  float* dx[2];
-  int ldd, kin, M;
-  __device__ bool setup(int z, int& M_, int& N_, int& K0, int& K1) const {
-    M_ = M; N_ = kin; K0 = 0; K1 = np[z];
-    return true;
-  }
-  __device__ float a(int z, int i, int k) const { return dp.at(z, i, k); }
-  __device__ float b(int z, int k, int j) const { return wp[z][(size_t)j * np[z] + k]; }
-  __device__ void epi(int z, int i, int j, float v) const { dx[z][(size_t)i * ldd + j] = v; }
-};
-
-// GLU data gradient of layer 0: both branches feed the same G, so K spans Re then Im columns
+// layer-0 data gradient: dG[m][kin] = sum_r sum_q dpre_r[m][q] Wp0_r[kin][q]  (N = 3W is tiny: the 64-wide generic
+// tile wastes far less than a 128-wide one, and K concatenates the two branches in one launch)
 struct GluDgrad0Op {
-  GluDpre dp;
+  const float* dpre[2];
   const float* wp[2];
-  int np0;
   float* dG;
-  int KG, M;
+  int np0, KG, M;
   __device__ bool setup(int, int& M_, int& N_, int& K0, int& K1) const {
     M_ = M; N_ = KG; K0 = 0; K1 = 2 * np0;
     return true;
   }
   __device__ float a(int, int i, int k) const {
-    const int r = k >= np0;
-    return dp.at(r, i, k - r * np0);
+    const float* p = k < np0 ? dpre[0] + (size_t)i * np0 + k : dpre[1] + (size_t)i * np0 + (k - np0);
+    return *p;
   }
   __device__ float b(int, int k, int j) const {
-    const int r = k >= np0;
-    return wp[r][(size_t)j * np0 + (k - r * np0)];
+    const float* p = k < np0 ? wp[0] + (size_t)j * np0 + k : wp[1] + (size_t)j * np0 + (k - np0);
+    return *p;
   }
   __device__ void epi(int, int i, int j, float v) const { dG[(size_t)i * KG + j] = v; }
 };
 
-// GLU weight gradient (z = branch*S + split): part[q][kin|bias] = sum_{m in split} dpre[m][q] x[m][kin]
-struct GluWgradOp {
-  GluDpre dp;
-  const float* x[2];
+struct GluPlainEpi {   // C (+)= acc, row-major
+  float* C;
+  int ldc, accumulate;
+  __device__ void tile(int, int, int row0, int col0, int M, int N, const sg_f32x16& acc, int lane) const {
+    const int c = col0 + (lane & 31);
+    if (c >= N) return;
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      const int row = row0 + g2_row_of(reg, lane);
+      if (row < M) {
+        float* o = C + (size_t)row * ldc + c;
+        *o = accumulate ? *o + acc[reg] : acc[reg];
+      }
+    }
+  }
+};
+
+struct GluWgradEpi {   // split-K slab: part[r][s][q][kin | bias]
   float* part[2];
-  int np[2];
-  int ldx, kin, M, S, chunk;
-  __device__ bool setup(int z, int& M_, int& N_, int& K0, int& K1) const {
-    const int r = z / S, s = z - r * S;
-    M_ = np[r]; N_ = kin + 1; K0 = s * chunk; K1 = min(M, K0 + chunk);
-    return true;
-  }
-  __device__ float a(int z, int i, int k) const { return dp.at(z / S, k, i); }
-  __device__ float b(int z, int k, int j) const {
-    const float v = x[z / S][(size_t)k * ldx + (j < kin ? j : kin - 1)];     // branch-free: load, then select
-    return j < kin ? v : 1.f;
-  }
-  __device__ void epi(int z, int i, int j, float v) const {
-    const int r = z / S, s = z - r * S;
-    part[r][((size_t)s * np[r] + i) * (kin + 1) + j] = v;
+  __device__ void tile(int r, int s, int row0, int col0, int M, int N, const sg_f32x16& acc, int lane) const {
+    const int c = col0 + (lane & 31);
+    if (c >= N) return;
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      const int row = row0 + g2_row_of(reg, lane);
+      if (row < M) part[r][((size_t)s * M + row) * N + c] = acc[reg];
+    }
   }
 };
 
@@ -323,10 +326,12 @@ struct DigOp {  // dig = dpF F + dpB BC
   __device__ void epi(int, int i, int j, float v) const { dig[(size_t)i * Wm + j] = v; }
 };
 
-struct Da3Op {  // z = branch: d(last GLU out)[m][c] = sum_o dig[m][o] Wfold[roff+c][o]
+struct Da3Op {  // z = branch: d(last GLU out)[m][c] = sum_o dig[m][o] Wfold[roff+c][o]  -> its d(pre-activation)
   const float* dig;
   const float* wfold;
-  float* da3[2];
+  const float* out[2];
+  const float* gate[2];
+  float* dpre[2];
   int cp2[2];
   int M, Wm, WmP;
   __device__ bool setup(int z, int& M_, int& N_, int& K0, int& K1) const {
@@ -335,7 +340,13 @@ struct Da3Op {  // z = branch: d(last GLU out)[m][c] = sum_o dig[m][o] Wfold[rof
   }
   __device__ float a(int, int i, int k) const { return dig[(size_t)i * Wm + k]; }
   __device__ float b(int z, int k, int j) const { return wfold[(size_t)((z ? cp2[0] : 0) + j) * WmP + k]; }
-  __device__ void epi(int z, int i, int j, float v) const { da3[z][(size_t)i * cp2[z] + j] = v; }
+  __device__ void epi(int z, int i, int j, float v) const {
+    const size_t o = (size_t)i * cp2[z] + j;
+    const float g = gate[z][o], y = out[z][o];
+    float* dp = dpre[z] + (size_t)i * 2 * cp2[z] + ((j >> 4) << 5) + (j & 15);
+    dp[0] = v * g;
+    dp[16] = v * y * (1.f - g);
+  }
 };
 
 // weight gradients of the heads + Wfold, z = which*S + split
@@ -429,20 +440,21 @@ extern "C" int stemgnn_spectral_glu_fwd(const float* packed, float* saved, int B
   const SgSavedLayout S = sg_saved_layout(d);
   hipStream_t st = (hipStream_t)stream;
   for (int l = 0; l < 3; ++l) {
-    GluFwdOp op;
+    G2Args g;
+    GluFwdEpi e;
     for (int r = 0; r < 2; ++r) {
-      op.x[r] = l == 0 ? saved + S.G : saved + S.out[r][l - 1];
-      op.wp[r] = packed + P.w[r][l];
-      op.bp[r] = packed + P.b[r][l];
-      op.out[r] = saved + S.out[r][l];
-      op.gate[r] = saved + S.gate[r][l];
-      op.np[r] = sg_glu_np(d, l, r);
+      g.A[r] = l == 0 ? saved + S.G : saved + S.out[r][l - 1];
+      g.lda[r] = l == 0 ? d.KG : d.CP;
+      g.B[r] = packed + P.w[r][l];
+      g.ldb[r] = sg_glu_np(d, l, r);
+      g.M[r] = d.M; g.N[r] = sg_glu_np(d, l, r); g.K[r] = sg_glu_kin(d, l);
+      e.bp[r] = packed + P.b[r][l];
+      e.out[r] = saved + S.out[r][l];
+      e.gate[r] = saved + S.gate[r][l];
+      e.cp[r] = sg_glu_cp(d, l, r);
     }
-    op.ldx = l == 0 ? d.KG : d.CP;
-    op.kin = sg_glu_kin(d, l);
-    op.M = d.M;
-    const int maxN = op.np[0] > op.np[1] ? op.np[0] : op.np[1];
-    SG_TRY((sg_launch_gemm<GluFwdOp, 128, 64, true, false, true>(op, d.M, maxN, 2, st)));
+    g.nsplit = 1; g.chunk = (sg_glu_kin(d, l) + 15) & ~15; g.b_ones_col = -1;
+    SG_TRY((g2_launch<GluFwdEpi, true, false>(g, e, 2, st)));
   }
   return 0;
 }
@@ -460,47 +472,43 @@ extern "C" int stemgnn_spectral_glu_bwd(const float* packed, const float* saved,
   hipStream_t st = (hipStream_t)stream;
   const int chunk = split_chunk(d.M, nsplit);
   for (int l = 2; l >= 0; --l) {
-    // d(out of layer l) lives in dact[r][(2-l)&1]: l=2 -> slot 0 (ld CP2), l=1 -> slot 1, l=0 -> slot 0
-    const int slot_in = (2 - l) & 1;
-    GluDpre dp;
-    for (int r = 0; r < 2; ++r) {
-      dp.dout[r] = scratch + C.dact[r][slot_in];
-      dp.out[r] = saved + S.out[r][l];
-      dp.gate[r] = saved + S.gate[r][l];
-      dp.cp[r] = sg_glu_cp(d, l, r);
-    }
-    {  // weight gradient
-      GluWgradOp op;
-      op.dp = dp;
+    // d(pre-activation) of layer l lives in dact[r][(2-l)&1] as [M x NP(l,r)] (pair order); it was written by
+    // igft_heads_bwd (l = 2) or by the data-gradient epilogue of layer l+1
+    const int slot = (2 - l) & 1;
+    {  // weight gradient: part[q][kin | bias] = sum_m dpre[m][q] * x[m][kin]   (split over the M rows)
+      G2Args g;
+      GluWgradEpi e;
       for (int r = 0; r < 2; ++r) {
-        op.x[r] = l == 0 ? saved + S.G : saved + S.out[r][l - 1];
-        op.part[r] = gradpart + Gl.w[r][l];
-        op.np[r] = sg_glu_np(d, l, r);
+        g.A[r] = scratch + C.dact[r][slot];
+        g.lda[r] = sg_glu_np(d, l, r);
+        g.B[r] = l == 0 ? saved + S.G : saved + S.out[r][l - 1];
+        g.ldb[r] = l == 0 ? d.KG : d.CP;
+        g.M[r] = sg_glu_np(d, l, r); g.N[r] = sg_glu_kin(d, l) + 1; g.K[r] = d.M;
+        e.part[r] = gradpart + Gl.w[r][l];
       }
-      op.ldx = l == 0 ? d.KG : d.CP;
-      op.kin = sg_glu_kin(d, l);
-      op.M = d.M; op.S = nsplit; op.chunk = chunk;
-      const int maxM = op.np[0] > op.np[1] ? op.np[0] : op.np[1];
-      SG_TRY((sg_launch_gemm<GluWgradOp, 64, 64, false, false, false>(op, maxM, op.kin + 1, 2 * nsplit, st)));
+      g.nsplit = nsplit; g.chunk = chunk; g.b_ones_col = sg_glu_kin(d, l);
+      SG_TRY((g2_launch<GluWgradEpi, false, false>(g, e, 2, st)));
     }
-    if (l > 0) {  // data gradient -> d(out of layer l-1)
-      GluDgradOp op;
-      op.dp = dp;
+    if (l > 0) {  // data gradient -> d(pre-activation) of layer l-1
+      G2Args g;
+      GluDpreEpi e;
       for (int r = 0; r < 2; ++r) {
-        op.wp[r] = packed + P.w[r][l];
-        op.np[r] = sg_glu_np(d, l, r);
-        op.dx[r] = scratch + C.dact[r][slot_in ^ 1];
+        g.A[r] = scratch + C.dact[r][slot];
+        g.lda[r] = sg_glu_np(d, l, r);
+        g.B[r] = packed + P.w[r][l];
+        g.ldb[r] = sg_glu_np(d, l, r);
+        g.M[r] = d.M; g.N[r] = d.CP; g.K[r] = sg_glu_np(d, l, r);
+        e.out[r] = saved + S.out[r][l - 1];
+        e.gate[r] = saved + S.gate[r][l - 1];
+        e.dpre[r] = scratch + C.dact[r][slot ^ 1];
       }
-      op.ldd = d.CP; op.kin = d.CP; op.M = d.M;
-      SG_TRY((sg_launch_gemm<GluDgradOp, 128, 64, true, true, false>(op, d.M, d.CP, 2, st)));
-    } else {
+      e.cp = d.CP;
+      g.nsplit = 1; g.chunk = (2 * d.CP + 15) & ~15; g.b_ones_col = -1;
+      SG_TRY((g2_launch<GluDpreEpi, true, true>(g, e, 2, st)));
+    } else {      // layer 0: both branches feed the same G -> one launch with K = Re columns then Im columns
       GluDgrad0Op op;
-      op.dp = dp;
-      op.wp[0] = packed + P.w[0][0];
-      op.wp[1] = packed + P.w[1][0];
-      op.np0 = sg_glu_np(d, 0, 0);
-      op.dG = scratch + C.dG;
-      op.KG = d.KG; op.M = d.M;
+      for (int r = 0; r < 2; ++r) { op.dpre[r] = scratch + C.dact[r][slot]; op.wp[r] = packed + P.w[r][0]; }
+      op.dG = scratch + C.dG; op.np0 = sg_glu_np(d, 0, 0); op.KG = d.KG; op.M = d.M;
       SG_TRY((sg_launch_gemm<GluDgrad0Op, 32, 64, true, true, false>(op, d.M, d.KG, 1, st)));
     }
   }
@@ -574,7 +582,12 @@ extern "C" int stemgnn_igft_heads_bwd(const float* const* params_host, const flo
   {
     Da3Op op;
     op.dig = dig; op.wfold = packed + P.wfold;
-    for (int r = 0; r < 2; ++r) { op.da3[r] = scratch + C.dact[r][0]; op.cp2[r] = d.CP2[r]; }
+    for (int r = 0; r < 2; ++r) {
+      op.dpre[r] = scratch + C.dact[r][0];
+      op.out[r] = saved + S.out[r][2];
+      op.gate[r] = saved + S.gate[r][2];
+      op.cp2[r] = d.CP2[r];
+    }
     op.M = d.M; op.Wm = d.Wm; op.WmP = d.WmP;
     const int maxN = d.CP2[0] > d.CP2[1] ? d.CP2[0] : d.CP2[1];
     SG_TRY((sg_launch_gemm<Da3Op, 64, 64, true, true, false>(op, d.M, maxN, 2, st)));

@@ -1,0 +1,190 @@
+// High-throughput exact-fp32 MFMA GEMM for the GLU family (forward / data-gradient / weight-gradient),
+// plain row-major operands.  gfx950: v_mfma_f32_32x32x2_f32, wave64.
+//
+//   * block tile 128 x 128 x 16, 256 threads = 4 waves (2 x 2), each wave 64 x 64 = 2 x 2 MFMA tiles of
+//     32 x 32 (64 accumulator registers); per k-step of 2: 2 + 2 LDS fragment reads feed 4 MFMAs of 64 cycles.
+//   * both operands are staged K-major in LDS (As[k][i], Bs[k][j], row stride 132 floats).  An operand whose
+//     global layout is contiguous along i/j is moved with 16-byte global loads + ds_write_b128; an operand that
+//     is contiguous along k (x[m][k], W^T) is moved with 16-byte global loads (4 k's of one row; 4 adjacent
+//     lanes cover a 64-byte row segment) + 4 ds_write_b32 (2-way bank aliasing only, free for b32 stores).
+//   * LDS is double buffered and the next K tile is prefetched into registers before the MFMA loop of the
+//     current one: one barrier per K tile.
+//   * z = branch * nsplit + split: two problems (Re / Im branch) per launch, optional split over the K range
+//     (weight gradients reduce over the M = B*N rows).
+//   * shapes that break the 16-byte alignment rules (odd W*multi ...) run the same kernel with VEC = false
+//     (scalar, fully predicated loads).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float sg_f32x16 __attribute__((ext_vector_type(16)));
+
+struct G2Args {
+  const float* A[2];
+  const float* B[2];
+  int lda[2], ldb[2];
+  int M[2], N[2], K[2];   // per branch: output M x N, reduction length K
+  int nsplit, chunk;      // K range of split s: [s*chunk, min(K, (s+1)*chunk))
+  int b_ones_col;         // >= 0: column j of B that reads as 1.0 (bias-gradient trick), data columns are j < b_ones_col
+};
+
+constexpr int G2_BM = 128, G2_BN = 128, G2_BK = 16, G2_LD = 132;
+
+// D layout of v_mfma_f32_32x32x2_f32: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+__device__ __forceinline__ int g2_row_of(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
+
+template <bool KCONTIG, bool VEC>
+struct G2Loader {
+  // fetch the 2 float4 this thread stages for a (128 x 16) operand tile.  rows = i (or j) extent, kk = K limit
+  static __device__ __forceinline__ void load(const float* __restrict__ P, int ld, int i0, int imax, int kb, int kmax,
+                                              int ones_col, int tid, float4 (&v)[2]) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int f = tid + 256 * t;
+      float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+      if constexpr (KCONTIG) {            // element (i, k) at P[i*ld + k]; float4 = 4 k's of row i
+        const int i = i0 + (f >> 2), k = kb + ((f & 3) << 2);
+        if constexpr (VEC) {
+          const bool ok = i < imax && k < kmax;               // K % 4 == 0 is guaranteed on the VEC path
+          const float4 x = *reinterpret_cast<const float4*>(P + (size_t)(ok ? i : 0) * ld + (ok ? k : 0));
+          if (ok) r = x;
+        } else {
+          const float* p = P + (size_t)(i < imax ? i : 0) * ld;
+          const float a = p[k < kmax ? k : 0], b = p[k + 1 < kmax ? k + 1 : 0], c = p[k + 2 < kmax ? k + 2 : 0],
+                      d = p[k + 3 < kmax ? k + 3 : 0];
+          const bool io = i < imax;
+          r = make_float4(io && k < kmax ? a : 0.f, io && k + 1 < kmax ? b : 0.f, io && k + 2 < kmax ? c : 0.f,
+                          io && k + 3 < kmax ? d : 0.f);
+        }
+      } else {                            // element (i, k) at P[k*ld + i]; float4 = 4 i's of row k
+        const int k = kb + (f >> 5), i = i0 + ((f & 31) << 2);
+        const int idata = ones_col >= 0 ? ones_col : imax;    // columns that exist in memory
+        if constexpr (VEC) {
+          const bool ok = k < kmax && i < idata;                // idata % 4 == 0 is guaranteed on the VEC path
+          const float4 x = *reinterpret_cast<const float4*>(P + (size_t)(ok ? k : 0) * ld + (ok ? i : 0));
+          if (ok) r = x;
+        } else {
+          const float* p = P + (size_t)(k < kmax ? k : 0) * ld;
+          const float a = p[i < idata ? i : 0], b = p[i + 1 < idata ? i + 1 : 0], c = p[i + 2 < idata ? i + 2 : 0],
+                      d = p[i + 3 < idata ? i + 3 : 0];
+          const bool ko = k < kmax;
+          r = make_float4(ko && i < idata ? a : 0.f, ko && i + 1 < idata ? b : 0.f, ko && i + 2 < idata ? c : 0.f,
+                          ko && i + 3 < idata ? d : 0.f);
+        }
+        if (ones_col >= 0 && k < kmax) {
+          if (i == ones_col) r.x = 1.f;
+          if (i + 1 == ones_col) r.y = 1.f;
+          if (i + 2 == ones_col) r.z = 1.f;
+          if (i + 3 == ones_col) r.w = 1.f;
+        }
+      }
+      v[t] = r;
+    }
+  }
+  // write the staged values K-major into LDS: T[k][i]
+  static __device__ __forceinline__ void store(float* __restrict__ T, int tid, const float4 (&v)[2]) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int f = tid + 256 * t;
+      if constexpr (KCONTIG) {
+        const int i = f >> 2, k = (f & 3) << 2;
+        T[(k + 0) * G2_LD + i] = v[t].x;
+        T[(k + 1) * G2_LD + i] = v[t].y;
+        T[(k + 2) * G2_LD + i] = v[t].z;
+        T[(k + 3) * G2_LD + i] = v[t].w;
+      } else {
+        const int k = f >> 5, i = (f & 31) << 2;
+        *reinterpret_cast<float4*>(T + k * G2_LD + i) = v[t];
+      }
+    }
+  }
+};
+
+template <class Epi, bool A_KC, bool B_KC, bool VEC>
+__global__ __launch_bounds__(256) void sg_gemm2(const G2Args g, const Epi epi) {
+  __shared__ __attribute__((aligned(16))) float lds[2 * 2 * G2_BK * G2_LD];
+  const int z = blockIdx.z;
+  const int r = z / g.nsplit, s = z - r * g.nsplit;
+  const int M = g.M[r], N = g.N[r], K = g.K[r];
+  const int m0 = blockIdx.x * G2_BM, n0 = blockIdx.y * G2_BN;
+  if (m0 >= M || n0 >= N) return;
+  const int K0 = s * g.chunk, K1 = min(K, K0 + g.chunk);
+  const float* __restrict__ A = g.A[r];
+  const float* __restrict__ Bp = g.B[r];
+  const int lda = g.lda[r], ldb = g.ldb[r];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  sg_f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  float4 ra[2], rb[2];
+  using LA = G2Loader<A_KC, VEC>;
+  using LB = G2Loader<B_KC, VEC>;
+  if (K0 < K1) {
+    LA::load(A, lda, m0, M, K0, K1, -1, tid, ra);
+    LB::load(Bp, ldb, n0, N, K0, K1, g.b_ones_col, tid, rb);
+    LA::store(lds, tid, ra);
+    LB::store(lds + G2_BK * G2_LD, tid, rb);
+  }
+  __syncthreads();
+  int buf = 0;
+  for (int kb = K0; kb < K1; kb += G2_BK) {
+    const bool more = kb + G2_BK < K1;
+    if (more) {
+      LA::load(A, lda, m0, M, kb + G2_BK, K1, -1, tid, ra);
+      LB::load(Bp, ldb, n0, N, kb + G2_BK, K1, g.b_ones_col, tid, rb);
+    }
+    const float* As = lds + buf * (2 * G2_BK * G2_LD);
+    const float* Bs = As + G2_BK * G2_LD;
+    const int fi = lane & 31, fk = lane >> 5;
+#pragma unroll
+    for (int ks = 0; ks < G2_BK; ks += 2) {
+      const float a0 = As[(ks + fk) * G2_LD + wm * 64 + fi], a1 = As[(ks + fk) * G2_LD + wm * 64 + 32 + fi];
+      const float b0 = Bs[(ks + fk) * G2_LD + wn * 64 + fi], b1 = Bs[(ks + fk) * G2_LD + wn * 64 + 32 + fi];
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    }
+    if (more) {
+      float* An = lds + (buf ^ 1) * (2 * G2_BK * G2_LD);
+      LA::store(An, tid, ra);
+      LB::store(An + G2_BK * G2_LD, tid, rb);
+    }
+    __syncthreads();
+    buf ^= 1;
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      epi.tile(r, s, m0 + wm * 64 + i * 32, n0 + wn * 64 + j * 32, M, N, acc[i][j], lane);
+}
+
+// 16-byte alignment rules of the VEC path
+static inline bool g2_aligned(const void* p, int ld) { return (((uintptr_t)p) & 15) == 0 && (ld & 3) == 0; }
+
+template <class Epi, bool A_KC, bool B_KC>
+static inline hipError_t g2_launch(const G2Args& g, const Epi& epi, int nbranch, hipStream_t st) {
+  int maxM = 0, maxN = 0;
+  bool vec = true;
+  for (int r = 0; r < nbranch; ++r) {
+    maxM = g.M[r] > maxM ? g.M[r] : maxM;
+    maxN = g.N[r] > maxN ? g.N[r] : maxN;
+    vec = vec && g2_aligned(g.A[r], g.lda[r]) && g2_aligned(g.B[r], g.ldb[r]);
+    if (A_KC || B_KC) vec = vec && (g.K[r] & 3) == 0 && (g.chunk & 3) == 0;
+    if (!A_KC) vec = vec && (g.M[r] & 3) == 0;
+    if (!B_KC) vec = vec && (((g.b_ones_col >= 0 ? g.b_ones_col : g.N[r]) & 3) == 0);
+  }
+  dim3 grid((maxM + G2_BM - 1) / G2_BM, (maxN + G2_BN - 1) / G2_BN, nbranch * g.nsplit);
+  if (grid.x == 0 || grid.y == 0 || grid.z == 0) return hipSuccess;
+  if (vec) hipLaunchKernelGGL((sg_gemm2<Epi, A_KC, B_KC, true>), grid, dim3(256), 0, st, g, epi);
+  else hipLaunchKernelGGL((sg_gemm2<Epi, A_KC, B_KC, false>), grid, dim3(256), 0, st, g, epi);
+  return hipGetLastError();
+}

@@ -12,7 +12,17 @@ import torch
 
 from . import _lib
 
-_NSPLIT = int(os.environ.get("STEMGNN_NSPLIT", "8"))      # split-M factor of the weight-gradient GEMMs
+_NSPLIT = int(os.environ.get("STEMGNN_NSPLIT", "16"))     # split-M factor of the weight-gradient GEMMs
+_DIRECT_GRAD = False
+
+
+def set_direct_grad(flag=True):
+    """Opt-in: backward WRITES the hot-path / GRU parameter gradients straight into existing ``p.grad`` buffers
+    (e.g. the views of a FlatGradBucket) instead of returning them to autograd, which would launch one
+    accumulate kernel per parameter (~70 tiny launches per step).  Semantics: overwrite, i.e. equivalent to
+    ``zero_grad(); backward()`` -- do not use when accumulating gradients over several backward passes."""
+    global _DIRECT_GRAD
+    _DIRECT_GRAD = bool(flag)
 _NCHUNK = int(os.environ.get("STEMGNN_ATTN_CHUNKS", "4"))  # row chunks of the attention backward
 
 
@@ -81,6 +91,7 @@ class GruFront(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w_ih, w_hh, b_ih, b_hh):
         lib = _lib.load()
+        gru_params = (w_ih, w_hh, b_ih, b_hh)
         for name, t in (("x", x), ("GRU.weight_ih_l0", w_ih), ("GRU.weight_hh_l0", w_hh)):
             _require_gpu(t, name)
         x = x.contiguous()
@@ -97,6 +108,7 @@ class GruFront(torch.autograd.Function):
         # save_for_backward (not ctx attributes): h_all is an OUTPUT -- holding it on ctx would form a
         # ctx <-> grad_fn reference cycle that never frees the step's buffers
         ctx.save_for_backward(x, w_ih, w_hh, h_all, reserve)
+        ctx.gru_params = gru_params
         return h_all
 
     @staticmethod
@@ -108,13 +120,20 @@ class GruFront(torch.autograd.Function):
         dev, f32 = x.device, torch.float32
         dh_all = dh_all.contiguous()
         scratch = torch.empty(lib.stemgnn_gru_bwd_scratch_floats(B, S, Hd, W), device=dev, dtype=f32)
-        dw_ih, dw_hh = torch.empty_like(w_ih), torch.empty_like(w_hh)
-        db_ih = torch.empty(3 * Hd, device=dev, dtype=f32)
-        db_hh = torch.empty(3 * Hd, device=dev, dtype=f32)
+        prm = ctx.gru_params
+        direct = _DIRECT_GRAD and all(p.grad is not None and p.grad.is_contiguous() for p in prm)
+        if direct:
+            dw_ih, dw_hh, db_ih, db_hh = (p.grad for p in prm)
+        else:
+            dw_ih, dw_hh = torch.empty_like(w_ih), torch.empty_like(w_hh)
+            db_ih = torch.empty(3 * Hd, device=dev, dtype=f32)
+            db_hh = torch.empty(3 * Hd, device=dev, dtype=f32)
         _lib.check(lib.stemgnn_gru_bwd(dh_all.data_ptr(), x.data_ptr(), w_hh.data_ptr(), h_all.data_ptr(),
                                        reserve.data_ptr(), B, S, Hd, W, scratch.data_ptr(), dw_ih.data_ptr(),
                                        dw_hh.data_ptr(), db_ih.data_ptr(), db_hh.data_ptr(),
                                        gru_status(dev).data_ptr(), _stream()), "gru_bwd")
+        if direct:
+            return None, None, None, None, None
         return None, dw_ih, dw_hh, db_ih, db_hh
 
 
@@ -207,6 +226,7 @@ class SpectralHotPath(torch.autograd.Function):
         dbackcast = torch.empty(B, N, W, device=dev, dtype=f32)
         xviews = [(x, W * N, 1, N), (backcast, N * W, W, 1)]
         grads = [[None] * 33, [None] * 33]
+        direct_idx = set()
         for s in (1, 0):
             parr = _lib.ptr_array(blocks[s])
             X, sb, sn, stt = xviews[s]
@@ -224,7 +244,11 @@ class SpectralHotPath(torch.autograd.Function):
             for i, p in enumerate(blocks[s]):
                 if p is None or (not has_bc and i in (7, 8)):   # block 1's short-cut is unused (:73-74) -> grad None
                     continue
-                grads[s][i] = torch.empty_like(p)
+                if _DIRECT_GRAD and p.grad is not None and p.grad.is_contiguous():
+                    grads[s][i] = p.grad          # written in place by the unpack kernel
+                    direct_idx.add((s, i))
+                else:
+                    grads[s][i] = torch.empty_like(p)
             _lib.check(lib.stemgnn_block_unpack_grads(
                 gradpart.data_ptr(), nsplit, tables.data_ptr(), _lib.ptr_array(grads[s]), W, multi, int(has_bc), st),
                 "block_unpack_grads")
@@ -233,12 +257,17 @@ class SpectralHotPath(torch.autograd.Function):
         _lib.check(lib.stemgnn_cheb_bwd(mul_L.data_ptr(), dmul_L.data_ptr(), dL.data_ptr(), cheb_scratch.data_ptr(),
                                         N, st), "cheb_bwd")
         dh = torch.empty_like(h)
-        dwk = torch.empty_like(wk)
-        dwq = torch.empty_like(wq)
+        kq_direct = _DIRECT_GRAD and wk.grad is not None and wq.grad is not None
+        dwk = wk.grad if kq_direct else torch.empty_like(wk)
+        dwq = wq.grad if kq_direct else torch.empty_like(wq)
         attn_scratch = torch.empty(lib.stemgnn_attn_scratch_floats(B, N, _NCHUNK), device=dev, dtype=f32)
         use_drop = training and drop_p > 0.0
         _lib.check(lib.stemgnn_attn_laplacian_bwd(
             dL.data_ptr(), h.data_ptr(), wk.data_ptr(), wq.data_ptr(), alpha, drop_p, int(training),
             seed.data_ptr() if use_drop else None, B, N, attn_saved.data_ptr(), attn_scratch.data_ptr(), _NCHUNK,
             dh.data_ptr(), dwk.data_ptr(), dwq.data_ptr(), st), "attn_laplacian_bwd")
+        for s_, i_ in direct_idx:
+            grads[s_][i_] = None                  # already in p.grad: nothing for autograd to accumulate
+        if kq_direct:
+            dwk = dwq = None
         return (dh, None, dwk, dwq, None, None, None, None, None, *grads[0], *grads[1])

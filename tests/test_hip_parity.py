@@ -218,3 +218,32 @@ def test_checkpoint_interchange_and_pickle():
     f2, a2 = clone(x.cuda())
     assert torch.equal(f1, f2) and torch.equal(a1, a2)
     assert list(model.state_dict().keys()) == list(sd.keys())
+
+
+def test_direct_grad_mode_matches_autograd_accumulation():
+    """ops.set_direct_grad(True): backward writes straight into pre-existing .grad buffers (flat bucket views)."""
+    from stemgnn_amd import ops
+    from stemgnn_amd.distributed import FlatGradBucket
+
+    N, W, multi, H, B = 30, 12, 5, 3, 6
+    sd = O.det_state_dict(N, W, multi, H, seed=8)
+    torch.manual_seed(2)
+    x, y = torch.randn(B, W, N), torch.randn(B, H, N)
+    model = _hip_model(N, W, multi, H, sd, p=0.0, train=True)
+    bucket = FlatGradBucket(model.parameters())
+    ops.set_direct_grad(True)
+    try:
+        for _ in range(2):                       # second pass must overwrite, not accumulate
+            bucket.zero()
+            forecast, _ = model(x.cuda())
+            torch.nn.functional.mse_loss(forecast, y.cuda()).backward()
+        torch.cuda.synchronize()
+    finally:
+        ops.set_direct_grad(False)
+    _, _, _, o_grads = O.loss_and_grads(x, y, sd)
+    for (k, p), view in zip(model.named_parameters(), bucket.views):
+        assert p.grad.data_ptr() == view.data_ptr(), k          # still the flat views
+        if o_grads[k] is None:
+            assert float(view.abs().max()) == 0.0, k
+        else:
+            assert relerr(view, o_grads[k]) < TOL, k
