@@ -40,8 +40,11 @@ def build_step(model, opt, bucket, x, y, world):
     loss_fn = torch.nn.MSELoss(reduction="mean")
     loss_buf = torch.zeros((), device=x.device)
 
+    fused_zero = getattr(opt, "fuse_zero_grad", False)
+
     def fwd_bwd():
-        bucket.zero()
+        if not fused_zero:
+            bucket.zero()                   # FusedRMSprop clears the gradients inside its step kernel
         forecast, _ = model(x)
         loss = loss_fn(forecast, y)
         loss.backward()
@@ -178,7 +181,11 @@ def main():
     model.to(dev).train()
     broadcast_parameters(model)
     bucket = FlatGradBucket(model.parameters())
-    opt = torch.optim.RMSprop(model.parameters(), lr=1e-4, eps=1e-8, capturable=True, foreach=True)
+    if os.environ.get("STEMGNN_TORCH_OPT", "0") == "1":     # A/B: the library optimizer the reference driver uses
+        opt = torch.optim.RMSprop(model.parameters(), lr=1e-4, eps=1e-8, capturable=True, foreach=True)
+    else:                                                    # same arithmetic, one fused kernel (+ grad zeroing)
+        from stemgnn_amd.optim import FusedRMSprop
+        opt = FusedRMSprop(model.parameters(), lr=1e-4, alpha=0.99, eps=1e-8, bucket=bucket)
     g = torch.Generator().manual_seed(1234 + rank)
     x = torch.randn(cfg["B"], cfg["W"], cfg["N"], generator=g).to(dev)
     y = torch.randn(cfg["B"], cfg["H"], cfg["N"], generator=g).to(dev)

@@ -150,6 +150,23 @@ int stemgnn_igft_heads_bwd(const float* const* params_host, const float* packed,
                            float* scratch, float* gradpart, int nsplit,
                            int B, int N, int W, int multi, void* stream);
 
+/* ---- callers on either side of the blocks, fused ------------------------------------------------
+ * fc tail (models/base_model.py:97-101,174-179): fsum [B*N, W] (block forecast sum) ->
+ * forecast [B,H,N] = Linear(W,H)(LeakyReLU_0.01(Linear(W,W)(fsum))) permuted.  stemgnn_fc_tail_supported(W,H)
+ * tells whether the fused kernels cover (W,H) (registers / LDS); otherwise the caller keeps its own fc. */
+int stemgnn_fc_tail_supported(int W, int H);
+size_t stemgnn_fc_tail_scratch_floats(int B, int N, int W, int H);
+int stemgnn_fc_tail_fwd(const float* fsum, const float* w0, const float* b0, const float* w2, const float* b2,
+                        int B, int N, int W, int H, float* forecast, void* stream);
+int stemgnn_fc_tail_bwd(const float* dforecast, const float* fsum, const float* w0, const float* b0, const float* w2,
+                        int B, int N, int W, int H, float* scratch, float* dfsum, float* dw0, float* db0,
+                        float* dw2, float* db2, void* stream);
+/* RMSprop step of the reference driver (models/handler.py:127,165; torch defaults alpha=0.99, momentum 0, not
+ * centered) over flat, 16-byte aligned parameter / gradient / square_avg buffers of n floats; lr is read from
+ * device memory; zero_grad != 0 also clears the gradients for the next step (handler.py:160). */
+int stemgnn_rmsprop_step(float* params, float* grads, float* square_avg, size_t n, const float* lr_dev,
+                         float alpha, float eps, int zero_grad, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -39,6 +39,11 @@ SIGNATURES = {
     "stemgnn_gru_bwd_scratch_floats": (c_size_t, [c_int, c_int, c_int, c_int]),
     "stemgnn_gru_fwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P]),
     "stemgnn_gru_bwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P]),
+    "stemgnn_fc_tail_supported": (c_int, [c_int, c_int]),
+    "stemgnn_fc_tail_scratch_floats": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "stemgnn_fc_tail_fwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P]),
+    "stemgnn_fc_tail_bwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P]),
+    "stemgnn_rmsprop_step": (c_int, [_P, _P, _P, c_size_t, _P, c_float, c_float, c_int, _P]),
     "stemgnn_block_pack": (c_int, [_PP, _P, _P, c_int, c_int, _P]),
     "stemgnn_block_unpack_grads": (c_int, [_P, c_int, _P, _PP, c_int, c_int, c_int, _P]),
     "stemgnn_gft_fwd": (c_int, [_P, _P, c_long, c_long, c_long, _P, c_int, c_int, c_int, _P]),

@@ -10,7 +10,7 @@ containers: all arithmetic after the GRU runs in the hand-written HIP kernels of
 
 The ``nn.GRU`` module (models/base_model.py:92,137) is kept as the parameter container; its recurrence
 runs in the persistent HIP kernels of ``csrc/gru.hip`` (``STEMGNN_GRU=miopen`` selects the library GRU for
-A/B runs).  The 2-layer ``fc`` tail (:175) stays a PyTorch-ROCm library call (negligible work).
+A/B runs).  The 2-layer ``fc`` tail (:175-179) runs in the fused kernel of ``csrc/tail.hip``.
 """
 import os
 
@@ -19,7 +19,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import _lib
-from .ops import GruFront, SpectralHotPath
+from .ops import FcTail, GruFront, SpectralHotPath
 
 _BLOCK_FIELDS = ("forecast", "forecast_result", "backcast", "backcast_short_cut")
 
@@ -131,6 +131,10 @@ class Model(nn.Module):
 
     def forward(self, x):
         fsum, attention, _ = self.hot_path(x)
+        if _lib.load().stemgnn_fc_tail_supported(self.time_step, self.horizon):
+            # fused fc tail (csrc/tail.hip): Linear - LeakyReLU - Linear and the permute to [B,H,N] in one kernel;
+            # for H == 1 the reference's unsqueeze/squeeze (:176-177) yields the same [B,1,N] tensor
+            return FcTail.apply(fsum, self.fc[0].weight, self.fc[0].bias, self.fc[2].weight, self.fc[2].bias), attention
         forecast = self.fc(fsum)                                   # [B,N,H]  (:175)
         if forecast.size(-1) == 1:                                 # (:176-177)
             return forecast.unsqueeze(1).squeeze(-1), attention

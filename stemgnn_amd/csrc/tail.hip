@@ -1,0 +1,258 @@
+// Callers on either side of the spectral blocks (SURVEY 8f "next" rows), fused into single kernels:
+//   * the fc tail  forecast = Linear(W,H)(LeakyReLU_0.01(Linear(W,W)(block forecast sum)))  permuted to [B,H,N]
+//     (reference models/base_model.py:97-101, 174-179) and its backward;
+//   * the optimizer step of the reference driver (models/handler.py:126-127,165): RMSprop(lr, alpha=0.99,
+//     eps=1e-8) over ONE flat parameter / gradient / state buffer, with the gradient zeroing of the next step
+//     (handler.py:160 model.zero_grad()) fused in.
+// Both are HBM/latency-bound elementwise work: one launch each instead of ~10 library kernels.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/stemgnn_hip.h"
+
+#define SG_TRY(e)                                \
+  do {                                           \
+    hipError_t _e = (e);                         \
+    if (_e != hipSuccess) return -(int)_e;       \
+  } while (0)
+
+constexpr int TAIL_MAXW = 64;    // window sizes up to 64 / horizons up to 32 keep a row in registers
+constexpr int TAIL_MAXH = 32;    // (fully unrolled, predicated loops: two instantiations, <16,4> and <64,32>)
+
+// forward: one thread per series row m = (b, n).  LDS: w0[W*W] | b0[W] | w2[H*W] | b2[H]
+template <int WM, int HM>
+__global__ __launch_bounds__(256) void sg_fc_tail_fwd_kernel(const float* __restrict__ fsum, const float* __restrict__ w0,
+                                                             const float* __restrict__ b0, const float* __restrict__ w2,
+                                                             const float* __restrict__ b2, int B, int N, int W, int H,
+                                                             float* __restrict__ forecast) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* sw0 = sm;
+  float* sb0 = sw0 + W * W;
+  float* sw2 = sb0 + W;
+  float* sb2 = sw2 + H * W;
+  for (int i = threadIdx.x; i < W * W; i += 256) sw0[i] = w0[i];
+  for (int i = threadIdx.x; i < W; i += 256) sb0[i] = b0[i];
+  for (int i = threadIdx.x; i < H * W; i += 256) sw2[i] = w2[i];
+  for (int i = threadIdx.x; i < H; i += 256) sb2[i] = b2[i];
+  __syncthreads();
+  const int m = blockIdx.x * 256 + threadIdx.x;
+  if (m >= B * N) return;
+  const int b = m / N, n = m - b * N;
+  float x[WM], a[WM];
+#pragma unroll
+  for (int t = 0; t < WM; ++t) x[t] = t < W ? fsum[(size_t)m * W + t] : 0.f;
+#pragma unroll
+  for (int t = 0; t < WM; ++t) {
+    float z = t < W ? sb0[t] : 0.f;
+#pragma unroll
+    for (int u = 0; u < WM; ++u) z = fmaf(x[u], (t < W && u < W) ? sw0[t * W + u] : 0.f, z);
+    a[t] = z > 0.f ? z : 0.01f * z;
+  }
+#pragma unroll
+  for (int h = 0; h < HM; ++h) {
+    if (h < H) {
+      float y = sb2[h];
+#pragma unroll
+      for (int t = 0; t < WM; ++t) y = fmaf(a[t], t < W ? sw2[h * W + t] : 0.f, y);
+      forecast[((size_t)b * H + h) * N + n] = y;      // [B,H,N]: coalesced over n
+    }
+  }
+}
+
+// backward: recomputes z (cheap) from fsum; writes dfsum and per-block partial sums of the weight gradients.
+// partial layout per block: dw0[W*W] | db0[W] | dw2[H*W] | db2[H]
+template <int WM, int HM>
+__global__ __launch_bounds__(256) void sg_fc_tail_bwd_kernel(const float* __restrict__ dforecast, const float* __restrict__ fsum,
+                                                             const float* __restrict__ w0, const float* __restrict__ b0,
+                                                             const float* __restrict__ w2, int B, int N, int W, int H,
+                                                             float* __restrict__ dfsum, float* __restrict__ partial) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int nacc = W * W + W + H * W + H;
+  float* sw0 = sm;
+  float* sb0 = sw0 + W * W;
+  float* sw2 = sb0 + W;
+  float* acc = sw2 + H * W;        // [nacc] block accumulators
+  for (int i = threadIdx.x; i < W * W; i += 256) sw0[i] = w0[i];
+  for (int i = threadIdx.x; i < W; i += 256) sb0[i] = b0[i];
+  for (int i = threadIdx.x; i < H * W; i += 256) sw2[i] = w2[i];
+  for (int i = threadIdx.x; i < nacc; i += 256) acc[i] = 0.f;
+  __syncthreads();
+  const int m = blockIdx.x * 256 + threadIdx.x;
+  const bool live = m < B * N;
+  float x[WM], a[WM], dz[WM], dy[HM];
+  {
+    const int mc = live ? m : 0;
+    const int b = mc / N, n = mc - b * N;
+#pragma unroll
+    for (int t = 0; t < WM; ++t) x[t] = (live && t < W) ? fsum[(size_t)mc * W + t] : 0.f;
+#pragma unroll
+    for (int h = 0; h < HM; ++h) dy[h] = (live && h < H) ? dforecast[((size_t)b * H + h) * N + n] : 0.f;
+#pragma unroll
+    for (int t = 0; t < WM; ++t) {
+      float z = t < W ? sb0[t] : 0.f;
+#pragma unroll
+      for (int u = 0; u < WM; ++u) z = fmaf(x[u], (t < W && u < W) ? sw0[t * W + u] : 0.f, z);
+      a[t] = z > 0.f ? z : 0.01f * z;
+      float da = 0.f;
+#pragma unroll
+      for (int h = 0; h < HM; ++h) da = fmaf(dy[h], (h < H && t < W) ? sw2[h * W + t] : 0.f, da);
+      dz[t] = z > 0.f ? da : 0.01f * da;
+    }
+#pragma unroll
+    for (int u = 0; u < WM; ++u) {
+      float d = 0.f;
+#pragma unroll
+      for (int t = 0; t < WM; ++t) d = fmaf(dz[t], (t < W && u < W) ? sw0[t * W + u] : 0.f, d);
+      if (live && u < W) dfsum[(size_t)m * W + u] = d;
+    }
+  }
+  // weight-gradient partials of this block's 256 rows: stage dz / x / a / dy rows in LDS (row stride odd -> no bank
+  // conflicts), then one thread per weight element walks the rows in a fixed order (deterministic, no atomics)
+  float* sx = acc + nacc;                 // [256][W+1]
+  float* sdz = sx + 256 * (W + 1);        // [256][W+1]
+  float* sa = sdz + 256 * (W + 1);        // [256][W+1]
+  float* sdy = sa + 256 * (W + 1);        // [256][H+1]
+  {
+    const int rr = threadIdx.x;
+#pragma unroll
+    for (int t = 0; t < WM; ++t)
+      if (t < W) {
+        sx[rr * (W + 1) + t] = x[t];
+        sdz[rr * (W + 1) + t] = live ? dz[t] : 0.f;
+        sa[rr * (W + 1) + t] = live ? a[t] : 0.f;
+      }
+#pragma unroll
+    for (int h = 0; h < HM; ++h)
+      if (h < H) sdy[rr * (H + 1) + h] = dy[h];
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < nacc; e += 256) {
+    float sum = 0.f;
+    if (e < W * W) {
+      const int t = e / W, u = e - t * W;
+      for (int rr = 0; rr < 256; ++rr) sum = fmaf(sdz[rr * (W + 1) + t], sx[rr * (W + 1) + u], sum);
+    } else if (e < W * W + W) {
+      const int t = e - W * W;
+      for (int rr = 0; rr < 256; ++rr) sum += sdz[rr * (W + 1) + t];
+    } else if (e < W * W + W + H * W) {
+      const int q = e - W * W - W, h = q / W, t = q - h * W;
+      for (int rr = 0; rr < 256; ++rr) sum = fmaf(sdy[rr * (H + 1) + h], sa[rr * (W + 1) + t], sum);
+    } else {
+      const int h = e - W * W - W - H * W;
+      for (int rr = 0; rr < 256; ++rr) sum += sdy[rr * (H + 1) + h];
+    }
+    partial[(size_t)blockIdx.x * nacc + e] = sum;
+  }
+}
+
+__global__ void sg_fc_tail_reduce_kernel(const float* __restrict__ partial, int nblocks, int W, int H, float* __restrict__ dw0,
+                                         float* __restrict__ db0, float* __restrict__ dw2, float* __restrict__ db2) {
+  const int nacc = W * W + W + H * W + H;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nacc) return;
+  float s = 0.f;
+  for (int b = 0; b < nblocks; ++b) s += partial[(size_t)b * nacc + i];
+  if (i < W * W) dw0[i] = s;
+  else if (i < W * W + W) db0[i - W * W] = s;
+  else if (i < W * W + W + H * W) dw2[i - W * W - W] = s;
+  else db2[i - W * W - W - H * W] = s;
+}
+
+static size_t fc_tail_bwd_lds(int W, int H) {
+  const int nacc = W * W + W + H * W + H;
+  return (size_t)(W * W + W + H * W + nacc + 256 * (3 * (W + 1) + H + 1)) * sizeof(float);
+}
+extern "C" int stemgnn_fc_tail_supported(int W, int H) {
+  return W > 0 && H > 0 && W <= TAIL_MAXW && H <= TAIL_MAXH && fc_tail_bwd_lds(W, H) <= 150 * 1024;
+}
+extern "C" size_t stemgnn_fc_tail_scratch_floats(int B, int N, int W, int H) {
+  return (size_t)((B * N + 255) / 256) * (W * W + W + H * W + H);
+}
+
+extern "C" int stemgnn_fc_tail_fwd(const float* fsum, const float* w0, const float* b0, const float* w2, const float* b2,
+                                   int B, int N, int W, int H, float* forecast, void* stream) {
+  if (!fsum || !w0 || !b0 || !w2 || !b2 || !forecast || B <= 0 || N <= 0 || !stemgnn_fc_tail_supported(W, H))
+    return SG_EINVAL;
+  const size_t lds = (size_t)(W * W + W + H * W + H) * sizeof(float);
+  if (W <= 16 && H <= 4)
+    hipLaunchKernelGGL((sg_fc_tail_fwd_kernel<16, 4>), dim3((B * N + 255) / 256), dim3(256), lds, (hipStream_t)stream, fsum,
+                       w0, b0, w2, b2, B, N, W, H, forecast);
+  else
+    hipLaunchKernelGGL((sg_fc_tail_fwd_kernel<64, 32>), dim3((B * N + 255) / 256), dim3(256), lds, (hipStream_t)stream, fsum,
+                       w0, b0, w2, b2, B, N, W, H, forecast);
+  SG_TRY(hipGetLastError());
+  return 0;
+}
+
+extern "C" int stemgnn_fc_tail_bwd(const float* dforecast, const float* fsum, const float* w0, const float* b0,
+                                   const float* w2, int B, int N, int W, int H, float* scratch, float* dfsum, float* dw0,
+                                   float* db0, float* dw2, float* db2, void* stream) {
+  if (!dforecast || !fsum || !w0 || !b0 || !w2 || !scratch || !dfsum || !dw0 || !db0 || !dw2 || !db2 || B <= 0 ||
+      N <= 0 || W <= 0 || H <= 0 || W > TAIL_MAXW || H > TAIL_MAXH)
+    return SG_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const int nacc = W * W + W + H * W + H;
+  const int nblocks = (B * N + 255) / 256;
+  const size_t lds = fc_tail_bwd_lds(W, H);
+  if (!stemgnn_fc_tail_supported(W, H)) return SG_EINVAL;
+  static bool attr_done = false;
+  if (!attr_done && lds > 64 * 1024) {
+    SG_TRY(hipFuncSetAttribute((const void*)sg_fc_tail_bwd_kernel<64, 32>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               150 * 1024));
+    attr_done = true;
+  }
+  if (W <= 16 && H <= 4)
+    hipLaunchKernelGGL((sg_fc_tail_bwd_kernel<16, 4>), dim3(nblocks), dim3(256), lds, st, dforecast, fsum, w0, b0, w2, B, N,
+                       W, H, dfsum, scratch);
+  else
+    hipLaunchKernelGGL((sg_fc_tail_bwd_kernel<64, 32>), dim3(nblocks), dim3(256), lds, st, dforecast, fsum, w0, b0, w2, B, N,
+                       W, H, dfsum, scratch);
+  SG_TRY(hipGetLastError());
+  hipLaunchKernelGGL(sg_fc_tail_reduce_kernel, dim3((nacc + 255) / 256), dim3(256), 0, st, scratch, nblocks, W, H, dw0,
+                     db0, dw2, db2);
+  SG_TRY(hipGetLastError());
+  return 0;
+}
+
+// ---- fused RMSprop over flat buffers ------------------------------------------------------------------------------
+// torch.optim.RMSprop(momentum=0, centered=False, weight_decay=0):  sq = alpha*sq + (1-alpha)*g*g ;
+// p -= lr * g / (sqrt(sq) + eps).  lr is read from device memory so an LR scheduler can change it under graph replay.
+__global__ void sg_rmsprop_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ sq, size_t n,
+                                  const float* __restrict__ lr_dev, float alpha, float eps, int zero_grad) {
+  const float lr = lr_dev[0];
+  size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  const size_t stride = (size_t)gridDim.x * blockDim.x * 4;
+  for (; i + 3 < n; i += stride) {
+    float4 pv = *reinterpret_cast<float4*>(p + i), gv = *reinterpret_cast<float4*>(g + i),
+           sv = *reinterpret_cast<float4*>(sq + i);
+    sv.x = alpha * sv.x + (1.f - alpha) * gv.x * gv.x; pv.x -= lr * gv.x / (sqrtf(sv.x) + eps);
+    sv.y = alpha * sv.y + (1.f - alpha) * gv.y * gv.y; pv.y -= lr * gv.y / (sqrtf(sv.y) + eps);
+    sv.z = alpha * sv.z + (1.f - alpha) * gv.z * gv.z; pv.z -= lr * gv.z / (sqrtf(sv.z) + eps);
+    sv.w = alpha * sv.w + (1.f - alpha) * gv.w * gv.w; pv.w -= lr * gv.w / (sqrtf(sv.w) + eps);
+    *reinterpret_cast<float4*>(p + i) = pv;
+    *reinterpret_cast<float4*>(sq + i) = sv;
+    if (zero_grad) *reinterpret_cast<float4*>(g + i) = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  if (i < n && i + 3 >= n) {          // ragged tail (at most one thread)
+    for (size_t j = i; j < n; ++j) {
+      const float gv = g[j];
+      const float sv = alpha * sq[j] + (1.f - alpha) * gv * gv;
+      sq[j] = sv;
+      p[j] -= lr * gv / (sqrtf(sv) + eps);
+      if (zero_grad) g[j] = 0.f;
+    }
+  }
+}
+
+extern "C" int stemgnn_rmsprop_step(float* params, float* grads, float* square_avg, size_t n, const float* lr_dev,
+                                    float alpha, float eps, int zero_grad, void* stream) {
+  if (!params || !grads || !square_avg || !lr_dev || n == 0) return SG_EINVAL;
+  if ((((uintptr_t)params | (uintptr_t)grads | (uintptr_t)square_avg) & 15) != 0) return SG_EINVAL;
+  const size_t nvec = (n + 3) / 4;
+  unsigned blocks = (unsigned)((nvec + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(sg_rmsprop_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, params, grads, square_avg, n,
+                     lr_dev, alpha, eps, zero_grad);
+  SG_TRY(hipGetLastError());
+  return 0;
+}

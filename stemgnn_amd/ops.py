@@ -137,6 +137,48 @@ class GruFront(torch.autograd.Function):
         return None, dw_ih, dw_hh, db_ih, db_hh
 
 
+class FcTail(torch.autograd.Function):
+    """fc tail of Model.forward (reference models/base_model.py:175-179): fsum [B,N,W] -> forecast [B,H,N]."""
+
+    @staticmethod
+    def forward(ctx, fsum, w0, b0, w2, b2):
+        lib = _lib.load()
+        fsum = fsum.contiguous()
+        B, N, W = fsum.shape
+        H = w2.shape[0]
+        forecast = torch.empty(B, H, N, device=fsum.device, dtype=torch.float32)
+        w0, b0, w2, b2 = (t.contiguous() for t in (w0, b0, w2, b2))
+        _lib.check(lib.stemgnn_fc_tail_fwd(fsum.data_ptr(), w0.data_ptr(), b0.data_ptr(), w2.data_ptr(), b2.data_ptr(),
+                                           B, N, W, H, forecast.data_ptr(), _stream()), "fc_tail_fwd")
+        ctx.save_for_backward(fsum, w0, b0, w2)
+        ctx.fc_params = (w0, b0, w2, b2)
+        return forecast
+
+    @staticmethod
+    def backward(ctx, dforecast):
+        lib = _lib.load()
+        fsum, w0, b0, w2 = ctx.saved_tensors
+        B, N, W = fsum.shape
+        H = w2.shape[0]
+        dev, f32 = fsum.device, torch.float32
+        dforecast = dforecast.contiguous()
+        prm = ctx.fc_params
+        direct = _DIRECT_GRAD and all(p.grad is not None and p.grad.is_contiguous() for p in prm)
+        if direct:
+            dw0, db0, dw2, db2 = (p.grad for p in prm)
+        else:
+            dw0, db0, dw2, db2 = (torch.empty_like(p) for p in prm)
+        dfsum = torch.empty_like(fsum)
+        scratch = torch.empty(lib.stemgnn_fc_tail_scratch_floats(B, N, W, H), device=dev, dtype=f32)
+        _lib.check(lib.stemgnn_fc_tail_bwd(dforecast.data_ptr(), fsum.data_ptr(), w0.data_ptr(), b0.data_ptr(),
+                                           w2.data_ptr(), B, N, W, H, scratch.data_ptr(), dfsum.data_ptr(),
+                                           dw0.data_ptr(), db0.data_ptr(), dw2.data_ptr(), db2.data_ptr(), _stream()),
+                   "fc_tail_bwd")
+        if direct:
+            return dfsum, None, None, None, None
+        return dfsum, dw0, db0, dw2, db2
+
+
 class SpectralHotPath(torch.autograd.Function):
     """(h, x, weight_key, weight_query, 33 params of block 0, 33 params of block 1) ->
     (sum of the two block forecasts [B,N,W], attention [N,N], mul_L [4,N,N]).

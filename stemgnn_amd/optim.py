@@ -1,0 +1,55 @@
+"""Fused optimizer step for the reference driver's training loop.
+
+The reference trains with ``torch.optim.RMSprop(params, lr, eps=1e-8)`` (models/handler.py:127) and calls
+``model.zero_grad()`` / ``optim.step()`` every batch (:160,:165): ~70 small tensors, i.e. a launch-bound cloud of
+tiny kernels.  ``FusedRMSprop`` keeps ALL parameters, gradients and the running square average in three flat
+buffers and performs the step -- and the zeroing of the gradients for the next step -- in ONE HIP kernel
+(``stemgnn_rmsprop_step``).  Same arithmetic as torch.optim.RMSprop(momentum=0, centered=False, weight_decay=0).
+"""
+import torch
+
+from . import _lib
+from .distributed import FlatGradBucket
+
+
+class FusedRMSprop(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-2, alpha=0.99, eps=1e-8, bucket=None, fuse_zero_grad=True):
+        params = [p for p in params if p.requires_grad]
+        super().__init__(params, dict(lr=lr, alpha=alpha, eps=eps))
+        if not params or not params[0].is_cuda:
+            raise _lib.StemGNNHipError("FusedRMSprop needs parameters on a HIP device (move the model first)")
+        dev = params[0].device
+        self._params = params
+        self.numel = sum(p.numel() for p in params)
+        self.flat_p = torch.empty(self.numel, device=dev, dtype=torch.float32)
+        off = 0
+        for p in params:                      # re-point every parameter at its slice of the flat buffer
+            n = p.numel()
+            view = self.flat_p[off:off + n].view_as(p)
+            view.copy_(p.data)
+            p.data = view
+            off += n
+        self.bucket = bucket if bucket is not None else FlatGradBucket(params)
+        if self.bucket.numel != self.numel:
+            raise ValueError("gradient bucket and parameter list differ")
+        self.square_avg = torch.zeros_like(self.flat_p)
+        self._lr_host = float(lr)
+        self._lr_dev = torch.tensor([lr], device=dev, dtype=torch.float32)
+        self.fuse_zero_grad = bool(fuse_zero_grad)
+
+    def zero_grad(self, set_to_none=False):   # gradients live in the flat bucket; never drop the views
+        self.bucket.zero()
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = closure() if closure is not None else None
+        group = self.param_groups[0]
+        if float(group["lr"]) != self._lr_host:            # an LR scheduler changed it (host side, between replays)
+            self._lr_host = float(group["lr"])
+            self._lr_dev.fill_(self._lr_host)
+        lib = _lib.load()
+        _lib.check(lib.stemgnn_rmsprop_step(
+            self.flat_p.data_ptr(), self.bucket.flat.data_ptr(), self.square_avg.data_ptr(), self.numel,
+            self._lr_dev.data_ptr(), float(group["alpha"]), float(group["eps"]), int(self.fuse_zero_grad),
+            torch.cuda.current_stream().cuda_stream), "rmsprop_step")
+        return loss
