@@ -26,6 +26,7 @@
   } while (0)
 
 __device__ __forceinline__ float gru_sigmoid(float v) { return 1.f / (1.f + expf(-v)); }
+__device__ __forceinline__ int gru_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
 // ---- input projection: gi[(s,b)][j] = b_ih[j] + sum_t x[b][t][s] W_ih[j][t] ------------------------------
 struct GruGiOp {
@@ -396,6 +397,170 @@ __global__ __launch_bounds__(1024) void gru_bwd_cluster_kernel(const float* __re
   }
 }
 
+// =================================================================================================
+// Cluster recurrence v2 (U = ceil(Hd/P) <= 64, 3*P <= 16 waves): the k-slices are aligned with the owners.
+// Wave (g, q) of workgroup (b, p) holds W[gate g][own units][units of owner q] (<= 64 registers per lane) and
+// consumes exactly owner q's granules: lane k polls granule k of that slice, the value is broadcast to the
+// wave with v_readlane (no LDS staging, no workgroup barrier between exchange and mat-vec); only the gate
+// phase needs the 3*P partial sums -> ONE barrier per step (partials double buffered by step parity).
+// =================================================================================================
+__device__ __forceinline__ float gru_bcast(float v, int src_lane) {     // wave broadcast of lane src_lane (constant)
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src_lane));
+}
+__device__ __forceinline__ float gru_poll_lane(const gru_u64* g, unsigned tag, bool active, int* status) {
+  float v = 0.f;
+  if (active) v = gru_consume(g, tag, status);
+  return v;
+}
+
+// forward.  LDS: part[2][3*P][64]
+template <int P>
+__global__ __launch_bounds__(3 * P * 64) void gru_fwd_cluster2_kernel(const float* __restrict__ gi, const float* __restrict__ w_hh,
+                                                                      const float* __restrict__ b_hh, int B, int S, int Hd,
+                                                                      gru_u64* __restrict__ xbuf, int* __restrict__ status,
+                                                                      float* __restrict__ h_all, float* __restrict__ reserve) {
+  __shared__ float part[2][3 * P][64];
+  int b, p;
+  gru_cluster_ids(B, P, b, p);
+  if (b >= B) return;
+  const int U = (Hd + P - 1) / P;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = gru_uniform(tid >> 6);
+  const int g = wave / P, q = wave - g * P;            // gate, owner of the k-slice
+  const int u0 = p * U, un = max(0, min(Hd, u0 + U) - u0);
+  const int k0 = q * U, kn = max(0, min(Hd, k0 + U) - k0);
+  const int H3 = 3 * Hd;
+  float wr[64];
+  {
+    const bool lane_ok = lane < un;
+    const float* wrow = w_hh + ((size_t)g * Hd + (lane_ok ? u0 + lane : 0)) * Hd + (kn > 0 ? k0 : 0);
+#pragma unroll
+    for (int kk = 0; kk < 64; ++kk) {
+      const float v = wrow[kk < kn ? kk : 0];
+      wr[kk] = (lane_ok && kk < kn) ? v : 0.f;
+    }
+  }
+  const int gu = u0 + (tid < un ? tid : 0);            // gate-phase unit of this thread (wave 0 only)
+  const float bh0 = b_hh[gu], bh1 = b_hh[Hd + gu], bh2 = b_hh[2 * Hd + gu];
+  float hown = 0.f;                                     // h_{s-1} of this thread's unit
+
+  for (int s = 0; s < S; ++s) {
+    const size_t row = (size_t)s * B + b;
+    const float* gip = gi + row * H3;
+    const float gp0 = gip[gu], gp1 = gip[Hd + gu], gp2 = gip[2 * Hd + gu];     // prefetch for the gate phase
+    float hv = 0.f;
+    if (s > 0) hv = gru_poll_lane(xbuf + ((size_t)(s & 1) * B + b) * Hd + k0 + (lane < kn ? lane : 0), (unsigned)s,
+                                  lane < kn, status);
+    float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < 64; kk += 2) {
+      a0 = fmaf(wr[kk], gru_bcast(hv, kk), a0);
+      a1 = fmaf(wr[kk + 1], gru_bcast(hv, kk + 1), a1);
+    }
+    part[s & 1][wave][lane] = a0 + a1;
+    __syncthreads();
+    if (tid < un) {
+      float g0 = bh0, g1 = bh1, g2 = bh2;
+#pragma unroll
+      for (int qq = 0; qq < P; ++qq) {
+        g0 += part[s & 1][0 * P + qq][tid];
+        g1 += part[s & 1][1 * P + qq][tid];
+        g2 += part[s & 1][2 * P + qq][tid];
+      }
+      const float r = gru_sigmoid(gp0 + g0);
+      const float z = gru_sigmoid(gp1 + g1);
+      const float n = tanhf(gp2 + r * g2);
+      const float hn = (1.f - z) * n + z * hown;
+      hown = hn;
+      if (s + 1 < S) gru_publish(xbuf + ((size_t)((s + 1) & 1) * B + b) * Hd + gu, (unsigned)(s + 1), hn);
+      float* rs = reserve + row * 4 * Hd;
+      rs[gu] = r; rs[Hd + gu] = z; rs[2 * Hd + gu] = n; rs[3 * Hd + gu] = g2;
+      h_all[row * Hd + gu] = hn;
+    }
+  }
+}
+
+// backward.  LDS: part[2][3*P][64].  Wave (g, q): reduction slice j = g*Hd + units of owner q.
+template <int P>
+__global__ __launch_bounds__(3 * P * 64) void gru_bwd_cluster2_kernel(const float* __restrict__ dout, const float* __restrict__ w_hh,
+                                                                      const float* __restrict__ h_all,
+                                                                      const float* __restrict__ reserve, int B, int S, int Hd,
+                                                                      gru_u64* __restrict__ xbuf, int* __restrict__ status,
+                                                                      float* __restrict__ dgi, float* __restrict__ dghn) {
+  __shared__ float part[2][3 * P][64];
+  int b, p;
+  gru_cluster_ids(B, P, b, p);
+  if (b >= B) return;
+  const int U = (Hd + P - 1) / P;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = gru_uniform(tid >> 6);
+  const int g = wave / P, q = wave - g * P;
+  const int u0 = p * U, un = max(0, min(Hd, u0 + U) - u0);
+  const int k0 = q * U, kn = max(0, min(Hd, k0 + U) - k0);
+  const int H3 = 3 * Hd;
+  float wr[64];
+  {
+    const bool lane_ok = lane < un;
+    const float* wcol = w_hh + ((size_t)g * Hd + (kn > 0 ? k0 : 0)) * Hd + (lane_ok ? u0 + lane : 0);
+#pragma unroll
+    for (int kk = 0; kk < 64; ++kk) {
+      const float v = wcol[(size_t)(kk < kn ? kk : 0) * Hd];
+      wr[kk] = (lane_ok && kk < kn) ? v : 0.f;
+    }
+  }
+  const int gu = u0 + (tid < un ? tid : 0);
+  float dhz = 0.f;                                      // dh * z carried to the previous step (this thread's unit)
+  for (int i = tid; i < 2 * 3 * P * 64; i += 3 * P * 64) (&part[0][0][0])[i] = 0.f;
+  // inputs of the elementwise phase, prefetched one step ahead so their latency hides under the exchange + mat-vec
+  size_t prow = (size_t)(S - 1) * B + b;
+  float p_do = dout[prow * Hd + gu];
+  float p_r = reserve[prow * 4 * Hd + gu], p_z = reserve[prow * 4 * Hd + Hd + gu];
+  float p_n = reserve[prow * 4 * Hd + 2 * Hd + gu], p_g = reserve[prow * 4 * Hd + 3 * Hd + gu];
+  float p_h = h_all[(S > 1 ? prow - B : prow) * Hd + gu];
+  __syncthreads();
+
+  for (int s = S - 1; s >= 0; --s) {
+    const size_t row = (size_t)s * B + b;
+    const unsigned tag = (unsigned)(S - s);
+    gru_u64* xb = xbuf + ((size_t)(tag & 1) * B + b) * H3;
+    if (tid < un) {
+      float dh = p_do + dhz;
+#pragma unroll
+      for (int w = 0; w < 3 * P; ++w) dh += part[(tag + 1) & 1][w][tid];     // partials of the step after this one
+      const float r = p_r, z = p_z, n = p_n, ghn = p_g;
+      const float hprev = s > 0 ? p_h : 0.f;
+      const float dn = dh * (1.f - z) * (1.f - n * n);
+      const float dz = dh * (hprev - n) * z * (1.f - z);
+      const float dr = dn * ghn * r * (1.f - r);
+      const float dnr = dn * r;
+      dhz = dh * z;
+      if (s > 0) {
+        gru_publish(xb + gu, tag, dr);
+        gru_publish(xb + Hd + gu, tag, dz);
+        gru_publish(xb + 2 * Hd + gu, tag, dnr);
+        const size_t rn = row - B;                      // prefetch the next (earlier) step
+        p_do = dout[rn * Hd + gu];
+        p_r = reserve[rn * 4 * Hd + gu]; p_z = reserve[rn * 4 * Hd + Hd + gu];
+        p_n = reserve[rn * 4 * Hd + 2 * Hd + gu]; p_g = reserve[rn * 4 * Hd + 3 * Hd + gu];
+        p_h = h_all[(s > 1 ? rn - B : rn) * Hd + gu];
+      }
+      float* go = dgi + row * H3;
+      go[gu] = dr; go[Hd + gu] = dz; go[2 * Hd + gu] = dn;
+      dghn[row * Hd + gu] = dnr;
+    }
+    if (s == 0) break;
+    const float dv = gru_poll_lane(xb + (size_t)g * Hd + k0 + (lane < kn ? lane : 0), tag, lane < kn, status);
+    float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < 64; kk += 2) {
+      a0 = fmaf(wr[kk], gru_bcast(dv, kk), a0);
+      a1 = fmaf(wr[kk + 1], gru_bcast(dv, kk + 1), a1);
+    }
+    part[tag & 1][wave][lane] = a0 + a1;
+    __syncthreads();
+  }
+}
+
 // ---- weight gradients: reductions over all (s,b) rows as split-K GEMMs ----------------------------------------
 // z = split: part[z][j][k | bias] = sum_{rows in split} dgh[row][j] * hprev[row][k]
 struct GruWhhGradOp {
@@ -457,10 +622,21 @@ extern "C" size_t stemgnn_gru_reserve_floats(int B, int S, int Hd) { return (siz
 #define GRU_KC 48       // resident weights per lane (registers); the per-step loops are fully unrolled over it
 static int gru_pick_P(int B, int Hd) {
   const char* e = getenv("STEMGNN_GRU_CLUSTER");
-  if (e && atoi(e) == 0) return 0;
+  if (e && atoi(e) == 0) return 0;                 // 0: streaming kernels, 1: cluster v1, 2 / unset: v2 then v1
   for (int P = 1; P <= 8; P *= 2) {
     const GruCluster c = gru_cluster_geom(Hd, P);
     if (c.ksf >= 1 && c.ksb >= 1 && c.kcf <= GRU_KC && c.kcb <= GRU_KC && (size_t)B * P <= 224) return P;
+  }
+  return 0;
+}
+// v2 cluster (wave-level exchange): P in {1,2,4,5} with U = ceil(Hd/P) <= 64; 0 = not applicable
+static int gru_pick_P2(int B, int Hd) {
+  const char* e = getenv("STEMGNN_GRU_CLUSTER");
+  if (e && atoi(e) != 2) return 0;
+  static const int cand[4] = {1, 2, 4, 5};
+  for (int i = 0; i < 4; ++i) {
+    const int P = cand[i];
+    if ((Hd + P - 1) / P <= 64 && (size_t)B * P <= 224) return P;
   }
   return 0;
 }
@@ -485,6 +661,18 @@ extern "C" int stemgnn_gru_fwd(const float* x, const float* w_ih, const float* w
   float* gi = scratch + (size_t)3 * Hd * Hd;
   GruGiOp op{x, w_ih, b_ih, gi, B, S, Hd, W};
   SG_TRY((sg_launch_gemm<GruGiOp, 64, 64, true, true, false>(op, S * B, 3 * Hd, 1, st)));
+  const int P2 = gru_pick_P2(B, Hd);
+  if (P2 > 0) {
+    gru_u64* xbuf = (gru_u64*)(scratch + ((((size_t)3 * Hd * Hd + (size_t)3 * S * B * Hd) + 1) & ~(size_t)1));
+    SG_TRY(hipMemsetAsync(xbuf, 0, (size_t)2 * B * Hd * sizeof(gru_u64), st));      // tags := 0 before every launch
+    const dim3 grid(8 * ((B + 7) / 8) * P2);
+#define GRU_F2(PP) hipLaunchKernelGGL(gru_fwd_cluster2_kernel<PP>, grid, dim3(3 * PP * 64), 0, st, gi, w_hh, b_hh, B, S, Hd, \
+                                      xbuf, status, h_all, reserve)
+    if (P2 == 1) GRU_F2(1); else if (P2 == 2) GRU_F2(2); else if (P2 == 4) GRU_F2(4); else GRU_F2(5);
+#undef GRU_F2
+    SG_TRY(hipGetLastError());
+    return 0;
+  }
   const int P = gru_pick_P(B, Hd);
   if (P > 0) {
     const GruCluster c = gru_cluster_geom(Hd, P);
@@ -520,8 +708,18 @@ extern "C" int stemgnn_gru_bwd(const float* dh_all, const float* x, const float*
   float* dghn = dgi + (size_t)3 * S * B * Hd;
   float* p_hh = dghn + (size_t)S * B * Hd;
   float* p_ih = p_hh + (size_t)GRU_NSPLIT * 3 * Hd * (Hd + 1);
-  const int P = gru_pick_P(B, Hd);
-  if (P > 0) {
+  const int P2 = gru_pick_P2(B, Hd);
+  const int P = P2 > 0 ? 0 : gru_pick_P(B, Hd);
+  if (P2 > 0) {
+    gru_u64* xbuf = (gru_u64*)(scratch + ((((size_t)(p_ih - scratch) + (size_t)GRU_NSPLIT * 3 * Hd * (W + 1)) + 1) & ~(size_t)1));
+    SG_TRY(hipMemsetAsync(xbuf, 0, (size_t)2 * B * 3 * Hd * sizeof(gru_u64), st));
+    const dim3 grid(8 * ((B + 7) / 8) * P2);
+#define GRU_B2(PP) hipLaunchKernelGGL(gru_bwd_cluster2_kernel<PP>, grid, dim3(3 * PP * 64), 0, st, dh_all, w_hh, h_all, reserve, \
+                                      B, S, Hd, xbuf, status, dgi, dghn)
+    if (P2 == 1) GRU_B2(1); else if (P2 == 2) GRU_B2(2); else if (P2 == 4) GRU_B2(4); else GRU_B2(5);
+#undef GRU_B2
+    SG_TRY(hipGetLastError());
+  } else if (P > 0) {
     const GruCluster c = gru_cluster_geom(Hd, P);
     gru_u64* xbuf = (gru_u64*)(scratch + ((((size_t)(p_ih - scratch) + (size_t)GRU_NSPLIT * 3 * Hd * (W + 1)) + 1) & ~(size_t)1));
     if (P > 1) SG_TRY(hipMemsetAsync(xbuf, 0, (size_t)2 * B * 3 * Hd * sizeof(gru_u64), st));

@@ -10,10 +10,10 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-4
 
 
-@pytest.mark.parametrize("cluster", ["1", "0"])
-@pytest.mark.parametrize("B,S,W", [(32, 228, 12), (5, 33, 7), (3, 140, 12), (2, 300, 4), (9, 358, 12), (1, 64, 3)])
+@pytest.mark.parametrize("cluster", ["2", "1", "0"])
+@pytest.mark.parametrize("B,S,W", [(32, 228, 12), (5, 33, 7), (3, 140, 12), (2, 300, 4), (9, 358, 12), (1, 64, 3), (4, 307, 12)])
 def test_gru_fwd_bwd_vs_torch_cpu(B, S, W, cluster, monkeypatch):
-    monkeypatch.setenv("STEMGNN_GRU_CLUSTER", cluster)      # 1: multi-CU register-resident kernels, 0: streaming
+    monkeypatch.setenv("STEMGNN_GRU_CLUSTER", cluster)      # 2: cluster v2 (wave-level exchange), 1: cluster v1, 0: streaming
     from stemgnn_amd.ops import GruFront
 
     torch.manual_seed(S + B)
