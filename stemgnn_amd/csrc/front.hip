@@ -75,22 +75,23 @@ __global__ __launch_bounds__(256) void sg_keyquery_kernel(const float* __restric
   }
 }
 
-// One wave per adjacency row i: loops the batch, softmax over j in registers/LDS, accumulates the
-// batch mean (and the dropout mask, regenerated in backward from the same Philox stream).
-// dynamic LDS: qmax[B] + acc[4][N].
+// One wave per (adjacency row i, batch chunk): softmax over j for each batch of the chunk, the chunk's partial
+// batch-sum accumulates in LDS (the [B,N,N] tensor is never materialised) and goes to Apart[chunk][i][:].
+// The dropout mask is regenerated in backward from the same Philox stream.  grid (ceil(N/4), nbc).
+// dynamic LDS: qmax[bn] + acc[4][N]   (bn = batches per chunk)
 __global__ __launch_bounds__(256) void sg_attention_fwd_kernel(
     const float* __restrict__ key, const float* __restrict__ query, float alpha, float drop_p, int training,
-    const uint64_t* __restrict__ seedp, int B, int N, float* __restrict__ rowsum, float* __restrict__ A,
-    float* __restrict__ deg) {
+    const uint64_t* __restrict__ seedp, int B, int N, int bn, float* __restrict__ rowsum, float* __restrict__ Apart) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* qmax = smem;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  float* acc = smem + B + wave * N;
-  for (int b = wave; b < B; b += 4) {
+  float* acc = smem + bn + wave * N;
+  const int b0 = blockIdx.y * bn, b1 = min(B, b0 + bn);
+  for (int b = b0 + wave; b < b1; b += 4) {
     float m = -INFINITY;
     for (int j = lane; j < N; j += 64) m = fmaxf(m, query[(size_t)b * N + j]);
     m = sg_wave_max(m);
-    if (lane == 0) qmax[b] = m;
+    if (lane == 0) qmax[b - b0] = m;
   }
   __syncthreads();
   const int i = blockIdx.x * 4 + wave;
@@ -100,9 +101,9 @@ __global__ __launch_bounds__(256) void sg_attention_fwd_kernel(
   if (drop) { seed = seedp[0]; offset = seedp[1]; }
   const float keep_scale = drop ? 1.f / (1.f - drop_p) : 1.f;
   for (int j = lane; j < N; j += 64) acc[j] = 0.f;
-  for (int b = 0; b < B; ++b) {
+  for (int b = b0; b < b1; ++b) {
     const float kv = key[(size_t)b * N + i];
-    const float mx = sg_lrelu(kv + qmax[b], alpha);      // leaky-relu is monotone: row max is at max_j query
+    const float mx = sg_lrelu(kv + qmax[b - b0], alpha);      // leaky-relu is monotone: row max is at max_j query
     const float* q = query + (size_t)b * N;
     float s = 0.f;
     for (int j = lane; j < N; j += 64) s += expf(sg_lrelu(kv + q[j], alpha) - mx);
@@ -115,10 +116,22 @@ __global__ __launch_bounds__(256) void sg_attention_fwd_kernel(
       acc[j] += p;
     }
   }
+  float* out = Apart + ((size_t)blockIdx.y * N + i) * N;
+  for (int j = lane; j < N; j += 64) out[j] = acc[j];
+}
+
+// A[i][:] = (sum_chunks Apart[c][i][:]) / B  (fixed order), deg[i] = sum_j A[i][j].  One wave per row.
+__global__ __launch_bounds__(256) void sg_attention_reduce_kernel(const float* __restrict__ Apart, int nbc, int B, int N,
+                                                                  float* __restrict__ A, float* __restrict__ deg) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = blockIdx.x * 4 + wave;
+  if (i >= N) return;
   const float invB = 1.f / (float)B;
   float d = 0.f;
   for (int j = lane; j < N; j += 64) {
-    const float a = acc[j] * invB;
+    float s = 0.f;
+    for (int c = 0; c < nbc; ++c) s += Apart[((size_t)c * N + i) * N + j];
+    const float a = s * invB;
     A[(size_t)i * N + j] = a;
     d += a;
   }
@@ -344,7 +357,10 @@ struct ChebBwd2Op {
 // =================================================================================================
 // host side
 // =================================================================================================
-extern "C" size_t stemgnn_attn_saved_floats(int B, int N) { return (size_t)3 * B * N + (size_t)N * N + N; }
+static const int ATTN_NBC = 8;     // batch chunks of the attention forward (more waves; partial sums reduced in fixed order)
+extern "C" size_t stemgnn_attn_saved_floats(int B, int N) {
+  return (size_t)3 * B * N + (size_t)N * N + N + (size_t)ATTN_NBC * N * N;     // ... | deg | per-chunk partial sums
+}
 extern "C" size_t stemgnn_attn_scratch_floats(int B, int N, int nchunk) {
   return (size_t)N * N + (size_t)2 * B * N + (size_t)B * nchunk * N;
 }
@@ -363,10 +379,15 @@ extern "C" int stemgnn_attn_laplacian_fwd(const float* h, const float* wk, const
   float* deg = A + (size_t)N * N;
   hipLaunchKernelGGL(sg_keyquery_kernel, dim3(B, (N + 63) / 64), dim3(256), 0, st, h, wk, wq, key, query, B, N);
   SG_TRY(hipGetLastError());
-  const size_t lds = (size_t)(B + 4 * N) * sizeof(float);
-  if (lds > 150 * 1024) return SG_EINVAL;
-  hipLaunchKernelGGL(sg_attention_fwd_kernel, dim3((N + 3) / 4), dim3(256), lds, st, key, query, alpha, drop_p,
-                     training, seed, B, N, rowsum, A, deg);
+  float* Apart = deg + N;
+  const int nbc = B < ATTN_NBC ? B : ATTN_NBC;
+  const int bn = (B + nbc - 1) / nbc;
+  const size_t lds = (size_t)(bn + 4 * N) * sizeof(float);
+  if (lds > 64 * 1024) return SG_EINVAL;
+  hipLaunchKernelGGL(sg_attention_fwd_kernel, dim3((N + 3) / 4, (B + bn - 1) / bn), dim3(256), lds, st, key, query, alpha,
+                     drop_p, training, seed, B, N, bn, rowsum, Apart);
+  SG_TRY(hipGetLastError());
+  hipLaunchKernelGGL(sg_attention_reduce_kernel, dim3((N + 3) / 4), dim3(256), 0, st, Apart, (B + bn - 1) / bn, B, N, A, deg);
   SG_TRY(hipGetLastError());
   hipLaunchKernelGGL(sg_laplacian_fwd_kernel, dim3((N + 31) / 32, (N + 31) / 32), dim3(256), 0, st, A, deg,
                      attention_out, mul_L, N);
@@ -422,9 +443,9 @@ extern "C" int stemgnn_cheb_fwd(float* mul_L, int N, void* stream) {
   const size_t nn = (size_t)N * N;
   float* L = mul_L + nn;
   ChebFwdOp op2{L, L, mul_L + 2 * nn, N, 0};
-  SG_TRY((sg_launch_gemm<ChebFwdOp, 64, 64, true, false, false>(op2, N, N, 1, st)));
+  SG_TRY((sg_launch_gemm<ChebFwdOp, 32, 32, true, false, false, 64>(op2, N, N, 1, st)));
   ChebFwdOp op3{L, mul_L + 2 * nn, mul_L + 3 * nn, N, 1};
-  SG_TRY((sg_launch_gemm<ChebFwdOp, 64, 64, true, false, false>(op3, N, N, 1, st)));
+  SG_TRY((sg_launch_gemm<ChebFwdOp, 32, 32, true, false, false, 64>(op3, N, N, 1, st)));
   return 0;
 }
 
@@ -436,8 +457,8 @@ extern "C" int stemgnn_cheb_bwd(const float* mul_L, const float* dmul_L, float* 
   float* dLp = scratch;
   float* dT2p = scratch + nn;
   ChebBwd1Op op1{mul_L + nn, mul_L + 2 * nn, dmul_L + nn, dmul_L + 2 * nn, dmul_L + 3 * nn, dLp, dT2p, N};
-  SG_TRY((sg_launch_gemm<ChebBwd1Op, 64, 64, true, true, false>(op1, N, N, 2, st)));
+  SG_TRY((sg_launch_gemm<ChebBwd1Op, 32, 32, true, true, false, 64>(op1, N, N, 2, st)));
   ChebBwd2Op op2{mul_L + nn, dT2p, dLp, dL, N};
-  SG_TRY((sg_launch_gemm<ChebBwd2Op, 64, 64, true, true, false>(op2, N, N, 1, st)));
+  SG_TRY((sg_launch_gemm<ChebBwd2Op, 32, 32, true, true, false, 64>(op2, N, N, 1, st)));
   return 0;
 }

@@ -2,7 +2,8 @@
 // functor epilogue.  Exact fp32 (v_mfma_f32_16x16x4_f32 == an fmaf chain), wave64.
 //
 //   * 256 threads = 4 waves in a 2x2 grid; block tile BM x BN, wave tile (BM/2) x (BN/2) made of
-//     16x16 MFMA tiles; BK = 16 (four k-steps of 4 per LDS tile).
+//     16x16 MFMA tiles; BK = 16 by default (four k-steps of 4 per LDS tile); small, latency-bound problems
+//     (N x N x N Chebyshev products, GFT) use BK = 64 and 32 x 32 tiles: fewer dependent load->LDS->MFMA rounds.
 //   * operands are staged K-major in LDS:  As[k][i], Bs[k][j]; the row stride is chosen per
 //     operand so both the staging ds_write_b32 and the fragment ds_read_b32 are conflict-free
 //     (stride % 32 == 17 when threads walk k fastest, == 16 when they walk i/j fastest;
@@ -18,9 +19,9 @@
 
 typedef float sg_f32x4 __attribute__((ext_vector_type(4)));
 
-template <class Op, int BM, int BN, bool A_KFAST, bool B_KFAST, bool PAIR>
+template <class Op, int BM, int BN, bool A_KFAST, bool B_KFAST, bool PAIR, int BK = 16>
 __global__ __launch_bounds__(256) void sg_gemm_f32(const Op op) {
-  constexpr int BK = 16;
+  static_assert(BK % 16 == 0, "BK");
   constexpr int TM = BM / 32;           // 16x16 tiles per wave along M
   constexpr int TN = BN / 32;           // 16x16 tiles per wave along N
   constexpr int SA = BM + (A_KFAST ? 17 : 16);
@@ -58,8 +59,8 @@ __global__ __launch_bounds__(256) void sg_gemm_f32(const Op op) {
 #pragma unroll
     for (int r = 0; r < RA; ++r) {
       const int e = tid + 256 * r;
-      const int k = A_KFAST ? (e & 15) : (e / BM);
-      const int i = A_KFAST ? (e >> 4) : (e % BM);
+      const int k = A_KFAST ? (e % BK) : (e / BM);
+      const int i = A_KFAST ? (e / BK) : (e % BM);
       const int gi = m0 + i, gk = kbase + k;
       // unconditional load from a clamped (always valid) index, then select: a branch around each load would
       // make hipcc wait vmcnt(0) per element and serialise the tile's loads (cdna guide, ".s-level traps" (c))
@@ -69,8 +70,8 @@ __global__ __launch_bounds__(256) void sg_gemm_f32(const Op op) {
 #pragma unroll
     for (int r = 0; r < RB; ++r) {
       const int e = tid + 256 * r;
-      const int k = B_KFAST ? (e & 15) : (e / BN);
-      const int j = B_KFAST ? (e >> 4) : (e % BN);
+      const int k = B_KFAST ? (e % BK) : (e / BN);
+      const int j = B_KFAST ? (e / BK) : (e % BN);
       const int gj = n0 + j, gk = kbase + k;
       const float v = op.b(z, gk < K1 ? gk : K1 - 1, gj < N ? gj : N - 1);
       rb[r] = (gj < N && gk < K1) ? v : 0.f;
@@ -80,15 +81,15 @@ __global__ __launch_bounds__(256) void sg_gemm_f32(const Op op) {
 #pragma unroll
     for (int r = 0; r < RA; ++r) {
       const int e = tid + 256 * r;
-      const int k = A_KFAST ? (e & 15) : (e / BM);
-      const int i = A_KFAST ? (e >> 4) : (e % BM);
+      const int k = A_KFAST ? (e % BK) : (e / BM);
+      const int i = A_KFAST ? (e / BK) : (e % BM);
       As[k * SA + i] = ra[r];
     }
 #pragma unroll
     for (int r = 0; r < RB; ++r) {
       const int e = tid + 256 * r;
-      const int k = B_KFAST ? (e & 15) : (e / BN);
-      const int j = B_KFAST ? (e >> 4) : (e % BN);
+      const int k = B_KFAST ? (e % BK) : (e / BN);
+      const int j = B_KFAST ? (e / BK) : (e % BN);
       Bs[k * SB + j] = rb[r];
     }
   };
@@ -142,10 +143,10 @@ __global__ __launch_bounds__(256) void sg_gemm_f32(const Op op) {
   }
 }
 
-template <class Op, int BM, int BN, bool A_KFAST, bool B_KFAST, bool PAIR>
+template <class Op, int BM, int BN, bool A_KFAST, bool B_KFAST, bool PAIR, int BK = 16>
 static inline hipError_t sg_launch_gemm(const Op& op, int maxM, int maxN, int nz, hipStream_t stream) {
   dim3 grid((maxM + BM - 1) / BM, (maxN + BN - 1) / BN, nz);
   if (grid.x == 0 || grid.y == 0 || grid.z == 0) return hipSuccess;
-  hipLaunchKernelGGL((sg_gemm_f32<Op, BM, BN, A_KFAST, B_KFAST, PAIR>), grid, dim3(256), 0, stream, op);
+  hipLaunchKernelGGL((sg_gemm_f32<Op, BM, BN, A_KFAST, B_KFAST, PAIR, BK>), grid, dim3(256), 0, stream, op);
   return hipGetLastError();
 }

@@ -12,7 +12,7 @@ import torch
 
 from . import _lib
 
-_NSPLIT = int(os.environ.get("STEMGNN_NSPLIT", "16"))     # split-M factor of the weight-gradient GEMMs
+_NSPLIT = int(os.environ.get("STEMGNN_NSPLIT", "32"))     # split-M factor of the weight-gradient GEMMs
 _DIRECT_GRAD = False
 
 
