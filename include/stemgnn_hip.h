@@ -130,10 +130,13 @@ int stemgnn_gft_bwd(const float* mul_L, const float* X, long xs_b, long xs_n, lo
 /* ---- spe_seq_cell: DFT -> 3x GLU on Re and Im (models/base_model.py:46-54, GLU :12-13) ----------
  * G = saved + offset(G) is read; GLU outputs and gates are written into `saved`. */
 int stemgnn_spectral_glu_fwd(const float* packed, float* saved, int B, int N, int W, int multi, void* stream);
-/* needs d(last GLU outputs) in scratch.dact[r][0] (written by igft_heads_bwd); produces dG in
- * scratch.dG and the GLU weight-gradient partials in gradpart. */
+/* needs d(pre-activation) of the last GLU layer in scratch (written by igft_heads_bwd); produces dG in
+ * scratch.dG and the GLU weight-gradient partials in gradpart.
+ * parts: bit 0 = data-gradient chain (layer 2 -> 1 -> 0 -> dG), bit 1 = the weight-gradient GEMMs.  The two parts
+ * only share read-only inputs once the chain has run, so a caller may issue part 2 later or on another stream
+ * (it is off the critical path of the backward pass); 3 = both, in order. */
 int stemgnn_spectral_glu_bwd(const float* packed, const float* saved, float* scratch, float* gradpart,
-                             int nsplit, int B, int N, int W, int multi, void* stream);
+                             int nsplit, int parts, int B, int N, int W, int multi, void* stream);
 
 /* ---- C2R iDFT + graph-conv weight + forecast / backcast heads (models/base_model.py:55-58, 65-74)
  * forecast [M,W]: written (accumulate=0) or added to (accumulate=1: result[0]+result[1], :174).
@@ -142,12 +145,13 @@ int stemgnn_igft_heads_fwd(const float* const* params_host, const float* packed,
                            const float* X, long xs_b, long xs_n, long xs_t,
                            float* forecast, int accumulate, float* backcast,
                            int B, int N, int W, int multi, void* stream);
-/* dforecast [M,W], dbackcast [M,W] or NULL, backcast = forward output (for sigmoid').  Writes
- * scratch.dact[r][0] (d of the last GLU outputs) and the heads' weight-gradient partials. */
+/* dforecast [M,W], dbackcast [M,W] or NULL, backcast = forward output (for sigmoid').  parts bit 0: data path
+ * (dpF, dpB, dig and d(pre-activation) of the last GLU layer into scratch); bit 1: the heads' / graph-conv
+ * weight-gradient partials (needs bit 0's results). */
 int stemgnn_igft_heads_bwd(const float* const* params_host, const float* packed, const float* saved,
                            const float* X, long xs_b, long xs_n, long xs_t,
                            const float* dforecast, const float* dbackcast, const float* backcast,
-                           float* scratch, float* gradpart, int nsplit,
+                           float* scratch, float* gradpart, int nsplit, int parts,
                            int B, int N, int W, int multi, void* stream);
 
 /* ---- callers on either side of the blocks, fused ------------------------------------------------

@@ -49,10 +49,10 @@ SIGNATURES = {
     "stemgnn_gft_fwd": (c_int, [_P, _P, c_long, c_long, c_long, _P, c_int, c_int, c_int, _P]),
     "stemgnn_gft_bwd": (c_int, [_P, _P, c_long, c_long, c_long, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "stemgnn_spectral_glu_fwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
-    "stemgnn_spectral_glu_bwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+    "stemgnn_spectral_glu_bwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "stemgnn_igft_heads_fwd": (c_int, [_PP, _P, _P, _P, c_long, c_long, c_long, _P, c_int, _P,
                                        c_int, c_int, c_int, c_int, _P]),
-    "stemgnn_igft_heads_bwd": (c_int, [_PP, _P, _P, _P, c_long, c_long, c_long, _P, _P, _P, _P, _P, c_int,
+    "stemgnn_igft_heads_bwd": (c_int, [_PP, _P, _P, _P, c_long, c_long, c_long, _P, _P, _P, _P, _P, c_int, c_int,
                                        c_int, c_int, c_int, c_int, _P]),
 }
 

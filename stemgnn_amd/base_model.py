@@ -19,7 +19,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import _lib
-from .ops import FcTail, GruFront, SpectralHotPath
+from .ops import FcTail, GruFront, SpectralHotPath, StockBlockFn
 
 _BLOCK_FIELDS = ("forecast", "forecast_result", "backcast", "backcast_short_cut")
 
@@ -67,9 +67,15 @@ class StockBlockLayer(nn.Module):
         return out
 
     def forward(self, x, mul_L):
-        raise _lib.StemGNNHipError(
-            "stemgnn_amd.StockBlockLayer is driven by Model.forward (both blocks share one fused autograd node); "
-            "use stemgnn_amd.ops for stage-level access")
+        """x [B,1,N,W], mul_L [4,N,N] -> (forecast [B,N,W], backcast [B,1,N,W] | None)   (reference :61-75).
+        Stand-alone entry; Model.forward runs both blocks inside one fused autograd node instead."""
+        if not x.is_cuda:
+            raise _lib.StemGNNHipError(
+                f"input is on {x.device}: stemgnn_amd.StockBlockLayer runs only on a HIP device (no CPU fallback)")
+        B, _, N, W = x.shape
+        forecast, backcast = StockBlockFn.apply(x.reshape(B, N, W), mul_L, self.multi, self.stack_cnt == 0,
+                                                *self.hip_params())
+        return forecast, (backcast.unsqueeze(1) if backcast is not None else None)
 
 
 class Model(nn.Module):

@@ -460,9 +460,10 @@ extern "C" int stemgnn_spectral_glu_fwd(const float* packed, float* saved, int B
 }
 
 extern "C" int stemgnn_spectral_glu_bwd(const float* packed, const float* saved, float* scratch,
-                                        float* gradpart, int nsplit, int B, int N, int W, int multi,
+                                        float* gradpart, int nsplit, int parts, int B, int N, int W, int multi,
                                         void* stream) {
-  if (!packed || !saved || !scratch || !gradpart || nsplit <= 0 || B <= 0 || N <= 0 || W <= 0 || multi <= 0)
+  if (!packed || !saved || !scratch || !gradpart || nsplit <= 0 || B <= 0 || N <= 0 || W <= 0 || multi <= 0 ||
+      (parts & 3) == 0)
     return SG_EINVAL;
   const SgDims d = sg_dims(B, N, W, multi);
   const SgPackedLayout P = sg_packed_layout(d);
@@ -472,10 +473,10 @@ extern "C" int stemgnn_spectral_glu_bwd(const float* packed, const float* saved,
   hipStream_t st = (hipStream_t)stream;
   const int chunk = split_chunk(d.M, nsplit);
   for (int l = 2; l >= 0; --l) {
-    // d(pre-activation) of layer l lives in dact[r][(2-l)&1] as [M x NP(l,r)] (pair order); it was written by
+    // d(pre-activation) of layer l lives in dact[r][l] as [M x NP(l,r)] (pair order); it was written by
     // igft_heads_bwd (l = 2) or by the data-gradient epilogue of layer l+1
-    const int slot = (2 - l) & 1;
-    {  // weight gradient: part[q][kin | bias] = sum_m dpre[m][q] * x[m][kin]   (split over the M rows)
+    const int slot = l;
+    if (parts & 2) {  // weight gradient: part[q][kin | bias] = sum_m dpre[m][q] * x[m][kin]   (split over the M rows)
       G2Args g;
       GluWgradEpi e;
       for (int r = 0; r < 2; ++r) {
@@ -489,6 +490,7 @@ extern "C" int stemgnn_spectral_glu_bwd(const float* packed, const float* saved,
       g.nsplit = nsplit; g.chunk = chunk; g.b_ones_col = sg_glu_kin(d, l);
       SG_TRY((g2_launch<GluWgradEpi, false, false>(g, e, 2, st)));
     }
+    if (!(parts & 1)) continue;
     if (l > 0) {  // data gradient -> d(pre-activation) of layer l-1
       G2Args g;
       GluDpreEpi e;
@@ -500,7 +502,7 @@ extern "C" int stemgnn_spectral_glu_bwd(const float* packed, const float* saved,
         g.M[r] = d.M; g.N[r] = d.CP; g.K[r] = sg_glu_np(d, l, r);
         e.out[r] = saved + S.out[r][l - 1];
         e.gate[r] = saved + S.gate[r][l - 1];
-        e.dpre[r] = scratch + C.dact[r][slot ^ 1];
+        e.dpre[r] = scratch + C.dact[r][l - 1];
       }
       e.cp = d.CP;
       g.nsplit = 1; g.chunk = (2 * d.CP + 15) & ~15; g.b_ones_col = -1;
@@ -549,10 +551,10 @@ extern "C" int stemgnn_igft_heads_fwd(const float* const* params_host, const flo
 extern "C" int stemgnn_igft_heads_bwd(const float* const* params_host, const float* packed, const float* saved,
                                       const float* X, long xs_b, long xs_n, long xs_t,
                                       const float* dforecast, const float* dbackcast, const float* backcast,
-                                      float* scratch, float* gradpart, int nsplit,
+                                      float* scratch, float* gradpart, int nsplit, int parts,
                                       int B, int N, int W, int multi, void* stream) {
   if (!params_host || !packed || !saved || !X || !dforecast || !scratch || !gradpart || nsplit <= 0 ||
-      B <= 0 || N <= 0 || W <= 0 || multi <= 0)
+      B <= 0 || N <= 0 || W <= 0 || multi <= 0 || (parts & 3) == 0)
     return SG_EINVAL;
   const SgDims d = sg_dims(B, N, W, multi);
   const SgPackedLayout P = sg_packed_layout(d);
@@ -565,25 +567,25 @@ extern "C" int stemgnn_igft_heads_bwd(const float* const* params_host, const flo
   float* dpF = scratch + C.dpF;
   float* dpB = scratch + C.dpB;
   float* dig = scratch + C.dig;
-  if (has_bc) {
+  if ((parts & 1) && has_bc) {
     const size_t n = (size_t)d.M * W;
     const int blocks = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
     hipLaunchKernelGGL(sg_dsigmoid_kernel, dim3(blocks), dim3(256), 0, st, dbackcast, backcast, dpB, n);
     SG_TRY(hipGetLastError());
   }
-  {
+  if (parts & 1) {
     Head2BwdOp op{dforecast, params_host[3], saved + S.fs, dpF, d.M, W, d.Wm};
     SG_TRY((sg_launch_gemm<Head2BwdOp, 64, 64, true, false, false>(op, d.M, d.Wm, 1, st)));
   }
-  {
+  if (parts & 1) {
     DigOp op{dpF, dpB, params_host[1], params_host[5], dig, d.M, W, d.Wm, has_bc};
     SG_TRY((sg_launch_gemm<DigOp, 64, 64, true, false, false>(op, d.M, d.Wm, 1, st)));
   }
-  {
+  if (parts & 1) {
     Da3Op op;
     op.dig = dig; op.wfold = packed + P.wfold;
     for (int r = 0; r < 2; ++r) {
-      op.dpre[r] = scratch + C.dact[r][0];
+      op.dpre[r] = scratch + C.dact[r][2];
       op.out[r] = saved + S.out[r][2];
       op.gate[r] = saved + S.gate[r][2];
       op.cp2[r] = d.CP2[r];
@@ -592,7 +594,7 @@ extern "C" int stemgnn_igft_heads_bwd(const float* const* params_host, const flo
     const int maxN = d.CP2[0] > d.CP2[1] ? d.CP2[0] : d.CP2[1];
     SG_TRY((sg_launch_gemm<Da3Op, 64, 64, true, true, false>(op, d.M, maxN, 2, st)));
   }
-  {
+  if (parts & 2) {
     HeadsWgradOp op;
     op.dfo = dforecast; op.fs = saved + S.fs; op.dpF = dpF; op.ig = saved + S.ig; op.dpB = dpB; op.dig = dig;
     for (int r = 0; r < 2; ++r) { op.a3[r] = saved + S.out[r][2]; op.cp2[r] = d.CP2[r]; }

@@ -467,8 +467,8 @@ __global__ __launch_bounds__(3 * P * 64) void gru_fwd_cluster2_kernel(const floa
         g1 += part[s & 1][1 * P + qq][tid];
         g2 += part[s & 1][2 * P + qq][tid];
       }
-      const float r = gru_sigmoid(gp0 + g0);
-      const float z = gru_sigmoid(gp1 + g1);
+      const float r = gru_sigmoid(gp0 + g0);       // (the v_exp/v_rcp fast forms were measured: no gain, the step
+      const float z = gru_sigmoid(gp1 + g1);       //  is bound by the exchange latency, so the exact forms stay)
       const float n = tanhf(gp2 + r * g2);
       const float hn = (1.f - z) * n + z * hown;
       hown = hn;

@@ -136,7 +136,8 @@ struct SgScratchLayout {
   size_t dpF;            // M x Wm
   size_t dpB;            // M x W
   size_t dig;            // M x Wm
-  size_t dact[2][2];     // ping-pong M x 2CP per branch: d(pre-activation) of a GLU layer in "pair" column order
+  size_t dact[2][3];     // [branch][layer]: d(pre-activation) of GLU layer l, M x 2CP in "pair" column order (one buffer per
+                         // layer, so the weight-gradient GEMMs can run later / on another stream than the data-gradient chain)
   size_t dG;             // M x KG
   size_t total;
 };
@@ -147,7 +148,7 @@ SG_HD SgScratchLayout sg_scratch_layout(const SgDims& d) {
   L.dpB = off; off += M * d.W;
   L.dig = off; off += M * d.Wm;
   for (int r = 0; r < 2; ++r)
-    for (int p = 0; p < 2; ++p) { L.dact[r][p] = off; off += M * 2 * d.CP; }
+    for (int p = 0; p < 3; ++p) { L.dact[r][p] = off; off += M * 2 * d.CP; }
   L.dG = off; off += M * d.KG;
   L.total = off;
   return L;

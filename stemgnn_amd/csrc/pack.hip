@@ -96,9 +96,16 @@ __global__ void sg_pack_kernel(SgBlockParams prm, const float* __restrict__ tab,
       const int kq = c / d.nf[r], fi = c - kq * d.nf[r];
       const float* cinv = tab + (r ? T.cinvI : T.cinvR) + (size_t)fi * Wm;
       const float* wt = prm.p[0] + (size_t)kq * Wm * Wm + o;
-      float s = 0.f;
-      for (int tau = 0; tau < Wm; ++tau) s = fmaf(cinv[tau], wt[(size_t)tau * Wm], s);
-      val = s;
+      float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;      // independent chains: the strided loads overlap
+      int tau = 0;
+      for (; tau + 3 < Wm; tau += 4) {
+        s0 = fmaf(cinv[tau], wt[(size_t)tau * Wm], s0);
+        s1 = fmaf(cinv[tau + 1], wt[(size_t)(tau + 1) * Wm], s1);
+        s2 = fmaf(cinv[tau + 2], wt[(size_t)(tau + 2) * Wm], s2);
+        s3 = fmaf(cinv[tau + 3], wt[(size_t)(tau + 3) * Wm], s3);
+      }
+      for (; tau < Wm; ++tau) s0 = fmaf(cinv[tau], wt[(size_t)tau * Wm], s0);
+      val = (s0 + s1) + (s2 + s3);
     }
     packed[idx] = val;
     return;
@@ -196,12 +203,14 @@ __global__ void sg_unpack_kernel(const float* __restrict__ part, const float* __
     const int rem = (int)(e - (size_t)kq * Wm * Wm);
     const int tau = rem / Wm, o = rem - tau * Wm;
     const float* wf = part + G.wfold;
-    float s = 0.f;
+    float s0 = 0.f, s1 = 0.f;
+#pragma unroll 4
     for (int f = 0; f < d.nf[0]; ++f)
-      s = fmaf(tab[T.cinvR + (size_t)f * Wm + tau], wf[(size_t)(kq * d.nf[0] + f) * d.WmP + o], s);
+      s0 = fmaf(tab[T.cinvR + (size_t)f * Wm + tau], wf[(size_t)(kq * d.nf[0] + f) * d.WmP + o], s0);
+#pragma unroll 4
     for (int f = 0; f < d.nf[1]; ++f)
-      s = fmaf(tab[T.cinvI + (size_t)f * Wm + tau], wf[(size_t)(d.CP2[0] + kq * d.nf[1] + f) * d.WmP + o], s);
-    val = s;
+      s1 = fmaf(tab[T.cinvI + (size_t)f * Wm + tau], wf[(size_t)(d.CP2[0] + kq * d.nf[1] + f) * d.WmP + o], s1);
+    val = s0 + s1;
   } else if (pi <= 8) {
     const int isb = (pi - 1) & 1;             // 1,3,5,7 weights; 2,4,6,8 biases
     const int which = (pi - 1) >> 1;          // 0 forecast, 1 forecast_result, 2 backcast, 3 short-cut

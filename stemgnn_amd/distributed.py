@@ -40,6 +40,9 @@ class FlatGradBucket:
         self.flat.zero_()
 
     def all_reduce_mean(self, group=None):
+        if self.flat.is_cuda:
+            from .ops import join_side_streams
+            join_side_streams(self.flat.device)      # weight gradients may still be in flight on the side stream
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
             self.flat.div_(dist.get_world_size(group))

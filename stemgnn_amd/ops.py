@@ -14,15 +14,45 @@ from . import _lib
 
 _NSPLIT = int(os.environ.get("STEMGNN_NSPLIT", "32"))     # split-M factor of the weight-gradient GEMMs
 _DIRECT_GRAD = False
+_OVERLAP_WGRAD = False
+_side_streams = {}
+_pending_join = {}
 
 
-def set_direct_grad(flag=True):
+def _side_stream(device):
+    key = str(device)
+    st = _side_streams.get(key)
+    if st is None:
+        st = torch.cuda.Stream(device=device)
+        _side_streams[key] = st
+    return st
+
+
+def join_side_streams(device=None):
+    """Make the current stream wait for weight-gradient work queued on the side stream (see
+    SpectralHotPath.backward).  Called by every consumer of the gradients; cheap no-op when nothing is pending."""
+    keys = [str(device)] if device is not None else list(_pending_join.keys())
+    for k in keys:
+        item = _pending_join.pop(k, None)
+        if item is not None:
+            side, keep, extra = item
+            torch.cuda.current_stream().wait_stream(side)
+            del keep, extra
+
+
+def set_direct_grad(flag=True, overlap=False):
     """Opt-in: backward WRITES the hot-path / GRU parameter gradients straight into existing ``p.grad`` buffers
     (e.g. the views of a FlatGradBucket) instead of returning them to autograd, which would launch one
     accumulate kernel per parameter (~70 tiny launches per step).  Semantics: overwrite, i.e. equivalent to
-    ``zero_grad(); backward()`` -- do not use when accumulating gradients over several backward passes."""
-    global _DIRECT_GRAD
+    ``zero_grad(); backward()`` -- do not use when accumulating gradients over several backward passes.
+
+    ``overlap=True`` additionally queues the spectral blocks' weight-gradient GEMMs on a side HIP stream so they
+    overlap the rest of the backward pass (notably the latency-bound GRU recurrence).  The gradients are then
+    complete only after ``join_side_streams()``; FusedRMSprop.step, FlatGradBucket.all_reduce_mean and
+    GruFront.backward call it -- any other reader of ``.grad`` must call it first."""
+    global _DIRECT_GRAD, _OVERLAP_WGRAD
     _DIRECT_GRAD = bool(flag)
+    _OVERLAP_WGRAD = bool(flag) and bool(overlap) and os.environ.get("STEMGNN_OVERLAP_WGRAD", "1") == "1"
 _NCHUNK = int(os.environ.get("STEMGNN_ATTN_CHUNKS", "4"))  # row chunks of the attention backward
 
 
@@ -132,6 +162,7 @@ class GruFront(torch.autograd.Function):
                                        reserve.data_ptr(), B, S, Hd, W, scratch.data_ptr(), dw_ih.data_ptr(),
                                        dw_hh.data_ptr(), db_ih.data_ptr(), db_hh.data_ptr(),
                                        gru_status(dev).data_ptr(), _stream()), "gru_bwd")
+        join_side_streams(dev)          # the spectral blocks' weight gradients (side stream) overlapped this recurrence
         if direct:
             return None, None, None, None, None
         return None, dw_ih, dw_hh, db_ih, db_hh
@@ -177,6 +208,88 @@ class FcTail(torch.autograd.Function):
         if direct:
             return dfsum, None, None, None, None
         return dfsum, dw0, db0, dw2, db2
+
+
+class StockBlockFn(torch.autograd.Function):
+    """One StockBlockLayer (reference models/base_model.py:61-75) as a stand-alone autograd node:
+    (X [B,N,W] contiguous, mul_L [4,N,N], multi, has_backcast, 33 block params) -> (forecast [B,N,W], backcast [B,N,W]).
+    Model.forward uses the fused two-block node (SpectralHotPath); this one backs StockBlockLayer.forward."""
+
+    @staticmethod
+    def forward(ctx, X, mul_L, multi, has_bc, *params):
+        lib = _lib.load()
+        _require_gpu(X, "x")
+        _require_gpu(mul_L, "mul_L")
+        X = X.contiguous()
+        mul_L = mul_L.contiguous()
+        B, N, W = X.shape
+        dev, f32 = X.device, torch.float32
+        st = _stream()
+        params = [None if p is None else p.contiguous() for p in params]
+        tables = dft_tables(W, multi, dev)
+        pk = torch.empty(lib.stemgnn_packed_floats(W, multi), device=dev, dtype=f32)
+        sv = torch.empty(lib.stemgnn_saved_floats(B, N, W, multi), device=dev, dtype=f32)
+        forecast = torch.empty(B, N, W, device=dev, dtype=f32)
+        backcast = torch.empty(B, N, W, device=dev, dtype=f32) if has_bc else None
+        parr = _lib.ptr_array(params)
+        sb, sn, stt = N * W, W, 1
+        _lib.check(lib.stemgnn_block_pack(parr, tables.data_ptr(), pk.data_ptr(), W, multi, st), "block_pack")
+        _lib.check(lib.stemgnn_gft_fwd(mul_L.data_ptr(), X.data_ptr(), sb, sn, stt, sv.data_ptr(), B, N, W, st), "gft_fwd")
+        _lib.check(lib.stemgnn_spectral_glu_fwd(pk.data_ptr(), sv.data_ptr(), B, N, W, multi, st), "spectral_glu_fwd")
+        _lib.check(lib.stemgnn_igft_heads_fwd(parr, pk.data_ptr(), sv.data_ptr(), X.data_ptr(), sb, sn, stt,
+                                              forecast.data_ptr(), 0, backcast.data_ptr() if has_bc else None,
+                                              B, N, W, multi, st), "igft_heads_fwd")
+        ctx.dims = (B, N, W, multi, bool(has_bc))
+        ctx.params = params
+        ctx.aux = (X, mul_L, tables, pk, sv, backcast.detach() if has_bc else None)
+        if has_bc:
+            return forecast, backcast
+        return forecast, None
+
+    @staticmethod
+    def backward(ctx, dforecast, dbackcast):
+        lib = _lib.load()
+        B, N, W, multi, has_bc = ctx.dims
+        X, mul_L, tables, pk, sv, backcast = ctx.aux
+        params = ctx.params
+        dev, f32 = X.device, torch.float32
+        st = _stream()
+        nsplit = _NSPLIT
+        if dforecast is None:
+            dforecast = torch.zeros(B, N, W, device=dev, dtype=f32)
+        dforecast = dforecast.contiguous()
+        use_bc = has_bc and dbackcast is not None
+        if has_bc and not use_bc:
+            dbackcast = torch.zeros(B, N, W, device=dev, dtype=f32)
+            use_bc = True
+        scratch = torch.empty(lib.stemgnn_scratch_floats(B, N, W, multi), device=dev, dtype=f32)
+        dG = scratch[lib.stemgnn_scratch_offset_dG(B, N, W, multi):]
+        gradpart = torch.empty(lib.stemgnn_gradpart_floats(W, multi, nsplit), device=dev, dtype=f32)
+        dmul_L = torch.zeros(4, N, N, device=dev, dtype=f32)
+        dX = torch.empty(B, N, W, device=dev, dtype=f32)
+        parr = _lib.ptr_array(params)
+        sb, sn, stt = N * W, W, 1
+        _lib.check(lib.stemgnn_igft_heads_bwd(
+            parr, pk.data_ptr(), sv.data_ptr(), X.data_ptr(), sb, sn, stt, dforecast.data_ptr(),
+            dbackcast.contiguous().data_ptr() if use_bc else None, backcast.data_ptr() if use_bc else None,
+            scratch.data_ptr(), gradpart.data_ptr(), nsplit, 3, B, N, W, multi, st), "igft_heads_bwd")
+        _lib.check(lib.stemgnn_spectral_glu_bwd(pk.data_ptr(), sv.data_ptr(), scratch.data_ptr(), gradpart.data_ptr(),
+                                                nsplit, 3, B, N, W, multi, st), "spectral_glu_bwd")
+        _lib.check(lib.stemgnn_gft_bwd(mul_L.data_ptr(), X.data_ptr(), sb, sn, stt, dG.data_ptr(), dX.data_ptr(),
+                                       dmul_L.data_ptr(), 0, B, N, W, st), "gft_bwd")
+        grads = [None] * 33
+        for i, p in enumerate(params):
+            if p is None or (not has_bc and i in (7, 8)):
+                continue
+            grads[i] = torch.empty_like(p)
+        _lib.check(lib.stemgnn_block_unpack_grads(gradpart.data_ptr(), nsplit, tables.data_ptr(), _lib.ptr_array(grads),
+                                                  W, multi, int(has_bc), st), "block_unpack_grads")
+        if use_bc and ctx.needs_input_grad[0]:
+            # short-cut input of the backcast head (:71-72): backcast = sigmoid(BC(ig) - BS(x)) also depends on x directly.
+            # Model.forward never needs this term (x is data); only a stand-alone block with a differentiable input does.
+            dpb = dbackcast * backcast * (1.0 - backcast)
+            dX = dX - torch.matmul(dpb, params[7])
+        return (dX, dmul_L, None, None, *grads)
 
 
 class SpectralHotPath(torch.autograd.Function):
@@ -261,39 +374,79 @@ class SpectralHotPath(torch.autograd.Function):
         st = _stream()
         dfsum = dfsum.contiguous()
         nsplit = _NSPLIT
-        scratch = torch.empty(lib.stemgnn_scratch_floats(B, N, W, multi), device=dev, dtype=f32)
-        dG = scratch[lib.stemgnn_scratch_offset_dG(B, N, W, multi):]
-        gradpart = torch.empty(lib.stemgnn_gradpart_floats(W, multi, nsplit), device=dev, dtype=f32)
+        n_scratch = lib.stemgnn_scratch_floats(B, N, W, multi)
+        off_dG = lib.stemgnn_scratch_offset_dG(B, N, W, multi)
+        n_gradpart = lib.stemgnn_gradpart_floats(W, multi, nsplit)
         dmul_L = torch.empty(4, N, N, device=dev, dtype=f32)
         dbackcast = torch.empty(B, N, W, device=dev, dtype=f32)
         xviews = [(x, W * N, 1, N), (backcast, N * W, W, 1)]
         grads = [[None] * 33, [None] * 33]
         direct_idx = set()
         for s in (1, 0):
-            parr = _lib.ptr_array(blocks[s])
-            X, sb, sn, stt = xviews[s]
-            has_bc = s == 0
-            _lib.check(lib.stemgnn_igft_heads_bwd(
-                parr, packed[s].data_ptr(), saved[s].data_ptr(), X.data_ptr(), sb, sn, stt, dfsum.data_ptr(),
-                dbackcast.data_ptr() if has_bc else None, backcast.data_ptr() if has_bc else None,
-                scratch.data_ptr(), gradpart.data_ptr(), nsplit, B, N, W, multi, st), "igft_heads_bwd")
-            _lib.check(lib.stemgnn_spectral_glu_bwd(
-                packed[s].data_ptr(), saved[s].data_ptr(), scratch.data_ptr(), gradpart.data_ptr(), nsplit,
-                B, N, W, multi, st), "spectral_glu_bwd")
-            _lib.check(lib.stemgnn_gft_bwd(
-                mul_L.data_ptr(), X.data_ptr(), sb, sn, stt, dG.data_ptr(),
-                dbackcast.data_ptr() if s == 1 else None, dmul_L.data_ptr(), int(s == 0), B, N, W, st), "gft_bwd")
             for i, p in enumerate(blocks[s]):
-                if p is None or (not has_bc and i in (7, 8)):   # block 1's short-cut is unused (:73-74) -> grad None
+                if p is None or (s == 1 and i in (7, 8)):   # block 1's short-cut is unused (:73-74) -> grad None
                     continue
                 if _DIRECT_GRAD and p.grad is not None and p.grad.is_contiguous():
                     grads[s][i] = p.grad          # written in place by the unpack kernel
                     direct_idx.add((s, i))
                 else:
                     grads[s][i] = torch.empty_like(p)
-            _lib.check(lib.stemgnn_block_unpack_grads(
-                gradpart.data_ptr(), nsplit, tables.data_ptr(), _lib.ptr_array(grads[s]), W, multi, int(has_bc), st),
-                "block_unpack_grads")
+        # The weight-gradient GEMMs + un-packing feed nothing downstream in the backward pass.  When every block
+        # gradient is written in place (direct-grad mode) they run on a side stream, overlapping the rest of the
+        # chain -- in particular the latency-bound GRU recurrence, which leaves half of the CUs idle; whoever
+        # consumes the gradients (optimizer / all-reduce, or GruFront.backward at the latest) joins the stream.
+        n_block_grads = sum(g is not None for blk in grads for g in blk)
+        overlap = _OVERLAP_WGRAD and len(direct_idx) == n_block_grads
+        side = _side_stream(dev) if overlap else None
+        main = torch.cuda.current_stream()
+        keep = []
+        # one scratch / partial buffer for both blocks (a second set would push the backward working set past the
+        # 256 MB Infinity Cache and cost more than the overlap gains): block 1 runs in order, only block 0 -- the last
+        # one, whose weight gradients can hide under cheb/attention/GRU backward -- is forked to the side stream
+        scratch = torch.empty(n_scratch, device=dev, dtype=f32)
+        gradpart = torch.empty(n_gradpart, device=dev, dtype=f32)
+        for s in (1, 0):
+            dG = scratch[off_dG:]
+            parr = _lib.ptr_array(blocks[s])
+            X, sb, sn, stt = xviews[s]
+            has_bc = s == 0
+            garr = _lib.ptr_array(grads[s])
+
+            def heads(parts, stream):
+                _lib.check(lib.stemgnn_igft_heads_bwd(
+                    parr, packed[s].data_ptr(), saved[s].data_ptr(), X.data_ptr(), sb, sn, stt, dfsum.data_ptr(),
+                    dbackcast.data_ptr() if has_bc else None, backcast.data_ptr() if has_bc else None,
+                    scratch.data_ptr(), gradpart.data_ptr(), nsplit, parts, B, N, W, multi, stream), "igft_heads_bwd")
+
+            def glu(parts, stream):
+                _lib.check(lib.stemgnn_spectral_glu_bwd(
+                    packed[s].data_ptr(), saved[s].data_ptr(), scratch.data_ptr(), gradpart.data_ptr(), nsplit, parts,
+                    B, N, W, multi, stream), "spectral_glu_bwd")
+
+            def unpack(stream):
+                _lib.check(lib.stemgnn_block_unpack_grads(
+                    gradpart.data_ptr(), nsplit, tables.data_ptr(), garr, W, multi, int(has_bc), stream),
+                    "block_unpack_grads")
+
+            if overlap and s == 0:
+                heads(1, st)
+                glu(1, st)
+                side.wait_stream(main)                       # fork: the data-gradient chain of this block is queued
+                with torch.cuda.stream(side):
+                    sst = side.cuda_stream
+                    heads(2, sst)
+                    glu(2, sst)
+                    unpack(sst)
+                keep.append((scratch, gradpart))            # alive until the join
+            else:
+                heads(3, st)
+                glu(3, st)
+                unpack(st)
+            _lib.check(lib.stemgnn_gft_bwd(
+                mul_L.data_ptr(), X.data_ptr(), sb, sn, stt, dG.data_ptr(),
+                dbackcast.data_ptr() if s == 1 else None, dmul_L.data_ptr(), int(s == 0), B, N, W, st), "gft_bwd")
+        if overlap:
+            _pending_join[str(dev)] = (side, keep, (packed, saved, backcast, dfsum, dbackcast))
         dL = torch.empty(N, N, device=dev, dtype=f32)
         cheb_scratch = torch.empty(2 * N * N, device=dev, dtype=f32)
         _lib.check(lib.stemgnn_cheb_bwd(mul_L.data_ptr(), dmul_L.data_ptr(), dL.data_ptr(), cheb_scratch.data_ptr(),

@@ -47,6 +47,8 @@ class FusedRMSprop(torch.optim.Optimizer):
         if float(group["lr"]) != self._lr_host:            # an LR scheduler changed it (host side, between replays)
             self._lr_host = float(group["lr"])
             self._lr_dev.fill_(self._lr_host)
+        from .ops import join_side_streams
+        join_side_streams(self.flat_p.device)
         lib = _lib.load()
         _lib.check(lib.stemgnn_rmsprop_step(
             self.flat_p.data_ptr(), self.bucket.flat.data_ptr(), self.square_avg.data_ptr(), self.numel,

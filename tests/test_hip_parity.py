@@ -220,8 +220,10 @@ def test_checkpoint_interchange_and_pickle():
     assert list(model.state_dict().keys()) == list(sd.keys())
 
 
-def test_direct_grad_mode_matches_autograd_accumulation():
-    """ops.set_direct_grad(True): backward writes straight into pre-existing .grad buffers (flat bucket views)."""
+@pytest.mark.parametrize("overlap", [False, True])
+def test_direct_grad_mode_matches_autograd_accumulation(overlap):
+    """ops.set_direct_grad(True): backward writes straight into pre-existing .grad buffers (flat bucket views);
+    overlap=True also runs the weight-gradient GEMMs on a side stream (joined by the consumers)."""
     from stemgnn_amd import ops
     from stemgnn_amd.distributed import FlatGradBucket
 
@@ -231,12 +233,13 @@ def test_direct_grad_mode_matches_autograd_accumulation():
     x, y = torch.randn(B, W, N), torch.randn(B, H, N)
     model = _hip_model(N, W, multi, H, sd, p=0.0, train=True)
     bucket = FlatGradBucket(model.parameters())
-    ops.set_direct_grad(True)
+    ops.set_direct_grad(True, overlap=overlap)
     try:
         for _ in range(2):                       # second pass must overwrite, not accumulate
             bucket.zero()
             forecast, _ = model(x.cuda())
             torch.nn.functional.mse_loss(forecast, y.cuda()).backward()
+            ops.join_side_streams()
         torch.cuda.synchronize()
     finally:
         ops.set_direct_grad(False)
@@ -247,3 +250,44 @@ def test_direct_grad_mode_matches_autograd_accumulation():
             assert float(view.abs().max()) == 0.0, k
         else:
             assert relerr(view, o_grads[k]) < TOL, k
+
+
+@pytest.mark.parametrize("stack_i", [0, 1])
+def test_stock_block_layer_standalone(stack_i):
+    """StockBlockLayer(...).forward(x[B,1,N,W], mul_L) -> (forecast, backcast | None): reference :61-75."""
+    from stemgnn_amd import StockBlockLayer
+
+    N, W, multi, B = 21, 12, 5, 4
+    sd = O.det_state_dict(N, W, multi, 3, seed=11)
+    blk = StockBlockLayer(W, N, multi, stack_cnt=stack_i)
+    pre = f"stock_block.{stack_i}."
+    blk.load_state_dict({k[len(pre):]: v for k, v in sd.items() if k.startswith(pre)})
+    blk.cuda()
+    torch.manual_seed(4)
+    X = torch.randn(B, 1, N, W, requires_grad=True)
+    A = torch.rand(N, N)
+    L = torch.eye(N) - 0.5 * (A + A.T) / N
+    mul_L = O.cheb_polynomial(L).requires_grad_(True)
+    leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    o_f, o_b = O.stock_block(X, mul_L, leaves, stack_i)
+    wf, wb = torch.randn_like(o_f), (torch.randn_like(o_b) if o_b is not None else None)
+    loss = (o_f * wf).sum() + ((o_b * wb).sum() if o_b is not None else 0.0)
+    loss.backward()
+    Xg = X.detach().clone().cuda().requires_grad_(True)
+    Lg = mul_L.detach().clone().cuda().requires_grad_(True)
+    f, bc = blk(Xg, Lg)
+    assert (bc is None) == (o_b is None)
+    assert relerr(f, o_f.detach()) < TOL
+    l2 = (f * wf.cuda()).sum()
+    if bc is not None:
+        assert bc.shape == o_b.shape and relerr(bc, o_b.detach()) < TOL
+        l2 = l2 + (bc * wb.cuda()).sum()
+    l2.backward()
+    assert relerr(Xg.grad, X.grad) < TOL
+    assert relerr(Lg.grad[1:], mul_L.grad[1:]) < TOL
+    for k, p in blk.named_parameters():
+        og = leaves[pre + k].grad
+        if og is None:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+        else:
+            assert relerr(p.grad, og) < TOL, k
