@@ -89,7 +89,9 @@ int stemgnn_eigh_fwd(float* mul_L, float* lam, float* U, float* scratch, int N, 
 /* ---- GRU front (models/base_model.py:92,137: nn.GRU(time_step, units) over the node axis) ------------
  * seq_len S (= N nodes), batch B, input size W, hidden size Hd (= N).  PyTorch gate order (r,z,n).
  * x [B,W,S] is the model input read in place (x_s[b,t] = x[b,t,s]); w_ih [3Hd,W], w_hh [3Hd,Hd],
- * b_ih, b_hh [3Hd]; h_all [S,B,Hd] is exactly nn.GRU's output; reserve keeps r,z,n,gh_n for backward.
+ * b_ih, b_hh [3Hd]; h_ext [S+1,B,Hd]: slab 0 is set to zero (h_{-1}) and slabs 1..S are exactly nn.GRU's output
+ * (so h_ext + B*Hd is the [S,B,Hd] tensor, and h_ext itself is "h of the previous step" row for row -- the
+ * operand of the dW_hh GEMM); reserve keeps r,z,n,gh_n for backward.
  * Recurrence: P = 1..8 persistent workgroups per batch row keep their slice of w_hh resident in registers
  * for all S steps and exchange h (forward) / the gate gradients (backward) once per step through tagged
  * 8-byte granules (bounded spins; a timeout sets *status = 1, a device int the caller owns and zeroes);
@@ -98,10 +100,10 @@ size_t stemgnn_gru_reserve_floats(int B, int S, int Hd);
 size_t stemgnn_gru_fwd_scratch_floats(int B, int S, int Hd);
 size_t stemgnn_gru_bwd_scratch_floats(int B, int S, int Hd, int W);
 int stemgnn_gru_fwd(const float* x, const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh,
-                    int B, int S, int Hd, int W, float* scratch, float* h_all, float* reserve, int* status,
+                    int B, int S, int Hd, int W, float* scratch, float* h_ext, float* reserve, int* status,
                     void* stream);
 /* dh_all [S,B,Hd] = gradient of every output step -> dw_ih, dw_hh, db_ih, db_hh (x gets no gradient). */
-int stemgnn_gru_bwd(const float* dh_all, const float* x, const float* w_hh, const float* h_all,
+int stemgnn_gru_bwd(const float* dh_all, const float* x, const float* w_hh, const float* h_ext,
                     const float* reserve, int B, int S, int Hd, int W, float* scratch,
                     float* dw_ih, float* dw_hh, float* db_ih, float* db_hh, int* status, void* stream);
 

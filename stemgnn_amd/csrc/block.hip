@@ -194,18 +194,7 @@ struct GluPlainEpi {   // C (+)= acc, row-major
   }
 };
 
-struct GluWgradEpi {   // split-K slab: part[r][s][q][kin | bias]
-  float* part[2];
-  __device__ void tile(int r, int s, int row0, int col0, int M, int N, const sg_f32x16& acc, int lane) const {
-    const int c = col0 + (lane & 31);
-    if (c >= N) return;
-#pragma unroll
-    for (int reg = 0; reg < 16; ++reg) {
-      const int row = row0 + g2_row_of(reg, lane);
-      if (row < M) part[r][((size_t)s * M + row) * N + c] = acc[reg];
-    }
-  }
-};
+typedef G2SlabEpi GluWgradEpi;   // split-K slab: part[r][s][q][kin | bias]
 
 // =================================================================================================
 // IGFT (C2R iDFT folded into the graph-conv weight) and the heads
@@ -533,13 +522,13 @@ extern "C" int stemgnn_igft_heads_fwd(const float* const* params_host, const flo
     IgftOp op;
     for (int r = 0; r < 2; ++r) { op.a3[r] = saved + S.out[r][2]; op.cp2[r] = d.CP2[r]; }
     op.wfold = packed + P.wfold; op.ig = saved + S.ig; op.M = d.M; op.Wm = d.Wm; op.WmP = d.WmP;
-    SG_TRY((sg_launch_gemm<IgftOp, 64, 64, true, false, false>(op, d.M, d.Wm, 1, st)));
+    SG_TRY((sg_launch_gemm<IgftOp, 32, 64, true, false, false, 64>(op, d.M, d.Wm, 1, st)));
   }
   {
     Head1Op op{saved + S.ig, XView{X, xs_b, xs_n, xs_t, N},
                params_host[1], params_host[2], params_host[5], params_host[6], params_host[7], params_host[8],
                saved + S.fs, backcast, d.M, W, d.Wm, has_bc};
-    SG_TRY((sg_launch_gemm<Head1Op, 64, 64, true, true, false>(op, d.M, d.Wm + (has_bc ? W : 0), 1, st)));
+    SG_TRY((sg_launch_gemm<Head1Op, 32, 64, true, true, false, 64>(op, d.M, d.Wm + (has_bc ? W : 0), 1, st)));
   }
   {
     Head2Op op{saved + S.fs, params_host[3], params_host[4], forecast, d.M, W, d.Wm, accumulate};
@@ -575,11 +564,11 @@ extern "C" int stemgnn_igft_heads_bwd(const float* const* params_host, const flo
   }
   if (parts & 1) {
     Head2BwdOp op{dforecast, params_host[3], saved + S.fs, dpF, d.M, W, d.Wm};
-    SG_TRY((sg_launch_gemm<Head2BwdOp, 64, 64, true, false, false>(op, d.M, d.Wm, 1, st)));
+    SG_TRY((sg_launch_gemm<Head2BwdOp, 32, 64, true, false, false>(op, d.M, d.Wm, 1, st)));
   }
   if (parts & 1) {
     DigOp op{dpF, dpB, params_host[1], params_host[5], dig, d.M, W, d.Wm, has_bc};
-    SG_TRY((sg_launch_gemm<DigOp, 64, 64, true, false, false>(op, d.M, d.Wm, 1, st)));
+    SG_TRY((sg_launch_gemm<DigOp, 32, 64, true, false, false, 64>(op, d.M, d.Wm, 1, st)));
   }
   if (parts & 1) {
     Da3Op op;
@@ -592,7 +581,7 @@ extern "C" int stemgnn_igft_heads_bwd(const float* const* params_host, const flo
     }
     op.M = d.M; op.Wm = d.Wm; op.WmP = d.WmP;
     const int maxN = d.CP2[0] > d.CP2[1] ? d.CP2[0] : d.CP2[1];
-    SG_TRY((sg_launch_gemm<Da3Op, 64, 64, true, true, false>(op, d.M, maxN, 2, st)));
+    SG_TRY((sg_launch_gemm<Da3Op, 32, 64, true, true, false, 64>(op, d.M, maxN, 2, st)));
   }
   if (parts & 2) {
     HeadsWgradOp op;

@@ -167,6 +167,20 @@ __global__ __launch_bounds__(256) void sg_gemm2(const G2Args g, const Epi epi) {
       epi.tile(r, s, m0 + wm * 64 + i * 32, n0 + wn * 64 + j * 32, M, N, acc[i][j], lane);
 }
 
+// split-K slab epilogue: part[r][s][row][col]  (one slab per split, reduced later in a fixed order)
+struct G2SlabEpi {
+  float* part[2];
+  __device__ void tile(int r, int s, int row0, int col0, int M, int N, const sg_f32x16& acc, int lane) const {
+    const int c = col0 + (lane & 31);
+    if (c >= N) return;
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      const int row = row0 + g2_row_of(reg, lane);
+      if (row < M) part[r][((size_t)s * M + row) * N + c] = acc[reg];
+    }
+  }
+};
+
 // 16-byte alignment rules of the VEC path
 static inline bool g2_aligned(const void* p, int ld) { return (((uintptr_t)p) & 15) == 0 && (ld & 3) == 0; }
 

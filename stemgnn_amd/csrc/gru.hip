@@ -17,6 +17,7 @@
 #include <hip/hip_runtime.h>
 
 #include "../../include/stemgnn_hip.h"
+#include "gemm2.h"
 #include "gemm_core.h"
 
 #define SG_TRY(e)                                \
@@ -651,12 +652,14 @@ extern "C" size_t stemgnn_gru_bwd_scratch_floats(int B, int S, int Hd, int W) {
 }
 
 extern "C" int stemgnn_gru_fwd(const float* x, const float* w_ih, const float* w_hh, const float* b_ih,
-                               const float* b_hh, int B, int S, int Hd, int W, float* scratch, float* h_all,
+                               const float* b_hh, int B, int S, int Hd, int W, float* scratch, float* h_ext,
                                float* reserve, int* status, void* stream) {
-  if (!x || !w_ih || !w_hh || !b_ih || !b_hh || !scratch || !h_all || !reserve || !status || B <= 0 || S <= 0 ||
+  if (!x || !w_ih || !w_hh || !b_ih || !b_hh || !scratch || !h_ext || !reserve || !status || B <= 0 || S <= 0 ||
       Hd <= 0 || W <= 0)
     return SG_EINVAL;
   hipStream_t st = (hipStream_t)stream;
+  SG_TRY(hipMemsetAsync(h_ext, 0, (size_t)B * Hd * sizeof(float), st));    // slab 0: h_{-1} = 0
+  float* h_all = h_ext + (size_t)B * Hd;                                  // steps 0..S-1
   float* w_hhT = scratch;
   float* gi = scratch + (size_t)3 * Hd * Hd;
   GruGiOp op{x, w_ih, b_ih, gi, B, S, Hd, W};
@@ -697,13 +700,14 @@ extern "C" int stemgnn_gru_fwd(const float* x, const float* w_ih, const float* w
   return 0;
 }
 
-extern "C" int stemgnn_gru_bwd(const float* dh_all, const float* x, const float* w_hh, const float* h_all,
+extern "C" int stemgnn_gru_bwd(const float* dh_all, const float* x, const float* w_hh, const float* h_ext,
                                const float* reserve, int B, int S, int Hd, int W, float* scratch, float* dw_ih,
                                float* dw_hh, float* db_ih, float* db_hh, int* status, void* stream) {
-  if (!dh_all || !x || !w_hh || !h_all || !reserve || !scratch || !dw_ih || !dw_hh || !db_ih || !db_hh || !status ||
+  if (!dh_all || !x || !w_hh || !h_ext || !reserve || !scratch || !dw_ih || !dw_hh || !db_ih || !db_hh || !status ||
       B <= 0 || S <= 0 || Hd <= 0 || W <= 0)
     return SG_EINVAL;
   hipStream_t st = (hipStream_t)stream;
+  const float* h_all = h_ext + (size_t)B * Hd;
   float* dgi = scratch;
   float* dghn = dgi + (size_t)3 * S * B * Hd;
   float* p_hh = dghn + (size_t)S * B * Hd;
@@ -738,15 +742,30 @@ extern "C" int stemgnn_gru_bwd(const float* dh_all, const float* x, const float*
   }
   const int rows = S * B;
   const int chunk = ((rows + GRU_NSPLIT - 1) / GRU_NSPLIT + 15) & ~15;
-  GruWhhGradOp o1{dgi, dghn, h_all, p_hh, B, S, Hd, GRU_NSPLIT, chunk};
-  SG_TRY((sg_launch_gemm<GruWhhGradOp, 64, 64, false, false, false>(o1, 3 * Hd, Hd + 1, GRU_NSPLIT, st)));
+  {  // dW_hh | db_hh = dgh^T [3Hd x rows] * [h_prev | 1]: rows 0..2Hd-1 of dgh are dgi's r,z gates, rows 2Hd..3Hd-1 = dghn
+     // (two "branches" of one 128x128 MFMA GEMM launch); h_prev of row (s,b) is row (s,b) of h_ext (slab 0 = zeros)
+    G2Args g;
+    G2SlabEpi e;
+    g.A[0] = dgi;  g.lda[0] = 3 * Hd; g.M[0] = 2 * Hd;
+    g.A[1] = dghn; g.lda[1] = Hd;     g.M[1] = Hd;
+    for (int r = 0; r < 2; ++r) { g.B[r] = h_ext; g.ldb[r] = Hd; g.N[r] = Hd + 1; g.K[r] = rows; }
+    g.nsplit = GRU_NSPLIT; g.chunk = chunk; g.b_ones_col = Hd;
+    e.part[0] = p_hh;
+    e.part[1] = p_hh + (size_t)GRU_NSPLIT * 2 * Hd * (Hd + 1);
+    SG_TRY((g2_launch<G2SlabEpi, false, false>(g, e, 2, st)));
+  }
   GruWihGradOp o2{dgi, x, p_ih, B, S, Hd, W, GRU_NSPLIT, chunk};
   SG_TRY((sg_launch_gemm<GruWihGradOp, 64, 32, false, false, false>(o2, 3 * Hd, W + 1, GRU_NSPLIT, st)));
   {
     const size_t n = (size_t)3 * Hd * (Hd + 1);
-    hipLaunchKernelGGL(gru_reduce_grad_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p_hh, GRU_NSPLIT,
-                       3 * Hd, Hd, dw_hh, db_hh);
+    const size_t n0 = (size_t)2 * Hd * (Hd + 1), n1 = (size_t)Hd * (Hd + 1);
+    hipLaunchKernelGGL(gru_reduce_grad_kernel, dim3((unsigned)((n0 + 255) / 256)), dim3(256), 0, st, p_hh, GRU_NSPLIT,
+                       2 * Hd, Hd, dw_hh, db_hh);
     SG_TRY(hipGetLastError());
+    hipLaunchKernelGGL(gru_reduce_grad_kernel, dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, st,
+                       p_hh + (size_t)GRU_NSPLIT * n0, GRU_NSPLIT, Hd, Hd, dw_hh + (size_t)2 * Hd * Hd, db_hh + 2 * Hd);
+    SG_TRY(hipGetLastError());
+    (void)n;
   }
   {
     const size_t n = (size_t)3 * Hd * (W + 1);

@@ -129,22 +129,23 @@ class GruFront(torch.autograd.Function):
         Hd = w_hh.shape[1]
         dev, f32 = x.device, torch.float32
         w_ih, w_hh, b_ih, b_hh = (t.contiguous() for t in (w_ih, w_hh, b_ih, b_hh))
-        h_all = torch.empty(S, B, Hd, device=dev, dtype=f32)
+        h_ext = torch.empty(S + 1, B, Hd, device=dev, dtype=f32)     # slab 0 = h_{-1} = 0 (set by the library)
+        h_all = h_ext[1:]                                             # exactly nn.GRU's output, a contiguous view
         reserve = torch.empty(lib.stemgnn_gru_reserve_floats(B, S, Hd), device=dev, dtype=f32)
         scratch = torch.empty(lib.stemgnn_gru_fwd_scratch_floats(B, S, Hd), device=dev, dtype=f32)
         _lib.check(lib.stemgnn_gru_fwd(x.data_ptr(), w_ih.data_ptr(), w_hh.data_ptr(), b_ih.data_ptr(), b_hh.data_ptr(),
-                                       B, S, Hd, W, scratch.data_ptr(), h_all.data_ptr(), reserve.data_ptr(),
+                                       B, S, Hd, W, scratch.data_ptr(), h_ext.data_ptr(), reserve.data_ptr(),
                                        gru_status(dev).data_ptr(), _stream()), "gru_fwd")
         # save_for_backward (not ctx attributes): h_all is an OUTPUT -- holding it on ctx would form a
         # ctx <-> grad_fn reference cycle that never frees the step's buffers
-        ctx.save_for_backward(x, w_ih, w_hh, h_all, reserve)
+        ctx.save_for_backward(x, w_ih, w_hh, h_ext, reserve)
         ctx.gru_params = gru_params
         return h_all
 
     @staticmethod
     def backward(ctx, dh_all):
         lib = _lib.load()
-        x, w_ih, w_hh, h_all, reserve = ctx.saved_tensors
+        x, w_ih, w_hh, h_ext, reserve = ctx.saved_tensors
         B, W, S = x.shape
         Hd = w_hh.shape[1]
         dev, f32 = x.device, torch.float32
@@ -158,7 +159,7 @@ class GruFront(torch.autograd.Function):
             dw_ih, dw_hh = torch.empty_like(w_ih), torch.empty_like(w_hh)
             db_ih = torch.empty(3 * Hd, device=dev, dtype=f32)
             db_hh = torch.empty(3 * Hd, device=dev, dtype=f32)
-        _lib.check(lib.stemgnn_gru_bwd(dh_all.data_ptr(), x.data_ptr(), w_hh.data_ptr(), h_all.data_ptr(),
+        _lib.check(lib.stemgnn_gru_bwd(dh_all.data_ptr(), x.data_ptr(), w_hh.data_ptr(), h_ext.data_ptr(),
                                        reserve.data_ptr(), B, S, Hd, W, scratch.data_ptr(), dw_ih.data_ptr(),
                                        dw_hh.data_ptr(), db_ih.data_ptr(), db_hh.data_ptr(),
                                        gru_status(dev).data_ptr(), _stream()), "gru_bwd")
