@@ -27,6 +27,7 @@ import torch.distributed as dist  # noqa: E402
 
 WORKLOAD = dict(N=228, W=12, H=3, multi=5, B=32)      # PEMS07 shape, BASELINE.json configs[1]
 FP32_MFMA_PEAK_TFLOPS = 157.3                          # MI355X_MICROARCH.md: v_mfma_f32_* dense peak
+ROOFLINE_TRAFFIC_BYTES = 62.4e6                        # profiles/r01_pmc_fetch_write.md (dominant kernel, per launch)
 
 
 def glu_fwd_flops(B, N, W, multi):
@@ -81,7 +82,8 @@ def try_capture(fn, stream_warmups=3):
 
 
 def time_dominant_kernel(cfg, iters=20):
-    """Average launch duration of the dominant kernel (sg_gemm_f32<GluFwdOp>), HIP events on the launch stream."""
+    """Average launch duration of the dominant roofline kernel (sg_gemm2<GluFwdEpi>: the 3 launches of one
+    stemgnn_spectral_glu_fwd call), HIP events on the launch stream."""
     from stemgnn_amd import _lib
 
     lib = _lib.load()
@@ -257,10 +259,14 @@ def main():
     if rank == 0:
         avg_s, flops = time_dominant_kernel(cfg)
         ach = flops / avg_s / 1e12
-        out["roofline"] = {"kernel": "sg_gemm_f32<GluFwdOp,128,64> (spectral GLU forward GEMM, exact-fp32 MFMA)",
+        out["roofline"] = {"kernel": "sg_gemm2<GluFwdEpi,true,false,true> (spectral GLU forward GEMM, 128x128x16 tiles, "
+                                     "v_mfma_f32_32x32x2_f32, exact fp32)",
                            "bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                            "frac": ach / FP32_MFMA_PEAK_TFLOPS, "avg_launch_us": avg_s * 1e6,
-                           "flops_per_launch": flops, "traffic": None}
+                           "flops_per_launch": flops,
+                           # HBM bytes per launch from the PMC passes in profiles/r01_pmc_fetch_write.md
+                           # (2 x FETCH_SIZE + WRITE_SIZE, gfx950 correction), not re-measured live
+                           "traffic": ROOFLINE_TRAFFIC_BYTES}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg)
         print(json.dumps(out), flush=True)
