@@ -26,6 +26,10 @@ struct G2Args {
   int M[2], N[2], K[2];   // per branch: output M x N, reduction length K
   int nsplit, chunk;      // K range of split s: [s*chunk, min(K, (s+1)*chunk))
   int b_ones_col;         // >= 0: column j of B that reads as 1.0 (bias-gradient trick), data columns are j < b_ones_col
+  // XCD-aware tile order (filled by g2_launch).  The dispatcher places block L on XCD L % 8 (8 private L2s), so tiles
+  // that share an operand panel are given block ids that are equal mod 8: mode 0 groups the ny column tiles of one
+  // (row tile, z) -- they share the A panel; mode 1 groups all nx*ny tiles of one z (split-K slices share A and B).
+  int nx, ny, nz, xcd_mode;
 };
 
 constexpr int G2_BM = 128, G2_BN = 128, G2_BK = 16, G2_LD = 132;
@@ -103,10 +107,22 @@ struct G2Loader {
 template <class Epi, bool A_KC, bool B_KC, bool VEC>
 __global__ __launch_bounds__(256) void sg_gemm2(const G2Args g, const Epi epi) {
   __shared__ __attribute__((aligned(16))) float lds[2 * 2 * G2_BK * G2_LD];
-  const int z = blockIdx.z;
+  int bx, by, z;
+  {
+    const int L = blockIdx.x, c = L & 7, idx = L >> 3;
+    const int gt = g.xcd_mode ? g.nx * g.ny : g.ny;            // tiles per group
+    const int grp = c + 8 * (idx / gt), t = idx % gt;
+    if (g.xcd_mode) {
+      if (grp >= g.nz) return;
+      z = grp; bx = t % g.nx; by = t / g.nx;
+    } else {
+      if (grp >= g.nx * g.nz) return;
+      bx = grp % g.nx; z = grp / g.nx; by = t;
+    }
+  }
   const int r = z / g.nsplit, s = z - r * g.nsplit;
   const int M = g.M[r], N = g.N[r], K = g.K[r];
-  const int m0 = blockIdx.x * G2_BM, n0 = blockIdx.y * G2_BN;
+  const int m0 = bx * G2_BM, n0 = by * G2_BN;
   if (m0 >= M || n0 >= N) return;
   const int K0 = s * g.chunk, K1 = min(K, K0 + g.chunk);
   const float* __restrict__ A = g.A[r];
@@ -185,7 +201,8 @@ struct G2SlabEpi {
 static inline bool g2_aligned(const void* p, int ld) { return (((uintptr_t)p) & 15) == 0 && (ld & 3) == 0; }
 
 template <class Epi, bool A_KC, bool B_KC>
-static inline hipError_t g2_launch(const G2Args& g, const Epi& epi, int nbranch, hipStream_t st) {
+static inline hipError_t g2_launch(const G2Args& g_in, const Epi& epi, int nbranch, hipStream_t st) {
+  G2Args g = g_in;
   int maxM = 0, maxN = 0;
   bool vec = true;
   for (int r = 0; r < nbranch; ++r) {
@@ -196,8 +213,14 @@ static inline hipError_t g2_launch(const G2Args& g, const Epi& epi, int nbranch,
     if (!A_KC) vec = vec && (g.M[r] & 3) == 0;
     if (!B_KC) vec = vec && (((g.b_ones_col >= 0 ? g.b_ones_col : g.N[r]) & 3) == 0);
   }
-  dim3 grid((maxM + G2_BM - 1) / G2_BM, (maxN + G2_BN - 1) / G2_BN, nbranch * g.nsplit);
-  if (grid.x == 0 || grid.y == 0 || grid.z == 0) return hipSuccess;
+  g.nx = (maxM + G2_BM - 1) / G2_BM;
+  g.ny = (maxN + G2_BN - 1) / G2_BN;
+  g.nz = nbranch * g.nsplit;
+  if (g.nx == 0 || g.ny == 0 || g.nz == 0) return hipSuccess;
+  g.xcd_mode = g.nsplit > 1 ? 1 : 0;
+  const int ngroups = g.xcd_mode ? g.nz : g.nx * g.nz;
+  const int gt = g.xcd_mode ? g.nx * g.ny : g.ny;
+  dim3 grid(8 * ((ngroups + 7) / 8) * gt);
   if (vec) hipLaunchKernelGGL((sg_gemm2<Epi, A_KC, B_KC, true>), grid, dim3(256), 0, st, g, epi);
   else hipLaunchKernelGGL((sg_gemm2<Epi, A_KC, B_KC, false>), grid, dim3(256), 0, st, g, epi);
   return hipGetLastError();
