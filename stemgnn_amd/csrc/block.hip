@@ -403,8 +403,8 @@ extern "C" int stemgnn_gft_fwd(const float* mul_L, const float* X, long xs_b, lo
   if (!mul_L || !X || !G || B <= 0 || N <= 0 || W <= 0) return SG_EINVAL;
   GftFwdOp op{mul_L + (size_t)N * N, XView{X, xs_b, xs_n, xs_t, N}, G, B, N, W};
   hipStream_t st = (hipStream_t)stream;
-  if (xs_n == 1) SG_TRY((sg_launch_gemm<GftFwdOp, 32, 64, true, true, false, 64>(op, 3 * N, B * W, 1, st)));
-  else SG_TRY((sg_launch_gemm<GftFwdOp, 32, 64, true, false, false, 64>(op, 3 * N, B * W, 1, st)));
+  if (xs_n == 1) SG_TRY((sg_launch_gemm<GftFwdOp, 32, 64, true, true, false, 64, true>(op, 3 * N, B * W, 1, st)));
+  else SG_TRY((sg_launch_gemm<GftFwdOp, 32, 64, true, false, false, 64, true>(op, 3 * N, B * W, 1, st)));
   return 0;
 }
 
@@ -415,11 +415,11 @@ extern "C" int stemgnn_gft_bwd(const float* mul_L, const float* X, long xs_b, lo
   hipStream_t st = (hipStream_t)stream;
   if (dX) {
     GftBwdDxOp op{mul_L + (size_t)N * N, dG, dX, B, N, W};
-    SG_TRY((sg_launch_gemm<GftBwdDxOp, 32, 32, false, false, false, 64>(op, N, B * W, 1, st)));
+    SG_TRY((sg_launch_gemm<GftBwdDxOp, 32, 32, false, false, false, 64, true>(op, N, B * W, 1, st)));
   }
   GftBwdDtOp op{dG, XView{X, xs_b, xs_n, xs_t, N}, dmul_L + (size_t)N * N, B, N, W, accumulate};
-  if (xs_t == 1) SG_TRY((sg_launch_gemm<GftBwdDtOp, 32, 32, true, true, false, 64>(op, 3 * N, N, 1, st)));
-  else SG_TRY((sg_launch_gemm<GftBwdDtOp, 32, 32, true, false, false, 64>(op, 3 * N, N, 1, st)));
+  if (xs_t == 1) SG_TRY((sg_launch_gemm<GftBwdDtOp, 32, 32, true, true, false, 64, true>(op, 3 * N, N, 1, st)));
+  else SG_TRY((sg_launch_gemm<GftBwdDtOp, 32, 32, true, false, false, 64, true>(op, 3 * N, N, 1, st)));
   return 0;
 }
 

@@ -168,24 +168,31 @@ __global__ __launch_bounds__(256) void sg_laplacian_fwd_kernel(const float* __re
 
 // ---- backward -----------------------------------------------------------------------------------------
 // Laplacian backward: one wave per row i.  dAB = dA / B.
+// with_degree == 0 (no dropout): the degree path adds a ROW-CONSTANT dd_i to dA[i][:], which the softmax backward
+// annihilates exactly (sum_j p_j = 1); adding it in fp32 only injects eps*|dd_i| noise into a difference of O(1/N)
+// terms (at N=2048 that noise is the whole 1e-4 budget of d weight_key/query), so it is dropped.  With dropout the
+// mask makes the term non-constant and it is kept.
 __global__ __launch_bounds__(256) void sg_laplacian_bwd_kernel(const float* __restrict__ dL, const float* __restrict__ A,
                                                                const float* __restrict__ deg, float* __restrict__ dAB,
-                                                               int B, int N) {
+                                                               int B, int N, int with_degree) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = blockIdx.x * 4 + wave;
   if (i >= N) return;
   const float di = deg[i];
   const float sq = sqrtf(di);
   const float dhi = 1.f / (sq + 1e-7f);
-  float ddh = 0.f;
-  for (int j = lane; j < N; j += 64) {
-    const float s = 0.5f * (A[(size_t)i * N + j] + A[(size_t)j * N + i]);
-    const float qv = (i == j ? di : 0.f) - s;
-    const float dhj = 1.f / (sqrtf(deg[j]) + 1e-7f);
-    ddh += (dL[(size_t)i * N + j] + dL[(size_t)j * N + i]) * qv * dhj;
+  float dd = 0.f;
+  if (with_degree) {
+    float ddh = 0.f;
+    for (int j = lane; j < N; j += 64) {
+      const float s = 0.5f * (A[(size_t)i * N + j] + A[(size_t)j * N + i]);
+      const float qv = (i == j ? di : 0.f) - s;
+      const float dhj = 1.f / (sqrtf(deg[j]) + 1e-7f);
+      ddh += (dL[(size_t)i * N + j] + dL[(size_t)j * N + i]) * qv * dhj;
+    }
+    ddh = sg_wave_sum(ddh);
+    dd = -ddh * dhi * dhi / (2.f * sq) + dL[(size_t)i * N + i] * dhi * dhi;
   }
-  ddh = sg_wave_sum(ddh);
-  const float dd = -ddh * dhi * dhi / (2.f * sq) + dL[(size_t)i * N + i] * dhi * dhi;
   const float invB = 1.f / (float)B;
   for (int j = lane; j < N; j += 64) {
     const float dhj = 1.f / (sqrtf(deg[j]) + 1e-7f);
@@ -412,7 +419,8 @@ extern "C" int stemgnn_attn_laplacian_bwd(const float* dL, const float* h, const
   float* dkey = dAB + (size_t)N * N;
   float* dquery = dkey + (size_t)B * N;
   float* dqpart = dquery + (size_t)B * N;
-  hipLaunchKernelGGL(sg_laplacian_bwd_kernel, dim3((N + 3) / 4), dim3(256), 0, st, dL, A, deg, dAB, B, N);
+  hipLaunchKernelGGL(sg_laplacian_bwd_kernel, dim3((N + 3) / 4), dim3(256), 0, st, dL, A, deg, dAB, B, N,
+                     (training && drop_p > 0.f) ? 1 : 0);
   SG_TRY(hipGetLastError());
   const size_t lds = (size_t)(4 * N) * sizeof(float);
   if (lds > 150 * 1024) return SG_EINVAL;
@@ -443,9 +451,9 @@ extern "C" int stemgnn_cheb_fwd(float* mul_L, int N, void* stream) {
   const size_t nn = (size_t)N * N;
   float* L = mul_L + nn;
   ChebFwdOp op2{L, L, mul_L + 2 * nn, N, 0};
-  SG_TRY((sg_launch_gemm<ChebFwdOp, 32, 32, true, false, false, 64>(op2, N, N, 1, st)));
+  SG_TRY((sg_launch_gemm<ChebFwdOp, 32, 32, true, false, false, 64, true>(op2, N, N, 1, st)));
   ChebFwdOp op3{L, mul_L + 2 * nn, mul_L + 3 * nn, N, 1};
-  SG_TRY((sg_launch_gemm<ChebFwdOp, 32, 32, true, false, false, 64>(op3, N, N, 1, st)));
+  SG_TRY((sg_launch_gemm<ChebFwdOp, 32, 32, true, false, false, 64, true>(op3, N, N, 1, st)));
   return 0;
 }
 
@@ -457,8 +465,8 @@ extern "C" int stemgnn_cheb_bwd(const float* mul_L, const float* dmul_L, float* 
   float* dLp = scratch;
   float* dT2p = scratch + nn;
   ChebBwd1Op op1{mul_L + nn, mul_L + 2 * nn, dmul_L + nn, dmul_L + 2 * nn, dmul_L + 3 * nn, dLp, dT2p, N};
-  SG_TRY((sg_launch_gemm<ChebBwd1Op, 32, 32, true, true, false, 64>(op1, N, N, 2, st)));
+  SG_TRY((sg_launch_gemm<ChebBwd1Op, 32, 32, true, true, false, 64, true>(op1, N, N, 2, st)));
   ChebBwd2Op op2{mul_L + nn, dT2p, dLp, dL, N};
-  SG_TRY((sg_launch_gemm<ChebBwd2Op, 32, 32, true, true, false, 64>(op2, N, N, 1, st)));
+  SG_TRY((sg_launch_gemm<ChebBwd2Op, 32, 32, true, true, false, 64, true>(op2, N, N, 1, st)));
   return 0;
 }

@@ -19,7 +19,10 @@
 
 typedef float sg_f32x4 __attribute__((ext_vector_type(4)));
 
-template <class Op, int BM, int BN, bool A_KFAST, bool B_KFAST, bool PAIR, int BK = 16>
+// TWO_LEVEL: the MFMA accumulator chain is flushed into a second accumulator after every K tile, so the fp32
+// summation error grows with sqrt(BK) + sqrt(K/BK) terms instead of with the whole chain length K (matters for the
+// N x N x N graph products at N >= 1024, whose results feed the ill-conditioned softmax backward).
+template <class Op, int BM, int BN, bool A_KFAST, bool B_KFAST, bool PAIR, int BK = 16, bool TWO_LEVEL = false>
 __global__ __launch_bounds__(256) void sg_gemm_f32(const Op op) {
   static_assert(BK % 16 == 0, "BK");
   constexpr int TM = BM / 32;           // 16x16 tiles per wave along M
@@ -53,6 +56,13 @@ __global__ __launch_bounds__(256) void sg_gemm_f32(const Op op) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) acc[i][j] = (sg_f32x4){0.f, 0.f, 0.f, 0.f};
 
+  sg_f32x4 acc2[TWO_LEVEL ? TM : 1][TWO_LEVEL ? TN : 1];
+  if constexpr (TWO_LEVEL) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc2[i][j] = (sg_f32x4){0.f, 0.f, 0.f, 0.f};
+  }
   float ra[RA], rb[RB];
 
   auto gload = [&](int kbase) {
@@ -115,7 +125,22 @@ __global__ __launch_bounds__(256) void sg_gemm_f32(const Op op) {
         for (int j = 0; j < TN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[j], acc[i][j], 0, 0, 0);
     }
+    if constexpr (TWO_LEVEL) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          acc2[i][j] += acc[i][j];
+          acc[i][j] = (sg_f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    }
     __syncthreads();
+  }
+  if constexpr (TWO_LEVEL) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[i][j] = acc2[i][j];
   }
 
   // epilogue: D layout of 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg
@@ -143,10 +168,10 @@ __global__ __launch_bounds__(256) void sg_gemm_f32(const Op op) {
   }
 }
 
-template <class Op, int BM, int BN, bool A_KFAST, bool B_KFAST, bool PAIR, int BK = 16>
+template <class Op, int BM, int BN, bool A_KFAST, bool B_KFAST, bool PAIR, int BK = 16, bool TWO_LEVEL = false>
 static inline hipError_t sg_launch_gemm(const Op& op, int maxM, int maxN, int nz, hipStream_t stream) {
   dim3 grid((maxM + BM - 1) / BM, (maxN + BN - 1) / BN, nz);
   if (grid.x == 0 || grid.y == 0 || grid.z == 0) return hipSuccess;
-  hipLaunchKernelGGL((sg_gemm_f32<Op, BM, BN, A_KFAST, B_KFAST, PAIR, BK>), grid, dim3(256), 0, stream, op);
+  hipLaunchKernelGGL((sg_gemm_f32<Op, BM, BN, A_KFAST, B_KFAST, PAIR, BK, TWO_LEVEL>), grid, dim3(256), 0, stream, op);
   return hipGetLastError();
 }
