@@ -6,7 +6,9 @@
 A "step" is one optimizer step of the drop-in model on one synthetic PEMS07-shaped batch
 (N=228, W=12, H=3, multi=5, per-GPU batch 32 -- BASELINE.json configs[1]): zero_grad -> forward ->
 MSELoss -> backward -> (flat grad all-reduce over RCCL when N>1) -> RMSprop(lr=1e-4, eps=1e-8) step,
-exactly the reference's loop body (models/handler.py:157-165), with the batch already resident in HBM.
+exactly the reference's loop body (models/handler.py:157-165); the z-scored series is resident in HBM and the
+batch windows are gathered from it by index inside the step (stemgnn_amd.engine.TrainStep, the same object
+stemgnn_amd.handler.train drives).
 Weak scaling: every rank trains on its own 32-sample batch ("replicas with a local graph").
 
 Rank 0 prints ONE JSON line with the throughput, a `roofline` object for the dominant kernel
@@ -35,50 +37,6 @@ def glu_fwd_flops(B, N, W, multi):
     of SURVEY 8d: 2*M*(C0*2C + 2C*C + 2C*C) per branch with C0 = 4W, C = 4*W*multi."""
     M, C0, C = B * N, 4 * W, 4 * W * multi
     return 2 * (2.0 * M * (C0 * 2 * C + C * 2 * C + C * 2 * C))
-
-
-def build_step(model, opt, bucket, x, y, world):
-    loss_fn = torch.nn.MSELoss(reduction="mean")
-    loss_buf = torch.zeros((), device=x.device)
-
-    fused_zero = getattr(opt, "fuse_zero_grad", False)
-
-    def fwd_bwd():
-        if not fused_zero:
-            bucket.zero()                   # FusedRMSprop clears the gradients inside its step kernel
-        forecast, _ = model(x)
-        loss = loss_fn(forecast, y)
-        loss.backward()
-        loss_buf.copy_(loss.detach())
-
-    def sync_grads():
-        bucket.all_reduce_mean()
-
-    def opt_step():
-        opt.step()
-
-    return fwd_bwd, sync_grads, opt_step, loss_buf
-
-
-def try_capture(fn, stream_warmups=3):
-    """Capture fn into a hipGraph (torch.cuda.CUDAGraph); returns a replay callable or None."""
-    try:
-        s = torch.cuda.Stream()
-        s.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(s):
-            for _ in range(stream_warmups):
-                fn()
-        torch.cuda.current_stream().wait_stream(s)
-        torch.cuda.synchronize()
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            fn()
-        torch.cuda.synchronize()
-        return g.replay
-    except Exception as e:  # noqa: BLE001
-        print(f"[bench] graph capture unavailable ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
-        torch.cuda.synchronize()
-        return None
 
 
 def time_dominant_kernel(cfg, iters=20):
@@ -172,59 +130,42 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    from stemgnn_amd import Model, ops
-    from stemgnn_amd.distributed import FlatGradBucket, broadcast_parameters
-
-    # gradients are written in place into the flat bucket (overwrite == accumulate after the fused zeroing), and the
-    # weight-gradient GEMMs of the spectral blocks overlap the GRU recurrence on a side stream
-    ops.set_direct_grad(True, overlap=True)
+    from stemgnn_amd import Model
+    from stemgnn_amd.distributed import broadcast_parameters
+    from stemgnn_amd.engine import TrainStep
+    from stemgnn_amd.optim import FusedRMSprop
 
     cfg = dict(WORKLOAD)
     torch.manual_seed(0)
     model = Model(cfg["N"], 2, cfg["W"], cfg["multi"], horizon=cfg["H"])      # defaults: dropout 0.5, leaky 0.2
     model.to(dev).train()
     broadcast_parameters(model)
-    bucket = FlatGradBucket(model.parameters())
-    if os.environ.get("STEMGNN_TORCH_OPT", "0") == "1":     # A/B: the library optimizer the reference driver uses
-        opt = torch.optim.RMSprop(model.parameters(), lr=1e-4, eps=1e-8, capturable=True, foreach=True)
-    else:                                                    # same arithmetic, one fused kernel (+ grad zeroing)
-        from stemgnn_amd.optim import FusedRMSprop
-        opt = FusedRMSprop(model.parameters(), lr=1e-4, alpha=0.99, eps=1e-8, bucket=bucket)
+    # same arithmetic as the driver's torch.optim.RMSprop (handler.py:127), one fused kernel (+ grad zeroing)
+    opt = FusedRMSprop(model.parameters(), lr=1e-4, alpha=0.99, eps=1e-8)
+    # synthetic z-scored series resident in HBM (PEMS07 length), windows gathered by index inside the step
+    T = 12672
     g = torch.Generator().manual_seed(1234 + rank)
-    x = torch.randn(cfg["B"], cfg["W"], cfg["N"], generator=g).to(dev)
-    y = torch.randn(cfg["B"], cfg["H"], cfg["N"], generator=g).to(dev)
+    series = torch.randn(T, cfg["N"], generator=g).to(dev)
+    n_windows = T - cfg["W"] - cfg["H"] + 1
+    total = args.steps + args.warmup + 1
+    epochs = -(-total * cfg["B"] // n_windows)                       # shuffled passes over the windows, back to back
+    order = torch.cat([torch.randperm(n_windows, generator=g) for _ in range(epochs)])[: total * cfg["B"]]
+    hi_all = (order + cfg["W"]).to(dev).view(total, cfg["B"])        # window-end rows (ForecastDataset.x_end_idx)
 
-    fwd_bwd, sync_grads, opt_step, loss_buf = build_step(model, opt, bucket, x, y, world)
-    # one eager step first (lazy init of tables, seed, RMSprop state)
-    fwd_bwd(); sync_grads(); opt_step()
+    # TrainStep = the driver's loop body (stemgnn_amd/handler.py train): window gather -> zero_grad -> forward ->
+    # MSE -> backward (gradients written in place into the flat bucket, block weight-gradient GEMMs overlapping the
+    # GRU recurrence on a side stream) -> [RCCL all-reduce] -> RMSprop; captured into hipGraph(s) after the first step
+    stepper = TrainStep(model, opt, cfg["B"], cfg["W"], cfg["H"], cfg["N"], series=series, world=world,
+                        graph=not args.no_graph)
+    stepper.run_indices(hi_all[0])          # eager step (lazy init of tables, seed, state) + graph capture
     torch.cuda.synchronize()
-    mode = "eager"
-    if not args.no_graph:
-        if world == 1:
-            def whole():
-                fwd_bwd(); opt_step()
-            rep = try_capture(whole)
-            if rep is not None:
-                step, mode = rep, "hipgraph(whole step)"
-            else:
-                def step():
-                    fwd_bwd(); opt_step()
-        else:
-            rep_a, rep_b = try_capture(fwd_bwd), None
-            if rep_a is not None:
-                rep_b = try_capture(opt_step)
-            if rep_a is not None and rep_b is not None:
-                mode = "hipgraph(fwd+bwd) + rccl all-reduce + hipgraph(optimizer)"
+    mode = stepper.mode
+    it = iter(range(1, total))
 
-                def step():
-                    rep_a(); sync_grads(); rep_b()
-            else:
-                def step():
-                    fwd_bwd(); sync_grads(); opt_step()
-    else:
-        def step():
-            fwd_bwd(); sync_grads(); opt_step()
+    def step():
+        stepper.run_indices(hi_all[next(it)])
 
+    loss_buf = stepper.loss
     for _ in range(args.warmup):
         step()
     if world > 1:
@@ -252,7 +193,7 @@ def main():
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "PEMS07-shape N=228 W=12 H=3 multi=5 stack=2, batch 32 per GPU, train step "
-                               "(fwd+MSE+bwd+RMSprop), dropout 0.5", "global_batch": world * cfg["B"],
+                               "(window gather+fwd+MSE+bwd+RMSprop), dropout 0.5", "global_batch": world * cfg["B"],
                    "per_gpu_batch": cfg["B"], "parallelism": f"dp{world}", "launch": mode},
         "final_loss": final_loss,
     }

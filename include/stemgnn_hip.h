@@ -173,6 +173,36 @@ int stemgnn_fc_tail_bwd(const float* dforecast, const float* fsum, const float* 
 int stemgnn_rmsprop_step(float* params, float* grads, float* square_avg, size_t n, const float* lr_dev,
                          float alpha, float eps, int zero_grad, void* stream);
 
+/* ---- data path either side of the hot path ---------------------------------------------
+ * normalized() (data_loader/forecast_dataloader.py:7-22): out[t,n] = (float)clip01?((raw[t,n]-sub[n])/div[n]) in IEEE
+ * fp64 (z_score: sub=mean, div=std with 0->1; min_max: sub=min, div=max-min+1e-5, clip01=1).  raw [T,N] fp64. */
+int stemgnn_normalize_series(const double* raw, const double* sub, const double* div, int clip01, float* out,
+                             long T, int N, void* stream);
+/* ForecastDataset.__getitem__ + default collate (forecast_dataloader.py:56-63, models/handler.py:136-138,158-159):
+ * x[b,w,:] = series[hi[b]-W+w,:], y[b,h,:] = series[hi[b]+h,:]; series [T,N] fp32 resident, hi [B] int64 (device).
+ * A window outside [0,T] is written as zeros and sets bit 0 of *status (device int, may be NULL). */
+int stemgnn_window_gather(const float* series, const long long* hi, float* x, float* y, int B, int W, int H, int N,
+                          long T, int* status, void* stream);
+/* nn.MSELoss(reduction='mean') of the driver (models/handler.py:140,162): loss[0] = mean((forecast-target)^2) with
+ * a fixed-order two-stage reduction; bwd: dforecast = grad_loss[0] * 2 (forecast-target)/n. */
+size_t stemgnn_mse_scratch_floats(void);
+int stemgnn_mse_fwd(const float* forecast, const float* target, size_t n, float* scratch, float* loss, void* stream);
+int stemgnn_mse_bwd(const float* forecast, const float* target, size_t n, const float* grad_loss, float* dforecast,
+                    void* stream);
+/* one iteration of the rolling inference (models/handler.py:56-61), out of place: inputs_next = inputs shifted left
+ * by L with forecast [B,L,N] appended; forecast_steps[b, step + j, :] = forecast[b,j,:] for j < min(horizon-step, L).
+ * L > W (which the reference fails on with a shape error) returns SG_EINVAL. */
+int stemgnn_roll_window(const float* inputs, const float* forecast, float* inputs_next, float* forecast_steps,
+                        int B, int W, int L, int N, int step, int horizon, void* stream);
+/* evaluate() (utils/math_utils.py:24-74) with the optional de_normalized() (forecast_dataloader.py:25-38) in front:
+ * target / forecast [count,H,N] fp32, v -> v*mul[n] + add[n] in fp64 when mul != NULL (z_score: std, mean; min_max:
+ * max-min+1e-8, min).  out (fp64) = overall[3] | by_node[3][N] | by_step[3][H] | by_step_node[3][H][N], each triple
+ * (MAPE with its +1e-5 and clip at 5, MAE, RMSE). */
+size_t stemgnn_eval_scratch_doubles(long count, int H, int N);
+size_t stemgnn_eval_out_doubles(int H, int N);
+int stemgnn_eval_metrics(const float* target, const float* forecast, const double* mul, const double* add,
+                         long count, int H, int N, double* scratch, double* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

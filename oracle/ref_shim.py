@@ -53,3 +53,20 @@ def load_reference_model_module():
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     return mod
+
+
+def load_reference_packages():
+    """Import the reference's ``data_loader.forecast_dataloader``, ``utils.math_utils`` and ``models.handler``
+    (as the packages they are, REFERENCE_ROOT prepended to sys.path) under the compat shims.  Returns the 3 modules."""
+    if not reference_available():
+        raise FileNotFoundError(f"reference not mounted at {REFERENCE_ROOT}")
+    _install_shims()
+    sys.dont_write_bytecode = True
+    if REFERENCE_ROOT not in sys.path:
+        sys.path.insert(0, REFERENCE_ROOT)
+    import warnings
+    warnings.filterwarnings("ignore", category=FutureWarning)
+    fd = importlib.import_module("data_loader.forecast_dataloader")
+    mu = importlib.import_module("utils.math_utils")
+    hd = importlib.import_module("models.handler")
+    return fd, mu, hd

@@ -44,6 +44,15 @@ SIGNATURES = {
     "stemgnn_fc_tail_fwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P]),
     "stemgnn_fc_tail_bwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P]),
     "stemgnn_rmsprop_step": (c_int, [_P, _P, _P, c_size_t, _P, c_float, c_float, c_int, _P]),
+    "stemgnn_normalize_series": (c_int, [_P, _P, _P, c_int, _P, c_long, c_int, _P]),
+    "stemgnn_window_gather": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_long, _P, _P]),
+    "stemgnn_mse_scratch_floats": (c_size_t, []),
+    "stemgnn_mse_fwd": (c_int, [_P, _P, c_size_t, _P, _P, _P]),
+    "stemgnn_mse_bwd": (c_int, [_P, _P, c_size_t, _P, _P, _P]),
+    "stemgnn_roll_window": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    "stemgnn_eval_scratch_doubles": (c_size_t, [c_long, c_int, c_int]),
+    "stemgnn_eval_out_doubles": (c_size_t, [c_int, c_int]),
+    "stemgnn_eval_metrics": (c_int, [_P, _P, _P, _P, c_long, c_int, c_int, _P, _P, _P]),
     "stemgnn_block_pack": (c_int, [_PP, _P, _P, c_int, c_int, _P]),
     "stemgnn_block_unpack_grads": (c_int, [_P, c_int, _P, _PP, c_int, c_int, c_int, _P]),
     "stemgnn_gft_fwd": (c_int, [_P, _P, c_long, c_long, c_long, _P, c_int, c_int, c_int, _P]),

@@ -1,0 +1,295 @@
+// Data path either side of the hot path, all HBM-bound copies / reductions:
+//   * normalisation of the raw series            data_loader/forecast_dataloader.py:7-22    (fp64 in, fp32 out)
+//   * window gather = Dataset.__getitem__ + default collate  forecast_dataloader.py:56-63, models/handler.py:136-138
+//   * MSE loss of the driver                     models/handler.py:140,162
+//   * rolling-inference window shift             models/handler.py:56-61
+//   * de-normalise + MAPE / MAE / RMSE           forecast_dataloader.py:25-38, utils/math_utils.py:24-74   (fp64)
+// The series stays resident in HBM as one [T, N] fp32 matrix; a batch is B (W+H)-row slabs of it, so every row is one
+// coalesced N-float copy.  Reductions are two-stage with a fixed order (bitwise reproducible).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/stemgnn_hip.h"
+
+#define SG_TRY(e)                                \
+  do {                                           \
+    hipError_t _e = (e);                         \
+    if (_e != hipSuccess) return -(int)_e;       \
+  } while (0)
+
+// ---------------------------------------------------------------------------------------------------------------
+// out[t,n] = float( clip01?( (raw[t,n] - sub[n]) / div[n] ) ) -- IEEE fp64 subtract and divide, as numpy does
+__global__ void sg_normalize_kernel(const double* __restrict__ raw, const double* __restrict__ sub,
+                                    const double* __restrict__ div, int clip01, float* __restrict__ out, size_t total,
+                                    int N) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < total; i += stride) {
+    const int n = (int)(i % (size_t)N);
+    double v = __ddiv_rn(__dsub_rn(raw[i], sub[n]), div[n]);
+    if (clip01) v = v < 0.0 ? 0.0 : (v > 1.0 ? 1.0 : v);      // np.clip: NaN passes through
+    out[i] = (float)v;
+  }
+}
+
+extern "C" int stemgnn_normalize_series(const double* raw, const double* sub, const double* div, int clip01, float* out,
+                                        long T, int N, void* stream) {
+  if (!raw || !sub || !div || !out || T <= 0 || N <= 0) return SG_EINVAL;
+  const size_t total = (size_t)T * N;
+  unsigned blocks = (unsigned)((total + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(sg_normalize_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, raw, sub, div, clip01, out,
+                     total, N);
+  SG_TRY(hipGetLastError());
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// x[b,w,:] = series[hi[b]-W+w,:] (w<W), y[b,h,:] = series[hi[b]+h,:] (h<H).  One workgroup per (row of the slab, b).
+// Out-of-range rows (a bad index) set *status and write zeros instead of faulting.
+__global__ void sg_window_gather_kernel(const float* __restrict__ series, const long long* __restrict__ hi,
+                                        float* __restrict__ x, float* __restrict__ y, int W, int H, int N, long T,
+                                        int* __restrict__ status) {
+  const int r = blockIdx.x, b = blockIdx.y;
+  const long long h0 = hi[b];
+  const long long t = h0 - W + r;
+  float* dst = r < W ? x + ((size_t)b * W + r) * N : y + ((size_t)b * H + (r - W)) * N;
+  const bool ok = h0 - W >= 0 && h0 + H <= T;
+  if (!ok && threadIdx.x == 0 && status) atomicOr(status, 1);
+  const float* src = series + (size_t)(ok ? t : 0) * N;
+  if ((N & 3) == 0) {
+    const float4* s4 = reinterpret_cast<const float4*>(src);
+    float4* d4 = reinterpret_cast<float4*>(dst);
+    for (int i = threadIdx.x; i < N / 4; i += blockDim.x) d4[i] = ok ? s4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+  } else {
+    for (int i = threadIdx.x; i < N; i += blockDim.x) dst[i] = ok ? src[i] : 0.f;
+  }
+}
+
+extern "C" int stemgnn_window_gather(const float* series, const long long* hi, float* x, float* y, int B, int W, int H,
+                                     int N, long T, int* status, void* stream) {
+  if (!series || !hi || !x || !y || B <= 0 || W <= 0 || H < 0 || N <= 0 || T < (long)W + H) return SG_EINVAL;
+  if ((N & 3) == 0 && ((((uintptr_t)series | (uintptr_t)x | (uintptr_t)y) & 15) != 0)) return SG_EINVAL;
+  const int threads = N >= 1024 ? 256 : (N >= 256 ? 128 : 64);
+  hipLaunchKernelGGL(sg_window_gather_kernel, dim3(W + H, B), dim3(threads), 0, (hipStream_t)stream, series, hi, x, y,
+                     W, H, N, T, status);
+  SG_TRY(hipGetLastError());
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// MSE (nn.MSELoss(reduction='mean'), handler.py:140): loss = sum((f-y)^2)/n; two-stage fixed-order reduction.
+constexpr int MSE_BLOCKS = 128;
+constexpr int MSE_THREADS = 256;
+
+__device__ __forceinline__ float sg_block_sum(float v, float* sm) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) sm[w] = v;
+  __syncthreads();
+  float t = 0.f;
+  if (threadIdx.x == 0)
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += sm[i];
+  return t;                                                       // valid on thread 0
+}
+
+__global__ __launch_bounds__(MSE_THREADS) void sg_mse_partial_kernel(const float* __restrict__ f,
+                                                                     const float* __restrict__ y, size_t n,
+                                                                     float* __restrict__ part) {
+  __shared__ float sm[MSE_THREADS / 64];
+  float acc = 0.f;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float d = f[i] - y[i];
+    acc = fmaf(d, d, acc);
+  }
+  const float t = sg_block_sum(acc, sm);
+  if (threadIdx.x == 0) part[blockIdx.x] = t;
+}
+
+__global__ void sg_mse_final_kernel(const float* __restrict__ part, int nparts, size_t n, float* __restrict__ loss) {
+  float v = (int)threadIdx.x < nparts ? part[threadIdx.x] : 0.f;
+  __shared__ float sm[MSE_BLOCKS / 64];
+  const float t = sg_block_sum(v, sm);
+  if (threadIdx.x == 0) loss[0] = t / (float)n;
+}
+
+__global__ void sg_mse_bwd_kernel(const float* __restrict__ f, const float* __restrict__ y, size_t n,
+                                  const float* __restrict__ gout, float* __restrict__ df) {
+  const float s = 2.f * gout[0] / (float)n;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    df[i] = s * (f[i] - y[i]);
+}
+
+extern "C" size_t stemgnn_mse_scratch_floats(void) { return MSE_BLOCKS; }
+
+extern "C" int stemgnn_mse_fwd(const float* forecast, const float* target, size_t n, float* scratch, float* loss,
+                               void* stream) {
+  if (!forecast || !target || !scratch || !loss || n == 0) return SG_EINVAL;
+  hipLaunchKernelGGL(sg_mse_partial_kernel, dim3(MSE_BLOCKS), dim3(MSE_THREADS), 0, (hipStream_t)stream, forecast,
+                     target, n, scratch);
+  SG_TRY(hipGetLastError());
+  hipLaunchKernelGGL(sg_mse_final_kernel, dim3(1), dim3(MSE_BLOCKS), 0, (hipStream_t)stream, scratch, MSE_BLOCKS, n,
+                     loss);
+  SG_TRY(hipGetLastError());
+  return 0;
+}
+
+extern "C" int stemgnn_mse_bwd(const float* forecast, const float* target, size_t n, const float* grad_loss,
+                               float* dforecast, void* stream) {
+  if (!forecast || !target || !grad_loss || !dforecast || n == 0) return SG_EINVAL;
+  unsigned blocks = (unsigned)((n + 255) / 256);
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(sg_mse_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, forecast, target, n, grad_loss,
+                     dforecast);
+  SG_TRY(hipGetLastError());
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// handler.py:56-61: inputs_next[b,w,:] = w < W-L ? inputs[b,w+L,:] : forecast[b,w-(W-L),:]   (L = model output length)
+// and forecast_steps[b, step+j, :] = forecast[b,j,:] for j < min(horizon-step, L).  Out of place (ping-pong buffers).
+__global__ void sg_roll_window_kernel(const float* __restrict__ inputs, const float* __restrict__ forecast,
+                                      float* __restrict__ inputs_next, float* __restrict__ forecast_steps, int W, int L,
+                                      int N, int step, int horizon) {
+  const int r = blockIdx.x, b = blockIdx.y;                       // r < W: window row; r >= W: forecast_steps row
+  const int take = min(horizon - step, L);
+  const float* src;
+  float* dst;
+  if (r < W) {
+    src = r < W - L ? inputs + ((size_t)b * W + r + L) * N : forecast + ((size_t)b * L + (r - (W - L))) * N;
+    dst = inputs_next + ((size_t)b * W + r) * N;
+  } else {
+    const int j = r - W;
+    if (j >= take) return;
+    src = forecast + ((size_t)b * L + j) * N;
+    dst = forecast_steps + ((size_t)b * horizon + step + j) * N;
+  }
+  for (int i = threadIdx.x; i < N; i += blockDim.x) dst[i] = src[i];
+}
+
+extern "C" int stemgnn_roll_window(const float* inputs, const float* forecast, float* inputs_next,
+                                   float* forecast_steps, int B, int W, int L, int N, int step, int horizon,
+                                   void* stream) {
+  if (!inputs || !forecast || !inputs_next || !forecast_steps || inputs == inputs_next) return SG_EINVAL;
+  if (B <= 0 || W <= 0 || N <= 0 || L <= 0 || L > W || step < 0 || step >= horizon) return SG_EINVAL;
+  hipLaunchKernelGGL(sg_roll_window_kernel, dim3(W + L, B), dim3(N >= 256 ? 256 : 64), 0, (hipStream_t)stream, inputs,
+                     forecast, inputs_next, forecast_steps, W, L, N, step, horizon);
+  SG_TRY(hipGetLastError());
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// evaluate(): target / forecast [count, H, N] fp32 (the reference holds the same values in float64 arrays,
+// handler.py:50); optional de-normalisation v*mul[n] + add[n] in fp64 with separate multiply and add roundings
+// (numpy: `data * std + mean`).  Per element: ape = min?(|f-t|/|t| + 1e-5, 5) (NaN kept), ae = |f-t|, se = (f-t)^2.
+// Stage 1: column c = (h, n) sums over a chunk of `count`; stage 2: fixed-order chunk sum, then every axis variant:
+// out = overall[3] | by_node[3][N] | by_step[3][H] | by_step_node[3][H][N]   (each triple = mape, mae, rmse).
+constexpr int EVAL_CHUNK_ROWS = 64;
+
+__global__ __launch_bounds__(256) void sg_eval_partial_kernel(const float* __restrict__ target,
+                                                              const float* __restrict__ forecast,
+                                                              const double* __restrict__ mul,
+                                                              const double* __restrict__ add, long count, int HN, int N,
+                                                              double* __restrict__ part) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= HN) return;
+  const long r0 = (long)blockIdx.y * EVAL_CHUNK_ROWS;
+  const long r1 = min(count, r0 + (long)EVAL_CHUNK_ROWS);
+  const int n = c % N;
+  const double mu = mul ? mul[n] : 1.0, ad = mul ? add[n] : 0.0;
+  double s_ape = 0.0, s_ae = 0.0, s_se = 0.0;
+  for (long r = r0; r < r1; ++r) {
+    double t = (double)target[(size_t)r * HN + c], f = (double)forecast[(size_t)r * HN + c];
+    if (mul) {
+      t = __dadd_rn(__dmul_rn(t, mu), ad);
+      f = __dadd_rn(__dmul_rn(f, mu), ad);
+    }
+    const double d = __dsub_rn(f, t);
+    const double ae = fabs(d);
+    double ape = __dadd_rn(__ddiv_rn(ae, fabs(t)), 1e-5);
+    ape = ape > 5.0 ? 5.0 : ape;
+    s_ape += ape;
+    s_ae += ae;
+    s_se = __dadd_rn(s_se, __dmul_rn(d, d));
+  }
+  const size_t nchunk = gridDim.y;
+  part[((size_t)0 * nchunk + blockIdx.y) * HN + c] = s_ape;
+  part[((size_t)1 * nchunk + blockIdx.y) * HN + c] = s_ae;
+  part[((size_t)2 * nchunk + blockIdx.y) * HN + c] = s_se;
+}
+
+// one workgroup; thread-per-column chunk sums -> by_step_node sums in LDS-free global scratch (`colsum`), then the
+// coarser variants by fixed-order loops (H*N is a few thousand at most: this is a microsecond-scale epilogue)
+__global__ __launch_bounds__(256) void sg_eval_final_kernel(const double* __restrict__ part, int nchunk, long count,
+                                                            int H, int N, double* __restrict__ colsum,
+                                                            double* __restrict__ out) {
+  const int HN = H * N;
+  double* nodesum = colsum + (size_t)3 * HN;                      // [3][N]
+  for (int q = 0; q < 3; ++q)
+    for (int c = threadIdx.x; c < HN; c += blockDim.x) {
+      double s = 0.0;
+      for (int k = 0; k < nchunk; ++k) s += part[((size_t)q * nchunk + k) * HN + c];
+      colsum[(size_t)q * HN + c] = s;
+    }
+  __syncthreads();
+  double* overall = out;
+  double* by_node = out + 3;
+  double* by_step = by_node + 3 * (size_t)N;
+  double* by_sn = by_step + 3 * (size_t)H;
+  const double cnt = (double)count;
+  for (int q = 0; q < 3; ++q) {
+    for (int c = threadIdx.x; c < HN; c += blockDim.x) {
+      const double m = colsum[(size_t)q * HN + c] / cnt;
+      by_sn[(size_t)q * HN + c] = q == 2 ? sqrt(m) : m;
+    }
+    for (int n = threadIdx.x; n < N; n += blockDim.x) {
+      double s = 0.0;
+      for (int h = 0; h < H; ++h) s += colsum[(size_t)q * HN + (size_t)h * N + n];
+      nodesum[(size_t)q * N + n] = s;
+      const double m = s / (cnt * H);
+      by_node[(size_t)q * N + n] = q == 2 ? sqrt(m) : m;
+    }
+    for (int h = threadIdx.x; h < H; h += blockDim.x) {
+      double s = 0.0;
+      for (int n = 0; n < N; ++n) s += colsum[(size_t)q * HN + (size_t)h * N + n];
+      const double m = s / (cnt * N);
+      by_step[(size_t)q * H + h] = q == 2 ? sqrt(m) : m;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    const int q = threadIdx.x;
+    double s = 0.0;
+    for (int n = 0; n < N; ++n) s += nodesum[(size_t)q * N + n];
+    const double m = s / (cnt * HN);
+    overall[q] = q == 2 ? sqrt(m) : m;
+  }
+}
+
+static inline int eval_nchunk(long count) { return (int)((count + EVAL_CHUNK_ROWS - 1) / EVAL_CHUNK_ROWS); }
+
+extern "C" size_t stemgnn_eval_scratch_doubles(long count, int H, int N) {
+  if (count <= 0 || H <= 0 || N <= 0) return 0;
+  return (size_t)3 * H * N * ((size_t)eval_nchunk(count) + 1) + 3 * (size_t)N;
+}
+extern "C" size_t stemgnn_eval_out_doubles(int H, int N) {
+  if (H <= 0 || N <= 0) return 0;
+  return 3 + 3 * (size_t)N + 3 * (size_t)H + 3 * (size_t)H * N;
+}
+
+extern "C" int stemgnn_eval_metrics(const float* target, const float* forecast, const double* mul, const double* add,
+                                    long count, int H, int N, double* scratch, double* out, void* stream) {
+  if (!target || !forecast || !scratch || !out || count <= 0 || H <= 0 || N <= 0) return SG_EINVAL;
+  if ((mul == nullptr) != (add == nullptr)) return SG_EINVAL;
+  const int HN = H * N, nchunk = eval_nchunk(count);
+  if (nchunk > 65535) return SG_EINVAL;
+  double* part = scratch;
+  double* colsum = scratch + (size_t)3 * HN * nchunk;
+  hipLaunchKernelGGL(sg_eval_partial_kernel, dim3((HN + 255) / 256, nchunk), dim3(256), 0, (hipStream_t)stream, target,
+                     forecast, mul, add, count, HN, N, part);
+  SG_TRY(hipGetLastError());
+  hipLaunchKernelGGL(sg_eval_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, part, nchunk, count, H, N, colsum,
+                     out);
+  SG_TRY(hipGetLastError());
+  return 0;
+}

@@ -1,0 +1,179 @@
+"""The training step of the reference driver (models/handler.py:157-166) as ONE replayable unit.
+
+    gather batch windows by index (resident series) -> zero_grad -> forward -> MSE -> backward
+    -> (flat gradient all-reduce over RCCL when world > 1) -> optimizer step -> loss accumulation
+
+With ``FusedRMSprop`` the whole step is captured once into a hipGraph (two graphs around the all-reduce when
+world > 1) and replayed per batch: the host only copies B int64 indices into a static buffer.  A ragged last batch
+(``drop_last=False``) or another optimizer runs the same code eagerly.  Used by ``stemgnn_amd.handler.train`` and
+``bench.py`` -- the benchmark measures exactly what the driver runs.
+"""
+import sys
+
+import torch
+
+from . import ops
+from .distributed import FlatGradBucket
+
+
+def capture(fn, warmups=3):
+    """Capture fn into a hipGraph (torch.cuda.CUDAGraph); returns the replay callable, or None if capture fails."""
+    try:
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(warmups):
+                fn()
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            fn()
+        torch.cuda.synchronize()
+        return g.replay
+    except Exception as e:  # noqa: BLE001
+        print(f"[stemgnn_amd] graph capture unavailable ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
+        torch.cuda.synchronize()
+        return None
+
+
+class TrainStep:
+    def __init__(self, model, optimizer, batch_size, window_size, horizon, units, series=None, world=1, graph=True):
+        self.model, self.opt = model, optimizer
+        self.B, self.W, self.H, self.N = int(batch_size), int(window_size), int(horizon), int(units)
+        self.world = world
+        dev = next(model.parameters()).device
+        self.device = dev
+        self.fused = hasattr(optimizer, "bucket")                       # FusedRMSprop: flat params + flat grads
+        self.bucket = optimizer.bucket if self.fused else (FlatGradBucket(model.parameters()) if world > 1 else None)
+        ops.set_direct_grad(self.fused, overlap=self.fused)
+        self.fuse_zero = self.fused and getattr(optimizer, "fuse_zero_grad", False)
+        self.series = series                                            # [T,N] fp32 resident, or None: x/y given
+        self.hi = torch.zeros(self.B, dtype=torch.int64, device=dev)    # static window-end indices
+        if series is not None:
+            self.hi.fill_(self.W)
+        self.x = torch.zeros(self.B, self.W, self.N, device=dev)
+        self.y = torch.zeros(self.B, self.H, self.N, device=dev)
+        self.loss = torch.zeros((), device=dev)
+        self.loss_sum = torch.zeros((), device=dev, dtype=torch.float64)
+        self.want_graph = bool(graph) and self.fused
+        self.mode = "eager"
+        self._replay = None
+        self._armed = False
+
+    # -- the step body, on whatever tensors it is handed ------------------------------------------------------
+    def _fwd_bwd(self, hi, x, y):
+        if self.series is not None:
+            ops.window_gather(self.series, hi, self.W, self.H, x, y)
+        if not self.fuse_zero:
+            if self.bucket is not None:
+                self.bucket.zero()
+            else:
+                self.model.zero_grad()                                  # handler.py:160
+        forecast, _ = self.model(x)                                     # :161
+        loss = ops.mse_loss(forecast, y)                                # :162
+        loss.backward()                                                 # :164
+        return loss.detach()
+
+    def _finish(self, loss):
+        self.opt.step()                                                 # :165
+        self.loss.copy_(loss)
+        self.loss_sum.add_(loss.double())                               # :166, without the per-step host sync
+
+    def _sync(self):
+        if self.world > 1:
+            self.bucket.all_reduce_mean()
+
+    def _arm(self):
+        """First full batch: one eager step happened already (lazy state), now capture."""
+        self._armed = True
+        if not self.want_graph:
+            return
+        if self.world == 1:
+            def whole():
+                self._finish(self._fwd_bwd(self.hi, self.x, self.y))
+            snap = self._snapshot()
+            rep = capture(whole)
+            self._restore(snap)
+            if rep is not None:
+                self._replay, self.mode = rep, "hipgraph(whole step)"
+        else:
+            box = {}
+
+            def part_a():
+                box["loss"] = self._fwd_bwd(self.hi, self.x, self.y)
+                self.loss.copy_(box["loss"])
+
+            def part_b():
+                self.opt.step()
+                self.loss_sum.add_(self.loss.double())
+            snap = self._snapshot()
+            ra = capture(part_a)
+            rb = capture(part_b) if ra is not None else None
+            self._restore(snap)
+            if ra is not None and rb is not None:
+                def rep():
+                    ra(); self._sync(); rb()
+                self._replay, self.mode = rep, "hipgraph(fwd+bwd) + rccl all-reduce + hipgraph(optimizer)"
+
+    def _snapshot(self):
+        """Capture warm-ups execute real steps: keep parameters / optimizer state / dropout stream to put back."""
+        st = dict(p=self.opt.flat_p.clone(), sq=self.opt.square_avg.clone(), g=self.opt.bucket.flat.clone(),
+                  loss=self.loss.clone(), loss_sum=self.loss_sum.clone())
+        seed = getattr(self.model, "_seed", None)
+        st["seed"] = None if seed is None else seed.clone()
+        return st
+
+    def _restore(self, st):
+        self.opt.flat_p.copy_(st["p"]); self.opt.square_avg.copy_(st["sq"]); self.opt.bucket.flat.copy_(st["g"])
+        self.loss.copy_(st["loss"]); self.loss_sum.copy_(st["loss_sum"])
+        if st["seed"] is not None:
+            self.model._seed.copy_(st["seed"])
+        torch.cuda.synchronize()
+
+    # -- public ----------------------------------------------------------------------------------------------
+    def run_indices(self, hi):
+        """One optimizer step on the windows ending at `hi` (int64 device tensor, <= batch_size of them)."""
+        if hi.numel() == self.B:
+            if self._replay is not None:
+                self.hi.copy_(hi)
+                self.opt.sync_lr()
+                self._replay()
+                return
+            self.hi.copy_(hi)
+            self._finish_eager(self.hi, self.x, self.y)
+            if not self._armed:
+                self._arm()
+            return
+        b = hi.numel()                                                  # ragged tail: eager, fresh buffers
+        x = torch.empty(b, self.W, self.N, device=self.device)
+        y = torch.empty(b, self.H, self.N, device=self.device)
+        self._finish_eager(hi, x, y)
+
+    def run_batch(self, x=None, y=None):
+        """One optimizer step on a ready batch (copied into the static buffers; None: reuse what is there)."""
+        if self.series is not None:
+            raise RuntimeError("this TrainStep gathers from a resident series: use run_indices")
+        if x is not None and x.shape[0] != self.B:
+            self._finish_eager(None, x.contiguous(), y.contiguous())
+            return
+        if x is not None:
+            self.x.copy_(x); self.y.copy_(y)
+        if self._replay is not None:
+            self.opt.sync_lr()
+            self._replay()
+            return
+        self._finish_eager(None, self.x, self.y)
+        if not self._armed:
+            self._arm()
+
+    def _finish_eager(self, hi, x, y):
+        loss = self._fwd_bwd(hi, x, y)
+        self._sync()
+        self._finish(loss)
+
+    def epoch_loss_sum(self, reset=True):
+        v = float(self.loss_sum.item())
+        if reset:
+            self.loss_sum.zero_()
+        return v

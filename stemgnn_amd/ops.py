@@ -467,3 +467,136 @@ class SpectralHotPath(torch.autograd.Function):
         if kq_direct:
             dwk = dwq = None
         return (dh, None, dwk, dwq, None, None, None, None, None, *grads[0], *grads[1])
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# data path either side of the hot path: thin wrappers over csrc/data.hip
+
+class MSELossFn(torch.autograd.Function):
+    """nn.MSELoss(reduction='mean') of the driver (reference models/handler.py:140,162) as two fixed-order kernels."""
+
+    @staticmethod
+    def forward(ctx, forecast, target):
+        lib = _lib.load()
+        _require_gpu(forecast, "forecast")
+        _require_gpu(target, "target")
+        if forecast.shape != target.shape:
+            raise _lib.StemGNNHipError(f"MSE: shapes differ {tuple(forecast.shape)} vs {tuple(target.shape)}")
+        forecast, target = forecast.contiguous(), target.contiguous()
+        scratch = torch.empty(lib.stemgnn_mse_scratch_floats(), device=forecast.device, dtype=torch.float32)
+        loss = torch.empty((), device=forecast.device, dtype=torch.float32)
+        _lib.check(lib.stemgnn_mse_fwd(forecast.data_ptr(), target.data_ptr(), forecast.numel(), scratch.data_ptr(),
+                                       loss.data_ptr(), _stream()), "mse_fwd")
+        ctx.save_for_backward(forecast, target)
+        return loss
+
+    @staticmethod
+    def backward(ctx, grad_loss):
+        lib = _lib.load()
+        forecast, target = ctx.saved_tensors
+        grad_loss = grad_loss.contiguous()
+        dforecast = torch.empty_like(forecast)
+        _lib.check(lib.stemgnn_mse_bwd(forecast.data_ptr(), target.data_ptr(), forecast.numel(), grad_loss.data_ptr(),
+                                       dforecast.data_ptr(), _stream()), "mse_bwd")
+        return dforecast, None
+
+
+def mse_loss(forecast, target):
+    return MSELossFn.apply(forecast, target)
+
+
+class MSELoss(torch.nn.Module):
+    """Drop-in for ``nn.MSELoss(reduction='mean')`` at models/handler.py:140."""
+
+    def __init__(self, reduction="mean"):
+        super().__init__()
+        if reduction != "mean":
+            raise ValueError("stemgnn_amd.ops.MSELoss implements reduction='mean' only (the reference's setting)")
+
+    def forward(self, forecast, target):
+        return MSELossFn.apply(forecast, target)
+
+
+def normalize_series(raw, sub, div, clip01):
+    """raw [T,N] float64 (device) -> float32 [T,N]: (raw - sub[n]) / div[n] in fp64, optional clip to [0,1]."""
+    lib = _lib.load()
+    if not raw.is_cuda or raw.dtype != torch.float64:
+        raise _lib.StemGNNHipError("normalize_series: raw must be a float64 tensor on a HIP device")
+    raw, sub, div = raw.contiguous(), sub.contiguous(), div.contiguous()
+    T, N = raw.shape
+    out = torch.empty(T, N, device=raw.device, dtype=torch.float32)
+    _lib.check(lib.stemgnn_normalize_series(raw.data_ptr(), sub.data_ptr(), div.data_ptr(), int(bool(clip01)),
+                                            out.data_ptr(), T, N, _stream()), "normalize_series")
+    return out
+
+
+_gather_status = {}
+
+
+def window_gather(series, hi, W, H, x=None, y=None):
+    """series [T,N] fp32 resident, hi [B] int64 (device): x[b] = series[hi-W:hi], y[b] = series[hi:hi+H]."""
+    lib = _lib.load()
+    _require_gpu(series, "series")
+    if hi.dtype != torch.int64 or hi.device != series.device:
+        raise _lib.StemGNNHipError("window_gather: hi must be an int64 tensor on the series' device")
+    T, N = series.shape
+    B = hi.numel()
+    if x is None:
+        x = torch.empty(B, W, N, device=series.device, dtype=torch.float32)
+    if y is None:
+        y = torch.empty(B, H, N, device=series.device, dtype=torch.float32)
+    key = str(series.device)
+    st = _gather_status.get(key)
+    if st is None:
+        st = _gather_status[key] = torch.zeros(1, dtype=torch.int32, device=series.device)
+    _lib.check(lib.stemgnn_window_gather(series.data_ptr(), hi.data_ptr(), x.data_ptr(), y.data_ptr(), B, W, H, N, T,
+                                         st.data_ptr(), _stream()), "window_gather")
+    return x, y
+
+
+def check_gather_status(device):
+    """Raise if any window_gather since the last check saw an out-of-range index (one sync; call per epoch)."""
+    st = _gather_status.get(str(device))
+    if st is not None and int(st.item()) != 0:
+        st.zero_()
+        raise IndexError("window_gather: window index outside the series")
+
+
+def roll_window(inputs, forecast, forecast_steps, step, horizon):
+    """One iteration of the reference's rolling inference (models/handler.py:56-61); returns the next inputs."""
+    lib = _lib.load()
+    _require_gpu(inputs, "inputs")
+    _require_gpu(forecast, "forecast")
+    B, W, N = inputs.shape
+    L = forecast.shape[1]
+    if L == 0:
+        raise Exception("Get blank inference result")                    # handler.py:54-55
+    inputs, forecast = inputs.contiguous(), forecast.contiguous()
+    nxt = torch.empty_like(inputs)
+    _lib.check(lib.stemgnn_roll_window(inputs.data_ptr(), forecast.data_ptr(), nxt.data_ptr(),
+                                       forecast_steps.data_ptr(), B, W, L, N, int(step), int(horizon), _stream()),
+               "roll_window")
+    return nxt
+
+
+def eval_metrics(target, forecast, mul=None, add=None):
+    """target / forecast [count,H,N] fp32 -> float64 device vector
+    overall[3] | by_node[3][N] | by_step[3][H] | by_step_node[3][H][N]  (MAPE, MAE, RMSE each)."""
+    lib = _lib.load()
+    _require_gpu(target, "target")
+    _require_gpu(forecast, "forecast")
+    if target.shape != forecast.shape or target.dim() != 3:
+        raise _lib.StemGNNHipError("eval_metrics: target/forecast must both be [count, time_step, node]")
+    target, forecast = target.contiguous(), forecast.contiguous()
+    C, H, N = target.shape
+    dev = target.device
+    scratch = torch.empty(lib.stemgnn_eval_scratch_doubles(C, H, N), device=dev, dtype=torch.float64)
+    out = torch.empty(lib.stemgnn_eval_out_doubles(H, N), device=dev, dtype=torch.float64)
+    if mul is not None:
+        mul = mul.to(device=dev, dtype=torch.float64).contiguous()
+        add = add.to(device=dev, dtype=torch.float64).contiguous()
+    _lib.check(lib.stemgnn_eval_metrics(target.data_ptr(), forecast.data_ptr(),
+                                        mul.data_ptr() if mul is not None else None,
+                                        add.data_ptr() if add is not None else None,
+                                        C, H, N, scratch.data_ptr(), out.data_ptr(), _stream()), "eval_metrics")
+    return out

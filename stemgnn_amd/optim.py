@@ -40,13 +40,19 @@ class FusedRMSprop(torch.optim.Optimizer):
     def zero_grad(self, set_to_none=False):   # gradients live in the flat bucket; never drop the views
         self.bucket.zero()
 
+    def sync_lr(self):
+        """Push a learning rate an LR scheduler changed (host side) to the device word the kernel reads.  step() calls
+        it; a hipGraph replay does not run step()'s Python, so engine.TrainStep calls it before every replay."""
+        lr = float(self.param_groups[0]["lr"])
+        if lr != self._lr_host:
+            self._lr_host = lr
+            self._lr_dev.fill_(lr)
+
     @torch.no_grad()
     def step(self, closure=None):
         loss = closure() if closure is not None else None
         group = self.param_groups[0]
-        if float(group["lr"]) != self._lr_host:            # an LR scheduler changed it (host side, between replays)
-            self._lr_host = float(group["lr"])
-            self._lr_dev.fill_(self._lr_host)
+        self.sync_lr()
         from .ops import join_side_streams
         join_side_streams(self.flat_p.device)
         lib = _lib.load()

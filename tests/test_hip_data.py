@@ -1,0 +1,201 @@
+"""GPU parity of the data path either side of the hot path against the oracle and the golden
+vectors the real reference produced: bit-exact for copies / fp64-normalise / rolling windows, 1e-12 for the fp64
+metrics (summation order), 1e-6 for the fp32 MSE, and the reference's own 3-epoch training run (losses, validation
+MAE/MAPE/RMSE, final weights) reproduced through stemgnn_amd.handler.train."""
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import data_oracle as do
+from tests.util import GOLDEN_DIR
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def G(name):
+    return np.load(os.path.join(GOLDEN_DIR, "data", name + ".npz"))
+
+
+@pytest.mark.parametrize("method", ["z_score", "min_max"])
+def test_dataset_matches_reference_bitwise(method):
+    from stemgnn_amd.forecast_dataloader import ForecastDataset, WindowLoader, de_normalized
+    z = G("norm_" + method)
+    T, N, W, H = (int(v) for v in z["cfg"])
+    keys = ("mean", "std") if method == "z_score" else ("min", "max")
+    stat = {k: z["stat_" + k].tolist() for k in keys}
+    ds = ForecastDataset(z["raw"], W, H, normalize_method=method, norm_statistic=dict(stat), device=DEV)
+    np.testing.assert_array_equal(ds.data.cpu().numpy(), z["data"].astype(np.float32))
+    assert ds.x_end_idx == z["x_end_idx_i1"].tolist() and len(ds) == len(z["x_all"])
+    x, y = ds.gather(list(range(len(ds))))
+    np.testing.assert_array_equal(x.cpu().numpy(), z["x_all"])
+    np.testing.assert_array_equal(y.cpu().numpy(), z["y_all"])
+    xi, yi = ds[3]
+    np.testing.assert_array_equal(xi.cpu().numpy(), z["x_all"][3])
+    np.testing.assert_array_equal(yi.cpu().numpy(), z["y_all"][3])
+    xs = torch.cat([xb for xb, _ in WindowLoader(ds, batch_size=7)])                 # ragged last batch
+    np.testing.assert_array_equal(xs.cpu().numpy(), z["x_all"])
+    assert ForecastDataset(z["raw"], W, H, normalize_method=method, norm_statistic=dict(stat), interval=3,
+                           device=DEV).x_end_idx == z["x_end_idx_i3"].tolist()
+    own = ForecastDataset(z["raw"], W, H, normalize_method=method, device=DEV)
+    np.testing.assert_array_equal(own.data.cpu().numpy(), z["data_ownstat"].astype(np.float32))
+    plain = ForecastDataset(z["raw"], W, H, device=DEV)                              # no normalisation: cast only
+    np.testing.assert_array_equal(plain.data.cpu().numpy(), do.fill_na(z["raw"]).astype(np.float32))
+    dn = de_normalized(torch.from_numpy(z["denorm_in"]).to(DEV), method, stat)
+    np.testing.assert_allclose(dn.cpu().numpy(), z["denorm_out"], rtol=1e-15, atol=0)
+
+
+def test_window_gather_full_size_and_bad_index():
+    """PEMS07 size: every window of the batch equals the slice of the resident series (bitwise); a window outside the
+    series is reported through the status word, not a fault."""
+    from stemgnn_amd import ops
+    T, N, W, H, B = 12672, 228, 12, 3, 32
+    g = torch.Generator().manual_seed(1)
+    series = torch.randn(T, N, generator=g).to(DEV)
+    hi = (torch.randperm(T - W - H + 1, generator=g)[:B] + W).to(DEV)
+    x, y = ops.window_gather(series, hi, W, H)
+    for b in range(B):
+        h = int(hi[b])
+        assert torch.equal(x[b], series[h - W:h]) and torch.equal(y[b], series[h:h + H])
+    for n in (1, 7, 230, 1024):                                                      # odd / vector widths
+        s = torch.randn(50, n, generator=g).to(DEV)
+        h2 = torch.tensor([W, 20, 50 - H], device=DEV)
+        x2, y2 = ops.window_gather(s, h2, W, H)
+        assert torch.equal(x2[1], s[20 - W:20]) and torch.equal(y2[2], s[50 - H:50]) and torch.equal(x2[0], s[0:W])
+    ops.check_gather_status(series.device)
+    bad = torch.tensor([W - 1, T], device=DEV)
+    xb, _ = ops.window_gather(series, bad, W, H)
+    assert float(xb.abs().max()) == 0.0
+    with pytest.raises(IndexError):
+        ops.check_gather_status(series.device)
+    ops.check_gather_status(series.device)                                           # cleared
+
+
+def test_metrics_match_reference():
+    from stemgnn_amd import math_utils
+    from stemgnn_amd.forecast_dataloader import denorm_coefficients
+    z = G("metrics")
+    t = torch.from_numpy(z["target"]).to(DEV)
+    f = torch.from_numpy(z["forecast"].astype(np.float32)).to(DEV)
+    stat = {"mean": z["stat_mean"].tolist(), "std": z["stat_std"].tolist()}
+    mul, add = denorm_coefficients("z_score", stat, DEV)
+    scores = dict(norm=math_utils.Scores(t, f), raw=math_utils.Scores(t, f, mul, add))
+    for tag, sc in scores.items():
+        for s in (0, 1):
+            for n in (0, 1):
+                got = sc.get(by_step=bool(s), by_node=bool(n))
+                for nm, v in zip(("mape", "mae", "rmse"), got):
+                    np.testing.assert_allclose(np.asarray(v), z[f"{tag}_s{s}n{n}_{nm}"], rtol=1e-12, atol=0,
+                                               err_msg=f"{tag} s{s} n{n} {nm}")
+    m = math_utils.evaluate(t, f, by_node=True)
+    np.testing.assert_allclose(m[1], z["norm_s0n1_mae"], rtol=1e-12)
+    np.testing.assert_allclose(math_utils.MAE(t, f), z["norm_s0n0_mae"], rtol=1e-12)
+    np.testing.assert_allclose(math_utils.RMSE(t, f, axis=(0, 2)), z["norm_s1n0_rmse"], rtol=1e-12)
+    # 0/0 stays NaN in MAPE (np.where(nan > 5) is False), MAE / RMSE unaffected
+    t0, f0 = t.clone(), f.clone()
+    t0[0, 0, 0] = 0.0; f0[0, 0, 0] = 0.0
+    with np.errstate(divide="ignore", invalid="ignore"):
+        want = do.evaluate(t0.cpu().numpy(), f0.cpu().numpy().astype(np.float64))
+    got = math_utils.evaluate(t0, f0)
+    assert np.isnan(got[0]) and np.isnan(want[0])
+    np.testing.assert_allclose(got[1:], want[1:], rtol=1e-12)
+    # larger, multi-chunk count against the oracle
+    g = torch.Generator().manual_seed(2)
+    tt, ff = torch.randn(1000, 3, 228, generator=g), torch.randn(1000, 3, 228, generator=g)
+    sc = math_utils.Scores(tt.to(DEV), ff.to(DEV))
+    for s in (0, 1):
+        for n in (0, 1):
+            want = do.evaluate(tt.numpy(), ff.numpy().astype(np.float64), by_step=bool(s), by_node=bool(n))
+            for a, b in zip(sc.get(bool(s), bool(n)), want):
+                np.testing.assert_allclose(a, b, rtol=1e-12)
+
+
+class StubModel(torch.nn.Module):
+    def __init__(self, L):
+        super().__init__()
+        self.L = L
+
+    def forward(self, x):
+        W = x.shape[1]
+        return torch.stack([0.5 * x[:, W - 1 - j, :] + 0.25 for j in range(self.L)], dim=1), None
+
+
+def test_rolling_inference_matches_reference_bitwise():
+    from stemgnn_amd import handler
+    from stemgnn_amd.forecast_dataloader import ForecastDataset, WindowLoader
+    z = G("rolling")
+    T, N, W, horizon, L, bs = (int(v) for v in z["cfg"])
+    ds = ForecastDataset(z["raw"], W, horizon, normalize_method="z_score", device=DEV)
+    f, t = handler.inference(StubModel(L), WindowLoader(ds, batch_size=bs), DEV, N, W, horizon)
+    np.testing.assert_array_equal(f.cpu().numpy().astype(np.float64), z["forecast"])
+    np.testing.assert_array_equal(t.cpu().numpy(), z["target"])
+    with pytest.raises(Exception):                                                   # L > W: the reference fails too
+        handler.inference(StubModel(W + 1), WindowLoader(ds, batch_size=bs), DEV, N, W, horizon)
+
+
+@pytest.mark.parametrize("shape", [(32, 3, 228), (5, 1, 7), (128, 12, 2048)])
+def test_mse_loss_matches_torch(shape):
+    from stemgnn_amd import ops
+    g = torch.Generator().manual_seed(4)
+    f = torch.randn(*shape, generator=g).to(DEV).requires_grad_(True)
+    y = torch.randn(*shape, generator=g).to(DEV)
+    loss = ops.MSELoss()(f, y)
+    (3.0 * loss).backward()
+    f64 = f.detach().double().cpu().requires_grad_(True)
+    ref = torch.nn.functional.mse_loss(f64, y.double().cpu())
+    (3.0 * ref).backward()
+    assert abs(float(loss) - float(ref)) <= 1e-6 * abs(float(ref))
+    assert float((f.grad.double().cpu() - f64.grad).abs().max()) <= 1e-6 * float(f64.grad.abs().max())
+    loss2 = ops.mse_loss(f.detach(), y)
+    assert float(loss2) == float(loss)                                               # fixed-order reduction
+
+
+@pytest.mark.parametrize("hipgraph", [True, False])
+def test_train_loop_reproduces_reference_run(tmp_path, hipgraph, monkeypatch):
+    """models/handler.py train(): the reference's own 3-epoch run (dropout 0, RMSProp, ExponentialLR every 2 epochs,
+    validation every epoch) replayed through the drop-in driver: same seed -> same initial weights and batch order;
+    per-step loss, validation metrics and the best checkpoint's weights agree to fp32 training drift."""
+    from stemgnn_amd import Model, handler
+    z = G("train_e2e")
+    T, N, W, H, multi, bs, epochs, ntrain = (int(v) for v in z["cfg"])
+    raw = z["raw"]
+    args = types.SimpleNamespace(window_size=W, horizon=H, multi_layer=multi, device=DEV, norm_method="z_score",
+                                 optimizer="RMSProp", lr=float(z["lr"]), decay_rate=0.5, exponential_decay_step=2,
+                                 batch_size=bs, epoch=epochs, validate_freq=1, early_stop=False, hipgraph=hipgraph)
+    losses, vals = [], []
+    real_validate = handler.validate
+
+    def logged_validate(*a, **k):
+        r = real_validate(*a, **k)
+        vals.append(r)
+        return r
+
+    monkeypatch.setattr(handler, "validate", logged_validate)
+    torch.manual_seed(0)
+    steppers = []
+
+    def hook(e, i, st):
+        losses.append(st.loss.clone())
+        steppers.append(st)
+
+    metrics, stat = handler.train(raw[:ntrain], raw[ntrain:], args, str(tmp_path),
+                                  model_factory=lambda *a, **k: Model(*a, dropout_rate=0.0, **k), step_hook=hook)
+    if hipgraph:
+        assert steppers[-1].mode.startswith("hipgraph"), steppers[-1].mode
+    got = torch.stack(losses).cpu().numpy().astype(np.float64)
+    np.testing.assert_allclose(got, z["losses"], rtol=1e-3)
+    np.testing.assert_allclose(stat["mean"], z["stat_mean"], rtol=0)
+    for e in range(epochs):
+        for k in ("mae", "mape", "rmse", "mae_node", "rmse_node"):
+            np.testing.assert_allclose(vals[e][k], z[f"val{e}_{k}"], rtol=2e-3, err_msg=f"epoch {e} {k}")
+    best = handler.load_model(str(tmp_path))
+    for k, v in best.state_dict().items():
+        ref = z["final." + k]
+        assert np.abs(v.cpu().numpy() - ref).max() <= 5e-3 * max(np.abs(ref).max(), 1e-6), k
+    for fn in ("target.csv", "predict.csv", "predict_abs_error.csv", "predict_ape.csv", "norm_stat.json", "2_stemgnn.pt"):
+        assert os.path.exists(os.path.join(str(tmp_path), fn)), fn
+    test_metrics = handler.test(raw[ntrain:], args, str(tmp_path), str(tmp_path / "test"))
+    np.testing.assert_allclose(test_metrics["mae"], vals[-1]["mae"], rtol=1e-6)       # same data, same best model
