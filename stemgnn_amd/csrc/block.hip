@@ -110,24 +110,43 @@ struct GftBwdDtOp {
 // 0-15 hold the linear_left result and lanes 16-31 the linear_right result of the SAME 16 channels, so one
 // cross-lane exchange (lane ^ 16) brings u and v together; left lanes store `out`, right lanes store the gate.
 struct GluFwdEpi {
+  static constexpr bool WHOLE = true;
   const float* bp[2];
   float* out[2];
   float* gate[2];
   int cp[2];
-  __device__ void tile(int r, int, int row0, int col0, int M, int N, const sg_f32x16& acc, int lane) const {
-    const bool right = (lane & 16) != 0;
-    const int c = (col0 >> 1) + (lane & 15);
-    const bool live = col0 < N;
-    const float bl = live ? bp[r][col0 + (lane & 15)] : 0.f, br = live ? bp[r][col0 + 16 + (lane & 15)] : 0.f;
-    float* dst = right ? gate[r] : out[r];
+  // one wave's 64 x 64 accumulator block = 2 row groups x 2 pair-column subtiles (16 left | 16 right each).  Every
+  // lane forms u, v and sigmoid(v) of its channel for BOTH subtiles (one lane^16 exchange each), then lanes 0-15
+  // store subtile 0 and lanes 16-31 subtile 1: each store instruction writes 32 consecutive channels (128 B) per row
+  // instead of two 64-byte pieces.
+  __device__ void whole(int r, int, int row0, int col0, int M, int N, const sg_f32x16 (&acc)[2][2], int lane) const {
+    const bool hi = (lane & 16) != 0;
+    const int k = lane & 15;
+    const bool live0 = col0 < N, live1 = col0 + 32 < N;
+    const float* b = bp[r];
+    const float bl0 = live0 ? b[col0 + k] : 0.f, br0 = live0 ? b[col0 + 16 + k] : 0.f;
+    const float bl1 = live1 ? b[col0 + 32 + k] : 0.f, br1 = live1 ? b[col0 + 48 + k] : 0.f;
+    const bool live = hi ? live1 : live0;
+    const int c = (col0 >> 1) + (lane & 31);
+    float* po = out[r] + c;
+    float* pg = gate[r] + c;
+    const int ld = cp[r];
 #pragma unroll
-    for (int reg = 0; reg < 16; ++reg) {
-      const float mine = acc[reg];
-      const float other = __shfl_xor(mine, 16, 64);
-      const float u = (right ? other : mine) + bl, v = (right ? mine : other) + br;
-      const float g = sg_sigmoid(v);
-      const int row = row0 + g2_row_of(reg, lane);
-      if (live && row < M) dst[(size_t)row * cp[r] + c] = right ? g : u * g;
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const float m0 = acc[i][0][reg], m1 = acc[i][1][reg];
+        const float o0 = __shfl_xor(m0, 16, 64), o1 = __shfl_xor(m1, 16, 64);
+        // subtile 0 is stored by the low half (it holds the left value itself), subtile 1 by the high half
+        const float u = hi ? o1 + bl1 : m0 + bl0;
+        const float v = hi ? m1 + br1 : o0 + br0;
+        const float g = sg_sigmoid(v);
+        const int row = row0 + i * 32 + g2_row_of(reg, lane);
+        if (live && row < M) {
+          po[(size_t)row * ld] = u * g;
+          pg[(size_t)row * ld] = g;
+        }
+      }
     }
   }
 };
@@ -135,23 +154,54 @@ struct GluFwdEpi {
 // data gradient of layer l -> d(pre-activation) of layer l-1 in pair order:
 //   d = dX[row][c];  left: d * gate ; right: d * out * (1 - gate)       (GLU backward)
 struct GluDpreEpi {
+  static constexpr bool WHOLE = true;
   const float* out[2];
   const float* gate[2];
   float* dpre[2];
   int cp;      // channels of layer l-1 (= N), its pair panel is 2*cp wide
-  __device__ void tile(int r, int, int row0, int col0, int M, int N, const sg_f32x16& acc, int lane) const {
-    const int c = col0 + (lane & 31);
-    if (c >= N) return;
-    const int q = ((c >> 4) << 5) + (c & 15);
+  // 32 channels of a subtile map to 64 consecutive pair columns [L16 R16 | L16 R16].  After one lane^16 exchange
+  // (low half sends its right value, high half its left value) instruction 1 writes the first 32 and instruction 2
+  // the second 32 of them: 128 contiguous bytes per row each.  The saved out / gate of a whole row group (2
+  // subtiles) are loaded up front so one memory round trip covers 64 values.
+  __device__ void whole(int r, int, int row0, int col0, int M, int N, const sg_f32x16 (&acc)[2][2], int lane) const {
+    const bool hi = (lane & 16) != 0;
+    const float* po = out[r];
+    const float* pg = gate[r];
+    float* pd = dpre[r];
 #pragma unroll
-    for (int reg = 0; reg < 16; ++reg) {
-      const int row = row0 + g2_row_of(reg, lane);
-      if (row < M) {
-        const size_t o = (size_t)row * cp + c;
-        const float d = acc[reg], g = gate[r][o], y = out[r][o];
-        float* dp = dpre[r] + (size_t)row * 2 * cp + q;
-        dp[0] = d * g;
-        dp[16] = d * y * (1.f - g);
+    for (int i = 0; i < 2; ++i) {
+      float y[2][16], g[2][16];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int c = col0 + j * 32 + (lane & 31);
+        const bool cl = c < N;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+          const int row = row0 + i * 32 + g2_row_of(reg, lane);
+          const size_t o = (size_t)(row < M ? row : 0) * cp + (cl ? c : 0);
+          y[j][reg] = po[o];
+          g[j][reg] = pg[o];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int cb = col0 + j * 32;                       // first channel of the subtile
+        const bool cl = cb + (lane & 31) < N;               // N % 16 == 0: a 16-channel half is live or dead as a whole
+        const bool cl_lo = cb < N, cl_hi = cb + 16 < N;
+        float* dp = pd + 2 * cb + (lane & 31);
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+          const int row = row0 + i * 32 + g2_row_of(reg, lane);
+          const float d = acc[i][j][reg];
+          const float left = d * g[j][reg], right = d * y[j][reg] * (1.f - g[j][reg]);
+          const float recv = __shfl_xor(hi ? left : right, 16, 64);
+          if (row < M) {
+            float* q = dp + (size_t)row * 2 * cp;
+            if (cl_lo) q[0] = hi ? recv : left;             // [L(cb..cb+15) | R(cb..cb+15)]
+            if (cl_hi) q[32] = hi ? right : recv;           // [L(cb+16..) | R(cb+16..)]
+          }
+          (void)cl;
+        }
       }
     }
   }
