@@ -408,6 +408,26 @@ __global__ __launch_bounds__(1024) void gru_bwd_cluster_kernel(const float* __re
 __device__ __forceinline__ float gru_bcast(float v, int src_lane) {     // wave broadcast of lane src_lane (constant)
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src_lane));
 }
+// mat-vec slice of one wave: lane = output unit, KU (even, >= the slice length) broadcast values.  Two k's per
+// v_pk_fma_f32 (weights in a VGPR pair, the two broadcast h values in an SGPR pair): 1.5 instructions per k instead
+// of 2, and the loop stops at KU instead of 64 -- the recurrence step is VALU- and exchange-latency bound.
+typedef float gru_f2 __attribute__((ext_vector_type(2)));
+template <int KU>
+__device__ __forceinline__ float gru_matvec(const gru_f2 (&wr)[32], float hv) {
+  gru_f2 a0 = {0.f, 0.f}, a1 = {0.f, 0.f};
+#pragma unroll
+  for (int kk = 0; kk + 3 < KU; kk += 4) {
+    const gru_f2 h0 = {gru_bcast(hv, kk), gru_bcast(hv, kk + 1)};
+    const gru_f2 h1 = {gru_bcast(hv, kk + 2), gru_bcast(hv, kk + 3)};
+    a0 = __builtin_elementwise_fma(wr[kk >> 1], h0, a0);
+    a1 = __builtin_elementwise_fma(wr[(kk >> 1) + 1], h1, a1);
+  }
+  if constexpr ((KU & 3) != 0) {
+    const gru_f2 h0 = {gru_bcast(hv, KU - 2), gru_bcast(hv, KU - 1)};
+    a0 = __builtin_elementwise_fma(wr[(KU - 2) >> 1], h0, a0);
+  }
+  return (a0.x + a1.x) + (a0.y + a1.y);
+}
 __device__ __forceinline__ float gru_poll_lane(const gru_u64* g, unsigned tag, bool active, int* status) {
   float v = 0.f;
   if (active) v = gru_consume(g, tag, status);
@@ -415,7 +435,7 @@ __device__ __forceinline__ float gru_poll_lane(const gru_u64* g, unsigned tag, b
 }
 
 // forward.  LDS: part[2][3*P][64]
-template <int P>
+template <int P, int KU>
 __global__ __launch_bounds__(3 * P * 64) void gru_fwd_cluster2_kernel(const float* __restrict__ gi, const float* __restrict__ w_hh,
                                                                       const float* __restrict__ b_hh, int B, int S, int Hd,
                                                                       gru_u64* __restrict__ xbuf, int* __restrict__ status,
@@ -431,14 +451,14 @@ __global__ __launch_bounds__(3 * P * 64) void gru_fwd_cluster2_kernel(const floa
   const int u0 = p * U, un = max(0, min(Hd, u0 + U) - u0);
   const int k0 = q * U, kn = max(0, min(Hd, k0 + U) - k0);
   const int H3 = 3 * Hd;
-  float wr[64];
+  gru_f2 wr[32];
   {
     const bool lane_ok = lane < un;
     const float* wrow = w_hh + ((size_t)g * Hd + (lane_ok ? u0 + lane : 0)) * Hd + (kn > 0 ? k0 : 0);
 #pragma unroll
-    for (int kk = 0; kk < 64; ++kk) {
+    for (int kk = 0; kk < KU; ++kk) {
       const float v = wrow[kk < kn ? kk : 0];
-      wr[kk] = (lane_ok && kk < kn) ? v : 0.f;
+      wr[kk >> 1][kk & 1] = (lane_ok && kk < kn) ? v : 0.f;
     }
   }
   const int gu = u0 + (tid < un ? tid : 0);            // gate-phase unit of this thread (wave 0 only)
@@ -452,13 +472,7 @@ __global__ __launch_bounds__(3 * P * 64) void gru_fwd_cluster2_kernel(const floa
     float hv = 0.f;
     if (s > 0) hv = gru_poll_lane(xbuf + ((size_t)(s & 1) * B + b) * Hd + k0 + (lane < kn ? lane : 0), (unsigned)s,
                                   lane < kn, status);
-    float a0 = 0.f, a1 = 0.f;
-#pragma unroll
-    for (int kk = 0; kk < 64; kk += 2) {
-      a0 = fmaf(wr[kk], gru_bcast(hv, kk), a0);
-      a1 = fmaf(wr[kk + 1], gru_bcast(hv, kk + 1), a1);
-    }
-    part[s & 1][wave][lane] = a0 + a1;
+    part[s & 1][wave][lane] = gru_matvec<KU>(wr, hv);
     __syncthreads();
     if (tid < un) {
       float g0 = bh0, g1 = bh1, g2 = bh2;
@@ -482,7 +496,7 @@ __global__ __launch_bounds__(3 * P * 64) void gru_fwd_cluster2_kernel(const floa
 }
 
 // backward.  LDS: part[2][3*P][64].  Wave (g, q): reduction slice j = g*Hd + units of owner q.
-template <int P>
+template <int P, int KU>
 __global__ __launch_bounds__(3 * P * 64) void gru_bwd_cluster2_kernel(const float* __restrict__ dout, const float* __restrict__ w_hh,
                                                                       const float* __restrict__ h_all,
                                                                       const float* __restrict__ reserve, int B, int S, int Hd,
@@ -499,14 +513,14 @@ __global__ __launch_bounds__(3 * P * 64) void gru_bwd_cluster2_kernel(const floa
   const int u0 = p * U, un = max(0, min(Hd, u0 + U) - u0);
   const int k0 = q * U, kn = max(0, min(Hd, k0 + U) - k0);
   const int H3 = 3 * Hd;
-  float wr[64];
+  gru_f2 wr[32];
   {
     const bool lane_ok = lane < un;
     const float* wcol = w_hh + ((size_t)g * Hd + (kn > 0 ? k0 : 0)) * Hd + (lane_ok ? u0 + lane : 0);
 #pragma unroll
-    for (int kk = 0; kk < 64; ++kk) {
+    for (int kk = 0; kk < KU; ++kk) {
       const float v = wcol[(size_t)(kk < kn ? kk : 0) * Hd];
-      wr[kk] = (lane_ok && kk < kn) ? v : 0.f;
+      wr[kk >> 1][kk & 1] = (lane_ok && kk < kn) ? v : 0.f;
     }
   }
   const int gu = u0 + (tid < un ? tid : 0);
@@ -551,13 +565,7 @@ __global__ __launch_bounds__(3 * P * 64) void gru_bwd_cluster2_kernel(const floa
     }
     if (s == 0) break;
     const float dv = gru_poll_lane(xb + (size_t)g * Hd + k0 + (lane < kn ? lane : 0), tag, lane < kn, status);
-    float a0 = 0.f, a1 = 0.f;
-#pragma unroll
-    for (int kk = 0; kk < 64; kk += 2) {
-      a0 = fmaf(wr[kk], gru_bcast(dv, kk), a0);
-      a1 = fmaf(wr[kk + 1], gru_bcast(dv, kk + 1), a1);
-    }
-    part[tag & 1][wave][lane] = a0 + a1;
+    part[tag & 1][wave][lane] = gru_matvec<KU>(wr, dv);
     __syncthreads();
   }
 }
@@ -641,6 +649,10 @@ static int gru_pick_P2(int B, int Hd) {
   }
   return 0;
 }
+static int gru_pick_KU(int Hd, int P) {              // unrolled mat-vec length: smallest instantiation >= the slice
+  const int U = (Hd + P - 1) / P;
+  return U <= 32 ? 32 : (U <= 48 ? 48 : (U <= 58 ? 58 : 64));
+}
 static size_t gru_xbuf_floats(int B, int Hd) { return (size_t)2 * 2 * B * 3 * Hd + 2; }   // u64 granules, 2 parities
 
 extern "C" size_t stemgnn_gru_fwd_scratch_floats(int B, int S, int Hd) {
@@ -669,10 +681,14 @@ extern "C" int stemgnn_gru_fwd(const float* x, const float* w_ih, const float* w
     gru_u64* xbuf = (gru_u64*)(scratch + ((((size_t)3 * Hd * Hd + (size_t)3 * S * B * Hd) + 1) & ~(size_t)1));
     SG_TRY(hipMemsetAsync(xbuf, 0, (size_t)2 * B * Hd * sizeof(gru_u64), st));      // tags := 0 before every launch
     const dim3 grid(8 * ((B + 7) / 8) * P2);
-#define GRU_F2(PP) hipLaunchKernelGGL(gru_fwd_cluster2_kernel<PP>, grid, dim3(3 * PP * 64), 0, st, gi, w_hh, b_hh, B, S, Hd, \
-                                      xbuf, status, h_all, reserve)
+#define GRU_F2K(PP, KK) hipLaunchKernelGGL((gru_fwd_cluster2_kernel<PP, KK>), grid, dim3(3 * PP * 64), 0, st, gi, w_hh, b_hh, \
+                                           B, S, Hd, xbuf, status, h_all, reserve)
+#define GRU_F2(PP) do { if (KU2 == 32) GRU_F2K(PP, 32); else if (KU2 == 48) GRU_F2K(PP, 48); \
+                        else if (KU2 == 58) GRU_F2K(PP, 58); else GRU_F2K(PP, 64); } while (0)
+    const int KU2 = gru_pick_KU(Hd, P2);
     if (P2 == 1) GRU_F2(1); else if (P2 == 2) GRU_F2(2); else if (P2 == 4) GRU_F2(4); else GRU_F2(5);
 #undef GRU_F2
+#undef GRU_F2K
     SG_TRY(hipGetLastError());
     return 0;
   }
@@ -718,10 +734,14 @@ extern "C" int stemgnn_gru_bwd(const float* dh_all, const float* x, const float*
     gru_u64* xbuf = (gru_u64*)(scratch + ((((size_t)(p_ih - scratch) + (size_t)GRU_NSPLIT * 3 * Hd * (W + 1)) + 1) & ~(size_t)1));
     SG_TRY(hipMemsetAsync(xbuf, 0, (size_t)2 * B * 3 * Hd * sizeof(gru_u64), st));
     const dim3 grid(8 * ((B + 7) / 8) * P2);
-#define GRU_B2(PP) hipLaunchKernelGGL(gru_bwd_cluster2_kernel<PP>, grid, dim3(3 * PP * 64), 0, st, dh_all, w_hh, h_all, reserve, \
-                                      B, S, Hd, xbuf, status, dgi, dghn)
+#define GRU_B2K(PP, KK) hipLaunchKernelGGL((gru_bwd_cluster2_kernel<PP, KK>), grid, dim3(3 * PP * 64), 0, st, dh_all, w_hh, h_all, \
+                                           reserve, B, S, Hd, xbuf, status, dgi, dghn)
+#define GRU_B2(PP) do { if (KU2 == 32) GRU_B2K(PP, 32); else if (KU2 == 48) GRU_B2K(PP, 48); \
+                        else if (KU2 == 58) GRU_B2K(PP, 58); else GRU_B2K(PP, 64); } while (0)
+    const int KU2 = gru_pick_KU(Hd, P2);
     if (P2 == 1) GRU_B2(1); else if (P2 == 2) GRU_B2(2); else if (P2 == 4) GRU_B2(4); else GRU_B2(5);
 #undef GRU_B2
+#undef GRU_B2K
     SG_TRY(hipGetLastError());
   } else if (P > 0) {
     const GruCluster c = gru_cluster_geom(Hd, P);
