@@ -392,54 +392,45 @@ struct Da3Op {  // z = branch: d(last GLU out)[m][c] = sum_o dig[m][o] Wfold[rof
 
 // weight gradients of the heads + Wfold, z = which*S + split
 struct HeadsWgradOp {
-  const float *dfo, *fs, *dpF, *ig, *dpB, *dig;
-  const float* a3[2];
-  int cp2[2];
-  XView X;
-  float *pFR, *pF, *pBC, *pBS, *pWf;
-  int M, W, Wm, WmP, KF, S, chunk, has_bc;
+  // five independent weight-gradient reductions over the M rows, each split S ways: z = which * S + split.
+  // Every operand access is a branch-free "descriptor" load (pointer / stride selected per `which`, uniform, read
+  // unconditionally so the reads hoist out of the tile loops): a switch -- or a pointer select whose arms read the
+  // descriptor -- puts each element's load in its own basic block with scalar reloads and serialises the tile.
+  //   A(i,k) = sign * (i < split ? pa0[k*lda0 + i] : pa1[k*lda1 + i - split])
+  //   B(k,j) = j < nb ? pb[(k / rdiv) * sb + (k % rdiv) * sn + j * st] : 1       (ones column = bias gradient)
+  const float *pa0[5], *pa1[5];
+  int lda0[5], lda1[5], split[5], Mw[5], Nw[5], nb[5], rdiv[5], ldp[5], on[5];
+  float sign[5];
+  const float* pb[5];
+  long sb[5], sn[5], st[5];
+  float* part[5];
+  int M, S, chunk;
   __device__ bool setup(int z, int& M_, int& N_, int& K0, int& K1) const {
     const int which = z / S, s = z - which * S;
     K0 = s * chunk; K1 = min(M, K0 + chunk);
-    switch (which) {
-      case 0: M_ = W; N_ = Wm + 1; break;
-      case 1: M_ = Wm; N_ = Wm + 1; break;
-      case 2: M_ = W; N_ = Wm + 1; return has_bc != 0;
-      case 3: M_ = W; N_ = W + 1; return has_bc != 0;
-      default: M_ = KF; N_ = Wm; break;
-    }
-    return true;
+    M_ = Mw[which]; N_ = Nw[which];
+    return on[which] != 0;
   }
   __device__ float a(int z, int i, int k) const {
-    switch (z / S) {
-      case 0: return dfo[(size_t)k * W + i];
-      case 1: return dpF[(size_t)k * Wm + i];
-      case 2: return dpB[(size_t)k * W + i];
-      case 3: return -dpB[(size_t)k * W + i];
-      default: {
-        const float* p = i < cp2[0] ? a3[0] + (size_t)k * cp2[0] + i : a3[1] + (size_t)k * cp2[1] + (i - cp2[0]);
-        return *p;
-      }
-    }
+    const int w = z / S;
+    const float *p0 = pa0[w], *p1 = pa1[w];
+    const int l0 = lda0[w], l1 = lda1[w], sp = split[w];
+    const float sg = sign[w];
+    const bool lo = i < sp;
+    const float* base = lo ? p0 : p1;
+    const size_t off = (size_t)k * (lo ? l0 : l1) + (lo ? i : i - sp);
+    return sg * base[off];
   }
   __device__ float b(int z, int k, int j) const {
-    switch (z / S) {
-      case 0: { const float v = fs[(size_t)k * Wm + (j < Wm ? j : Wm - 1)]; return j < Wm ? v : 1.f; }
-      case 1:
-      case 2: { const float v = ig[(size_t)k * Wm + (j < Wm ? j : Wm - 1)]; return j < Wm ? v : 1.f; }
-      case 3: { const float v = X.row(k, j < W ? j : W - 1); return j < W ? v : 1.f; }
-      default: return dig[(size_t)k * Wm + j];
-    }
+    const int w = z / S;
+    const int n = nb[w];
+    const int kb = k / rdiv[w], kr = k - kb * rdiv[w];
+    const float v = pb[w][kb * sb[w] + kr * sn[w] + (j < n ? j : n - 1) * st[w]];
+    return j < n ? v : 1.f;
   }
   __device__ void epi(int z, int i, int j, float v) const {
-    const int which = z / S, s = z - which * S;
-    switch (which) {
-      case 0: pFR[((size_t)s * W + i) * (Wm + 1) + j] = v; break;
-      case 1: pF[((size_t)s * Wm + i) * (Wm + 1) + j] = v; break;
-      case 2: pBC[((size_t)s * W + i) * (Wm + 1) + j] = v; break;
-      case 3: pBS[((size_t)s * W + i) * (W + 1) + j] = v; break;
-      default: pWf[((size_t)s * KF + i) * WmP + j] = v; break;
-    }
+    const int w = z / S, s = z - w * S;
+    part[w][((size_t)s * Mw[w] + i) * ldp[w] + j] = v;
   }
 };
 
@@ -552,7 +543,7 @@ extern "C" int stemgnn_spectral_glu_bwd(const float* packed, const float* saved,
       GluDgrad0Op op;
       for (int r = 0; r < 2; ++r) { op.dpre[r] = scratch + C.dact[r][slot]; op.wp[r] = packed + P.w[r][0]; }
       op.dG = scratch + C.dG; op.np0 = sg_glu_np(d, 0, 0); op.KG = d.KG; op.M = d.M;
-      SG_TRY((sg_launch_gemm<GluDgrad0Op, 32, 64, true, true, false>(op, d.M, d.KG, 1, st)));
+      SG_TRY((sg_launch_gemm<GluDgrad0Op, 32, 64, true, true, false, 64>(op, d.M, d.KG, 1, st)));
     }
   }
   return 0;
@@ -637,15 +628,25 @@ extern "C" int stemgnn_igft_heads_bwd(const float* const* params_host, const flo
   }
   if (parts & 2) {
     HeadsWgradOp op;
-    op.dfo = dforecast; op.fs = saved + S.fs; op.dpF = dpF; op.ig = saved + S.ig; op.dpB = dpB; op.dig = dig;
-    for (int r = 0; r < 2; ++r) { op.a3[r] = saved + S.out[r][2]; op.cp2[r] = d.CP2[r]; }
-    op.X = XView{X, xs_b, xs_n, xs_t, N};
-    op.pFR = gradpart + Gl.fr; op.pF = gradpart + Gl.fc; op.pBC = gradpart + Gl.bc; op.pBS = gradpart + Gl.bs;
-    op.pWf = gradpart + Gl.wfold;
-    op.M = d.M; op.W = W; op.Wm = d.Wm; op.WmP = d.WmP; op.KF = d.KF; op.S = nsplit;
-    op.chunk = split_chunk(d.M, nsplit); op.has_bc = has_bc;
+    const float* a3[2] = {saved + S.out[0][2], saved + S.out[1][2]};
+    const int huge = 1 << 30;
+    auto set = [&](int w, const float* A0, int lda, int rows, float sg, const float* Bp, int ldb, int ncolB, float* part,
+                   int ldp, int enabled) {
+      op.pa0[w] = A0; op.pa1[w] = A0; op.lda0[w] = lda; op.lda1[w] = lda; op.split[w] = huge; op.Mw[w] = rows;
+      op.Nw[w] = ldp; op.nb[w] = ncolB; op.rdiv[w] = huge; op.ldp[w] = ldp; op.on[w] = enabled; op.sign[w] = sg;
+      op.pb[w] = Bp; op.sb[w] = 0; op.sn[w] = ldb; op.st[w] = 1; op.part[w] = part;
+    };
+    // FR: dfo^T [fs | 1]; F: dpF^T [ig | 1]; BC: dpB^T [ig | 1]; BS: -dpB^T [X | 1]; Wfold: [Re3 | Im3]^T dig
+    set(0, dforecast, W, W, 1.f, saved + S.fs, d.Wm, d.Wm, gradpart + Gl.fr, d.Wm + 1, 1);
+    set(1, dpF, d.Wm, d.Wm, 1.f, saved + S.ig, d.Wm, d.Wm, gradpart + Gl.fc, d.Wm + 1, 1);
+    set(2, dpB, W, W, 1.f, saved + S.ig, d.Wm, d.Wm, gradpart + Gl.bc, d.Wm + 1, has_bc);
+    set(3, dpB, W, W, -1.f, X, 0, W, gradpart + Gl.bs, W + 1, has_bc);
+    op.rdiv[3] = N; op.sb[3] = xs_b; op.sn[3] = xs_n; op.st[3] = xs_t;
+    set(4, a3[0], d.CP2[0], d.KF, 1.f, dig, d.Wm, d.Wm, gradpart + Gl.wfold, d.WmP, 1);
+    op.pa1[4] = a3[1]; op.lda1[4] = d.CP2[1]; op.split[4] = d.CP2[0]; op.Nw[4] = d.Wm;
+    op.M = d.M; op.S = nsplit; op.chunk = split_chunk(d.M, nsplit);
     const int maxM = d.KF > d.Wm ? d.KF : d.Wm;
-    SG_TRY((sg_launch_gemm<HeadsWgradOp, 64, 64, false, false, false>(op, maxM, d.Wm + 1, 5 * nsplit, st)));
+    SG_TRY((sg_launch_gemm<HeadsWgradOp, 64, 64, false, false, false, 64>(op, maxM, d.Wm + 1, 5 * nsplit, st)));
   }
   return 0;
 }

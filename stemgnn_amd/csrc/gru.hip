@@ -775,7 +775,7 @@ extern "C" int stemgnn_gru_bwd(const float* dh_all, const float* x, const float*
     SG_TRY((g2_launch<G2SlabEpi, false, false>(g, e, 2, st)));
   }
   GruWihGradOp o2{dgi, x, p_ih, B, S, Hd, W, GRU_NSPLIT, chunk};
-  SG_TRY((sg_launch_gemm<GruWihGradOp, 64, 32, false, false, false>(o2, 3 * Hd, W + 1, GRU_NSPLIT, st)));
+  SG_TRY((sg_launch_gemm<GruWihGradOp, 64, 32, false, false, false, 64>(o2, 3 * Hd, W + 1, GRU_NSPLIT, st)));
   {
     const size_t n = (size_t)3 * Hd * (Hd + 1);
     const size_t n0 = (size_t)2 * Hd * (Hd + 1), n1 = (size_t)Hd * (Hd + 1);
