@@ -231,8 +231,22 @@ __global__ __launch_bounds__(256) void sg_attention_bwd_kernel(
     const float mx = sg_lrelu(kv + qmax, alpha);
     const float inv = 1.f / rowsum[(size_t)b * N + i];
     const float* dA = dAB + (size_t)i * N;
+    // pass 1: p and the (dropout-masked) dp of the first 4 x 64 columns stay in registers for pass 2 (one exp and
+    // one Philox per element instead of two); columns >= 256 are recomputed
+    float pc[4], dc[4];
     float dot = 0.f;
-    for (int j = lane; j < N; j += 64) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int j = lane + 64 * t;
+      const int jj = j < N ? j : N - 1;
+      float p = expf(sg_lrelu(kv + q[jj], alpha) - mx) * inv;
+      float dp = dA[jj];
+      if (drop) dp = sg_keep(seed, offset, ((uint64_t)b * N + i) * N + jj, drop_p) ? dp * keep_scale : 0.f;
+      if (j >= N) { p = 0.f; dp = 0.f; }
+      pc[t] = p; dc[t] = dp;
+      dot += dp * p;
+    }
+    for (int j = lane + 256; j < N; j += 64) {
       const float p = expf(sg_lrelu(kv + q[j], alpha) - mx) * inv;
       float dp = dA[j];
       if (drop) dp = sg_keep(seed, offset, ((uint64_t)b * N + i) * N + j, drop_p) ? dp * keep_scale : 0.f;
@@ -240,7 +254,18 @@ __global__ __launch_bounds__(256) void sg_attention_bwd_kernel(
     }
     dot = sg_wave_sum(dot);
     float dk = 0.f;
-    for (int j = lane; j < N; j += 64) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int j = lane + 64 * t;
+      if (j < N) {
+        const float pre = kv + q[j];
+        const float de = pc[t] * (dc[t] - dot);
+        const float dpre = pre > 0.f ? de : alpha * de;
+        dk += dpre;
+        dq[j] += dpre;
+      }
+    }
+    for (int j = lane + 256; j < N; j += 64) {
       const float pre = kv + q[j];
       const float p = expf(sg_lrelu(pre, alpha) - mx) * inv;
       float dp = dA[j];

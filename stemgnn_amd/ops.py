@@ -53,7 +53,7 @@ def set_direct_grad(flag=True, overlap=False):
     global _DIRECT_GRAD, _OVERLAP_WGRAD
     _DIRECT_GRAD = bool(flag)
     _OVERLAP_WGRAD = bool(flag) and bool(overlap) and os.environ.get("STEMGNN_OVERLAP_WGRAD", "1") == "1"
-_NCHUNK = int(os.environ.get("STEMGNN_ATTN_CHUNKS", "4"))  # row chunks of the attention backward
+_NCHUNK = int(os.environ.get("STEMGNN_ATTN_CHUNKS", "16"))  # row chunks of the attention backward
 
 
 def _stream():
