@@ -649,6 +649,18 @@ static int gru_pick_P2(int B, int Hd) {
   }
   return 0;
 }
+// The backward recurrence is latency-bound and occupies one workgroup on B*P of the 256 CUs.  It reserves (almost)
+// the whole LDS of its CU so that no LDS-using kernel of another stream (the spectral blocks' weight-gradient
+// GEMMs, which ops.py overlaps with it) can become co-resident: those land on the idle CUs instead of filling the
+// memory queues of the CUs whose poll latency sets the step time.  STEMGNN_GRU_LDS_HOG=0 disables it.
+template <int P>
+static size_t gru_lds_hog(const void* fn) {
+  static const bool on = !(getenv("STEMGNN_GRU_LDS_HOG") && atoi(getenv("STEMGNN_GRU_LDS_HOG")) == 0);
+  if (!on) return 0;
+  const size_t bytes = (size_t)156 * 1024 - sizeof(float) * 2 * 3 * P * 64;
+  (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  return bytes;
+}
 static int gru_pick_KU(int Hd, int P) {              // unrolled mat-vec length: smallest instantiation >= the slice
   const int U = (Hd + P - 1) / P;
   return U <= 32 ? 32 : (U <= 48 ? 48 : (U <= 58 ? 58 : 64));
@@ -734,8 +746,9 @@ extern "C" int stemgnn_gru_bwd(const float* dh_all, const float* x, const float*
     gru_u64* xbuf = (gru_u64*)(scratch + ((((size_t)(p_ih - scratch) + (size_t)GRU_NSPLIT * 3 * Hd * (W + 1)) + 1) & ~(size_t)1));
     SG_TRY(hipMemsetAsync(xbuf, 0, (size_t)2 * B * 3 * Hd * sizeof(gru_u64), st));
     const dim3 grid(8 * ((B + 7) / 8) * P2);
-#define GRU_B2K(PP, KK) hipLaunchKernelGGL((gru_bwd_cluster2_kernel<PP, KK>), grid, dim3(3 * PP * 64), 0, st, dh_all, w_hh, h_all, \
-                                           reserve, B, S, Hd, xbuf, status, dgi, dghn)
+#define GRU_B2K(PP, KK) do { const size_t hog = gru_lds_hog<PP>((const void*)gru_bwd_cluster2_kernel<PP, KK>); \
+    hipLaunchKernelGGL((gru_bwd_cluster2_kernel<PP, KK>), grid, dim3(3 * PP * 64), hog, st, dh_all, w_hh, h_all, \
+                       reserve, B, S, Hd, xbuf, status, dgi, dghn); } while (0)
 #define GRU_B2(PP) do { if (KU2 == 32) GRU_B2K(PP, 32); else if (KU2 == 48) GRU_B2K(PP, 48); \
                         else if (KU2 == 58) GRU_B2K(PP, 58); else GRU_B2K(PP, 64); } while (0)
     const int KU2 = gru_pick_KU(Hd, P2);

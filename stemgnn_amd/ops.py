@@ -401,17 +401,26 @@ class SpectralHotPath(torch.autograd.Function):
         side = _side_stream(dev) if overlap else None
         main = torch.cuda.current_stream()
         keep = []
-        # one scratch / partial buffer for both blocks (a second set would push the backward working set past the
-        # 256 MB Infinity Cache and cost more than the overlap gains): block 1 runs in order, only block 0 -- the last
-        # one, whose weight gradients can hide under cheb/attention/GRU backward -- is forked to the side stream
-        scratch = torch.empty(n_scratch, device=dev, dtype=f32)
-        gradpart = torch.empty(n_gradpart, device=dev, dtype=f32)
-        for s in (1, 0):
-            dG = scratch[off_dG:]
+        # Scheduling of the weight-gradient work (heads + GLU weight-gradient GEMMs + un-packing), which feeds nothing
+        # downstream in the backward pass.  overlap: both blocks' weight gradients go to the side stream, block 0's
+        # first (it overlaps the cheb / attention chain), then block 1's, which then runs under the GRU recurrence
+        # (that kernel is latency-bound on half of the CUs and reserves its CUs' LDS, so the GEMMs land on the idle
+        # CUs); block 1 therefore keeps its own scratch / partial buffers until the join.  STEMGNN_DEFER_B1=0 keeps
+        # block 1's weight gradients in order on the main stream with one shared scratch (less memory).
+        defer_b1 = overlap and os.environ.get("STEMGNN_DEFER_B1", "1") == "1"
+        scratch0 = torch.empty(n_scratch, device=dev, dtype=f32)
+        gradpart0 = torch.empty(n_gradpart, device=dev, dtype=f32)
+        bufs = {0: (scratch0, gradpart0), 1: (scratch0, gradpart0)}
+        if defer_b1:
+            bufs[1] = (torch.empty(n_scratch, device=dev, dtype=f32), torch.empty(n_gradpart, device=dev, dtype=f32))
+
+        def stage_fns(s):
+            scratch, gradpart = bufs[s]
             parr = _lib.ptr_array(blocks[s])
             X, sb, sn, stt = xviews[s]
             has_bc = s == 0
             garr = _lib.ptr_array(grads[s])
+            keep.append((parr, garr))
 
             def heads(parts, stream):
                 _lib.check(lib.stemgnn_igft_heads_bwd(
@@ -429,16 +438,26 @@ class SpectralHotPath(torch.autograd.Function):
                     gradpart.data_ptr(), nsplit, tables.data_ptr(), garr, W, multi, int(has_bc), stream),
                     "block_unpack_grads")
 
-            if overlap and s == 0:
+            return heads, glu, unpack
+
+        for s in (1, 0):
+            scratch = bufs[s][0]
+            dG = scratch[off_dG:]
+            X, sb, sn, stt = xviews[s]
+            heads, glu, unpack = stage_fns(s)
+            if overlap and (s == 0 or defer_b1):
                 heads(1, st)
                 glu(1, st)
-                side.wait_stream(main)                       # fork: the data-gradient chain of this block is queued
-                with torch.cuda.stream(side):
-                    sst = side.cuda_stream
-                    heads(2, sst)
-                    glu(2, sst)
-                    unpack(sst)
-                keep.append((scratch, gradpart))            # alive until the join
+                if s == 0:
+                    side.wait_stream(main)                   # fork: every data-gradient chain is queued
+                    with torch.cuda.stream(side):
+                        sst = side.cuda_stream
+                        for ss in ((0, 1) if defer_b1 else (0,)):
+                            h2, g2, u2 = (heads, glu, unpack) if ss == 0 else stage_fns(1)
+                            h2(2, sst)
+                            g2(2, sst)
+                            u2(sst)
+                    keep.append(bufs)                        # alive until the join
             else:
                 heads(3, st)
                 glu(3, st)
