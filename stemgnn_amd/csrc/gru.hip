@@ -609,20 +609,29 @@ struct GruWihGradOp {
 };
 
 // out_w[j][k] = sum_z part[z][j][k], out_b[j] = sum_z part[z][j][cols]
-__global__ void gru_reduce_grad_kernel(const float* __restrict__ part, int nsplit, int rows, int cols,
-                                       float* __restrict__ out_w, float* __restrict__ out_b) {
+// fixed-order sum of the split slabs of up to 3 weight-gradient products in ONE launch (blockIdx.y = job)
+struct GruReduceJobs {
+  const float* part[3];
+  float* out_w[3];
+  float* out_b[3];
+  int rows[3], cols[3];
+};
+__global__ void gru_reduce_grad_kernel(const GruReduceJobs J, int nsplit) {
+  const int job = blockIdx.y;
+  const int rows = J.rows[job], cols = J.cols[job];
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t slab = (size_t)rows * (cols + 1);
   if (idx >= slab) return;
+  const float* part = J.part[job];
   float s = 0.f;
   for (int z = 0; z < nsplit; ++z) s += part[(size_t)z * slab + idx];
   const int j = (int)(idx / (cols + 1)), k = (int)(idx - (size_t)j * (cols + 1));
-  if (k < cols) out_w[(size_t)j * cols + k] = s;
-  else out_b[j] = s;
+  if (k < cols) J.out_w[job][(size_t)j * cols + k] = s;
+  else J.out_b[job][j] = s;
 }
 
 // =================================================================================================
-static const int GRU_NSPLIT = 16;
+static const int GRU_NSPLIT = 32;
 
 extern "C" size_t stemgnn_gru_reserve_floats(int B, int S, int Hd) { return (size_t)4 * S * B * Hd; }
 #include <stdlib.h>
@@ -790,20 +799,16 @@ extern "C" int stemgnn_gru_bwd(const float* dh_all, const float* x, const float*
   GruWihGradOp o2{dgi, x, p_ih, B, S, Hd, W, GRU_NSPLIT, chunk};
   SG_TRY((sg_launch_gemm<GruWihGradOp, 64, 32, false, false, false, 64>(o2, 3 * Hd, W + 1, GRU_NSPLIT, st)));
   {
-    const size_t n = (size_t)3 * Hd * (Hd + 1);
-    const size_t n0 = (size_t)2 * Hd * (Hd + 1), n1 = (size_t)Hd * (Hd + 1);
-    hipLaunchKernelGGL(gru_reduce_grad_kernel, dim3((unsigned)((n0 + 255) / 256)), dim3(256), 0, st, p_hh, GRU_NSPLIT,
-                       2 * Hd, Hd, dw_hh, db_hh);
-    SG_TRY(hipGetLastError());
-    hipLaunchKernelGGL(gru_reduce_grad_kernel, dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, st,
-                       p_hh + (size_t)GRU_NSPLIT * n0, GRU_NSPLIT, Hd, Hd, dw_hh + (size_t)2 * Hd * Hd, db_hh + 2 * Hd);
-    SG_TRY(hipGetLastError());
-    (void)n;
-  }
-  {
-    const size_t n = (size_t)3 * Hd * (W + 1);
-    hipLaunchKernelGGL(gru_reduce_grad_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p_ih, GRU_NSPLIT,
-                       3 * Hd, W, dw_ih, db_ih);
+    const size_t n0 = (size_t)2 * Hd * (Hd + 1);
+    GruReduceJobs J;
+    J.part[0] = p_hh; J.out_w[0] = dw_hh; J.out_b[0] = db_hh; J.rows[0] = 2 * Hd; J.cols[0] = Hd;
+    J.part[1] = p_hh + (size_t)GRU_NSPLIT * n0; J.out_w[1] = dw_hh + (size_t)2 * Hd * Hd; J.out_b[1] = db_hh + 2 * Hd;
+    J.rows[1] = Hd; J.cols[1] = Hd;
+    J.part[2] = p_ih; J.out_w[2] = dw_ih; J.out_b[2] = db_ih; J.rows[2] = 3 * Hd; J.cols[2] = W;
+    size_t nmax = n0;
+    const size_t n2 = (size_t)3 * Hd * (W + 1);
+    if (n2 > nmax) nmax = n2;
+    hipLaunchKernelGGL(gru_reduce_grad_kernel, dim3((unsigned)((nmax + 255) / 256), 3), dim3(256), 0, st, J, GRU_NSPLIT);
     SG_TRY(hipGetLastError());
   }
   return 0;
