@@ -186,7 +186,8 @@ int stemgnn_window_gather(const float* series, const long long* hi, float* x, fl
 /* nn.MSELoss(reduction='mean') of the driver (models/handler.py:140,162): loss[0] = mean((forecast-target)^2) with
  * a fixed-order two-stage reduction; bwd: dforecast = grad_loss[0] * 2 (forecast-target)/n. */
 size_t stemgnn_mse_scratch_floats(void);
-int stemgnn_mse_fwd(const float* forecast, const float* target, size_t n, float* scratch, float* loss, void* stream);
+int stemgnn_mse_fwd(const float* forecast, const float* target, size_t n, float* scratch, float* loss,
+                    double* loss_accum, void* stream);   /* loss_accum (may be NULL): device double, += loss */
 int stemgnn_mse_bwd(const float* forecast, const float* target, size_t n, const float* grad_loss, float* dforecast,
                     void* stream);
 /* one iteration of the rolling inference (models/handler.py:56-61), out of place: inputs_next = inputs shifted left

@@ -47,7 +47,7 @@ SIGNATURES = {
     "stemgnn_normalize_series": (c_int, [_P, _P, _P, c_int, _P, c_long, c_int, _P]),
     "stemgnn_window_gather": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_long, _P, _P]),
     "stemgnn_mse_scratch_floats": (c_size_t, []),
-    "stemgnn_mse_fwd": (c_int, [_P, _P, c_size_t, _P, _P, _P]),
+    "stemgnn_mse_fwd": (c_int, [_P, _P, c_size_t, _P, _P, _P, _P]),
     "stemgnn_mse_bwd": (c_int, [_P, _P, c_size_t, _P, _P, _P]),
     "stemgnn_roll_window": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "stemgnn_eval_scratch_doubles": (c_size_t, [c_long, c_int, c_int]),

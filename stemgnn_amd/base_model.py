@@ -18,7 +18,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import _lib
+from . import _lib, ops
 from .ops import FcTail, GruFront, SpectralHotPath, StockBlockFn
 
 _BLOCK_FIELDS = ("forecast", "forecast_result", "backcast", "backcast_short_cut")
@@ -124,6 +124,9 @@ class Model(nn.Module):
             raise _lib.StemGNNHipError(
                 f"input is on {x.device}: stemgnn_amd.Model runs only on a HIP device (no CPU fallback)")
         x = x.contiguous()
+        blocks = (self.stock_block[0].hip_params(), self.stock_block[1].hip_params())
+        if ops._OVERLAP_WGRAD:        # side-stream mode: the weight packing overlaps the GRU recurrence
+            ops.prepack_blocks(blocks, self.time_step, self.multi_layer, x.device)
         if os.environ.get("STEMGNN_GRU", "hip") == "miopen":       # library GRU (MIOpen) -- A/B and debugging only
             h, _ = self.GRU(x.permute(2, 0, 1).contiguous())      # [N_seq, B, N_hid]  (:137)
         else:                                                      # persistent HIP recurrence (csrc/gru.hip)
@@ -131,7 +134,7 @@ class Model(nn.Module):
             h = GruFront.apply(x, g.weight_ih_l0, g.weight_hh_l0, g.bias_ih_l0, g.bias_hh_l0)
         use_drop = self.training and self.dropout_rate > 0.0
         seed = self._next_seed(x.device) if use_drop else None
-        params = self.stock_block[0].hip_params() + self.stock_block[1].hip_params()
+        params = blocks[0] + blocks[1]
         return SpectralHotPath.apply(h, x, self.weight_key, self.weight_query, self.multi_layer, self.alpha,
                                      self.dropout_rate, self.training, seed, *params)
 

@@ -106,11 +106,16 @@ __global__ __launch_bounds__(MSE_THREADS) void sg_mse_partial_kernel(const float
   if (threadIdx.x == 0) part[blockIdx.x] = t;
 }
 
-__global__ void sg_mse_final_kernel(const float* __restrict__ part, int nparts, size_t n, float* __restrict__ loss) {
+__global__ void sg_mse_final_kernel(const float* __restrict__ part, int nparts, size_t n, float* __restrict__ loss,
+                                    double* __restrict__ accum) {
   float v = (int)threadIdx.x < nparts ? part[threadIdx.x] : 0.f;
   __shared__ float sm[MSE_BLOCKS / 64];
   const float t = sg_block_sum(v, sm);
-  if (threadIdx.x == 0) loss[0] = t / (float)n;
+  if (threadIdx.x == 0) {
+    const float l = t / (float)n;
+    loss[0] = l;
+    if (accum) accum[0] += (double)l;          // running epoch sum (handler.py:166 without the host sync)
+  }
 }
 
 __global__ void sg_mse_bwd_kernel(const float* __restrict__ f, const float* __restrict__ y, size_t n,
@@ -123,13 +128,13 @@ __global__ void sg_mse_bwd_kernel(const float* __restrict__ f, const float* __re
 extern "C" size_t stemgnn_mse_scratch_floats(void) { return MSE_BLOCKS; }
 
 extern "C" int stemgnn_mse_fwd(const float* forecast, const float* target, size_t n, float* scratch, float* loss,
-                               void* stream) {
+                               double* loss_accum, void* stream) {
   if (!forecast || !target || !scratch || !loss || n == 0) return SG_EINVAL;
   hipLaunchKernelGGL(sg_mse_partial_kernel, dim3(MSE_BLOCKS), dim3(MSE_THREADS), 0, (hipStream_t)stream, forecast,
                      target, n, scratch);
   SG_TRY(hipGetLastError());
   hipLaunchKernelGGL(sg_mse_final_kernel, dim3(1), dim3(MSE_BLOCKS), 0, (hipStream_t)stream, scratch, MSE_BLOCKS, n,
-                     loss);
+                     loss, loss_accum);
   SG_TRY(hipGetLastError());
   return 0;
 }

@@ -56,6 +56,7 @@ class TrainStep:
         self.y = torch.zeros(self.B, self.H, self.N, device=dev)
         self.loss = torch.zeros((), device=dev)
         self.loss_sum = torch.zeros((), device=dev, dtype=torch.float64)
+        self._one = torch.ones((), device=dev)
         self.want_graph = bool(graph) and self.fused
         self.mode = "eager"
         self._replay = None
@@ -71,14 +72,14 @@ class TrainStep:
             else:
                 self.model.zero_grad()                                  # handler.py:160
         forecast, _ = self.model(x)                                     # :161
-        loss = ops.mse_loss(forecast, y)                                # :162
-        loss.backward()                                                 # :164
-        return loss.detach()
+        # :162 -- the loss lands in the static scalar and is added to the epoch sum inside the reduction kernel
+        # (:166 without the per-step host sync or extra launches)
+        loss = ops.mse_loss(forecast, y, self.loss.detach(), self.loss_sum)   # fresh alias: no history chaining
+        torch.autograd.backward(loss, grad_tensors=(self._one,))        # :164 (pre-allocated d(loss) = 1)
+        return self.loss
 
     def _finish(self, loss):
         self.opt.step()                                                 # :165
-        self.loss.copy_(loss)
-        self.loss_sum.add_(loss.double())                               # :166, without the per-step host sync
 
     def _sync(self):
         if self.world > 1:
@@ -102,11 +103,9 @@ class TrainStep:
 
             def part_a():
                 box["loss"] = self._fwd_bwd(self.hi, self.x, self.y)
-                self.loss.copy_(box["loss"])
 
             def part_b():
                 self.opt.step()
-                self.loss_sum.add_(self.loss.double())
             snap = self._snapshot()
             ra = capture(part_a)
             rb = capture(part_b) if ra is not None else None

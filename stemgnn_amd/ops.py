@@ -293,6 +293,26 @@ class StockBlockFn(torch.autograd.Function):
         return (dX, dmul_L, None, None, *grads)
 
 
+_prepacked = {}
+
+
+def prepack_blocks(block_params, W, multi, device):
+    """Pack both blocks' weights (stemgnn_block_pack) on the side stream now, so that they overlap whatever the
+    caller queues next on the current stream (Model.hot_path: the GRU recurrence).  The next SpectralHotPath.forward
+    on this device picks the packed panels up and joins the side stream."""
+    lib = _lib.load()
+    side, main = _side_stream(device), torch.cuda.current_stream()
+    tables = dft_tables(W, multi, device)
+    n_packed = lib.stemgnn_packed_floats(W, multi)
+    blocks = [[None if p is None else p.contiguous() for p in blk] for blk in block_params]
+    packed = [torch.empty(n_packed, device=device, dtype=torch.float32) for _ in blocks]
+    side.wait_stream(main)
+    for blk, pk in zip(blocks, packed):
+        _lib.check(lib.stemgnn_block_pack(_lib.ptr_array(blk), tables.data_ptr(), pk.data_ptr(), W, multi,
+                                          side.cuda_stream), "block_pack")
+    _prepacked[str(device)] = (packed, side, blocks)
+
+
 class SpectralHotPath(torch.autograd.Function):
     """(h, x, weight_key, weight_query, 33 params of block 0, 33 params of block 1) ->
     (sum of the two block forecasts [B,N,W], attention [N,N], mul_L [4,N,N]).
@@ -340,15 +360,21 @@ class SpectralHotPath(torch.autograd.Function):
         fsum = torch.empty(B, N, W, device=dev, dtype=f32)
         backcast = torch.empty(B, N, W, device=dev, dtype=f32)
         packed, saved = [], []
+        pre = _prepacked.pop(str(dev), None)
+        if pre is not None:
+            torch.cuda.current_stream().wait_stream(pre[1])      # join the side-stream packing
         n_packed = lib.stemgnn_packed_floats(W, multi)
         n_saved = lib.stemgnn_saved_floats(B, N, W, multi)
         xviews = [(x, W * N, 1, N), (backcast, N * W, W, 1)]   # X[b,n,t] strides of block 0 / block 1
         for s in range(2):
-            pk = torch.empty(n_packed, device=dev, dtype=f32)
             sv = torch.empty(n_saved, device=dev, dtype=f32)
             parr = _lib.ptr_array(blocks[s])
             X, sb, sn, stt = xviews[s]
-            _lib.check(lib.stemgnn_block_pack(parr, tables.data_ptr(), pk.data_ptr(), W, multi, st), "block_pack")
+            if pre is not None:
+                pk = pre[0][s]
+            else:
+                pk = torch.empty(n_packed, device=dev, dtype=f32)
+                _lib.check(lib.stemgnn_block_pack(parr, tables.data_ptr(), pk.data_ptr(), W, multi, st), "block_pack")
             _lib.check(lib.stemgnn_gft_fwd(mul_L.data_ptr(), X.data_ptr(), sb, sn, stt, sv.data_ptr(), B, N, W, st),
                        "gft_fwd")
             _lib.check(lib.stemgnn_spectral_glu_fwd(pk.data_ptr(), sv.data_ptr(), B, N, W, multi, st),
@@ -363,6 +389,7 @@ class SpectralHotPath(torch.autograd.Function):
         ctx.blocks = blocks
         ctx.aux = (h, x, wk, wq, seed, tables, mul_L, attn_saved, backcast, packed, saved)
         ctx.mark_non_differentiable(attention, mul_L)
+        ctx.set_materialize_grads(False)
         return fsum, attention, mul_L
 
     @staticmethod
@@ -495,7 +522,9 @@ class MSELossFn(torch.autograd.Function):
     """nn.MSELoss(reduction='mean') of the driver (reference models/handler.py:140,162) as two fixed-order kernels."""
 
     @staticmethod
-    def forward(ctx, forecast, target):
+    def forward(ctx, forecast, target, loss_out=None, accum=None):
+        """loss_out: optional float32 scalar to write the loss into (a static buffer); accum: optional float64 device
+        scalar that receives `+= loss` inside the reduction kernel (epoch loss sum without extra launches)."""
         lib = _lib.load()
         _require_gpu(forecast, "forecast")
         _require_gpu(target, "target")
@@ -503,10 +532,16 @@ class MSELossFn(torch.autograd.Function):
             raise _lib.StemGNNHipError(f"MSE: shapes differ {tuple(forecast.shape)} vs {tuple(target.shape)}")
         forecast, target = forecast.contiguous(), target.contiguous()
         scratch = torch.empty(lib.stemgnn_mse_scratch_floats(), device=forecast.device, dtype=torch.float32)
-        loss = torch.empty((), device=forecast.device, dtype=torch.float32)
+        loss = loss_out if loss_out is not None else torch.empty((), device=forecast.device, dtype=torch.float32)
+        if accum is not None and (accum.dtype != torch.float64 or accum.device != forecast.device):
+            raise _lib.StemGNNHipError("MSE: accum must be a float64 scalar on the forecast's device")
         _lib.check(lib.stemgnn_mse_fwd(forecast.data_ptr(), target.data_ptr(), forecast.numel(), scratch.data_ptr(),
-                                       loss.data_ptr(), _stream()), "mse_fwd")
+                                       loss.data_ptr(), accum.data_ptr() if accum is not None else None, _stream()),
+                   "mse_fwd")
         ctx.save_for_backward(forecast, target)
+        ctx.set_materialize_grads(False)
+        if loss_out is not None:
+            ctx.mark_dirty(loss_out)
         return loss
 
     @staticmethod
@@ -517,11 +552,11 @@ class MSELossFn(torch.autograd.Function):
         dforecast = torch.empty_like(forecast)
         _lib.check(lib.stemgnn_mse_bwd(forecast.data_ptr(), target.data_ptr(), forecast.numel(), grad_loss.data_ptr(),
                                        dforecast.data_ptr(), _stream()), "mse_bwd")
-        return dforecast, None
+        return dforecast, None, None, None
 
 
-def mse_loss(forecast, target):
-    return MSELossFn.apply(forecast, target)
+def mse_loss(forecast, target, loss_out=None, accum=None):
+    return MSELossFn.apply(forecast, target, loss_out, accum)
 
 
 class MSELoss(torch.nn.Module):

@@ -99,7 +99,7 @@ def test_data_entry_points_reject_bad_arguments():
     assert lib.stemgnn_roll_window(p, p + 64, p, p + 192, 2, 4, 2, 3, 0, 5, None) == _lib.SG_EINVAL         # in place
     assert lib.stemgnn_window_gather(p, p, p, p, 2, 12, 3, 5, 10, None, None) == _lib.SG_EINVAL             # T < W+H
     assert lib.stemgnn_eval_metrics(p, p, p, None, 5, 3, 4, p, p, None) == _lib.SG_EINVAL                   # mul w/o add
-    assert lib.stemgnn_mse_fwd(None, p, 8, p, p, None) == _lib.SG_EINVAL
+    assert lib.stemgnn_mse_fwd(None, p, 8, p, p, None, None) == _lib.SG_EINVAL
     assert lib.stemgnn_normalize_series(p, p, p, 0, p, 0, 4, None) == _lib.SG_EINVAL
     assert lib.stemgnn_eval_out_doubles(3, 5) == 3 + 15 + 9 + 45
     assert lib.stemgnn_eval_scratch_doubles(130, 3, 5) == 3 * 15 * (3 + 1) + 15
