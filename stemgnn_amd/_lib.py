@@ -7,7 +7,7 @@ import os
 from ctypes import POINTER, c_char_p, c_float, c_int, c_long, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libstemgnn_hip.so")
+LIB_PATH = os.environ.get("STEMGNN_HIP_LIB", os.path.join(_HERE, "libstemgnn_hip.so"))   # override: A/B builds only
 SG_BLOCK_NPARAMS = 33
 SG_EINVAL = -10001
 

@@ -198,7 +198,9 @@ __device__ __forceinline__ float gru_consume(const gru_u64* g, unsigned tag, int
   gru_u64 x = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   unsigned spins = 0;
   while ((unsigned)(x >> 32) != tag) {
+#ifndef GRU_NO_SLEEP
     __builtin_amdgcn_s_sleep(1);
+#endif
     x = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (++spins > (1u << 22)) { atomicExch(status, 1); break; }   // partner not resident / lost: give up, flag it
   }
