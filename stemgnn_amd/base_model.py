@@ -125,15 +125,22 @@ class Model(nn.Module):
                 f"input is on {x.device}: stemgnn_amd.Model runs only on a HIP device (no CPU fallback)")
         x = x.contiguous()
         blocks = (self.stock_block[0].hip_params(), self.stock_block[1].hip_params())
-        if ops._OVERLAP_WGRAD:        # side-stream mode: the weight packing overlaps the GRU recurrence
-            ops.prepack_blocks(blocks, self.time_step, self.multi_layer, x.device)
+        use_drop = self.training and self.dropout_rate > 0.0
+        seed = None
+        if ops._OVERLAP_WGRAD:        # side-stream mode: weight packing and the dropout-stream bookkeeping (a clone and
+            ops.prepack_blocks(blocks, self.time_step, self.multi_layer, x.device)   # an increment) overlap the GRU
+            if use_drop and os.environ.get("STEMGNN_SEED_SIDE", "1") == "1":
+                with torch.cuda.stream(ops._side_stream(x.device)):
+                    seed = self._next_seed(x.device)
+                if not torch.cuda.is_current_stream_capturing():
+                    seed.record_stream(torch.cuda.current_stream())
         if os.environ.get("STEMGNN_GRU", "hip") == "miopen":       # library GRU (MIOpen) -- A/B and debugging only
             h, _ = self.GRU(x.permute(2, 0, 1).contiguous())      # [N_seq, B, N_hid]  (:137)
         else:                                                      # persistent HIP recurrence (csrc/gru.hip)
             g = self.GRU
             h = GruFront.apply(x, g.weight_ih_l0, g.weight_hh_l0, g.bias_ih_l0, g.bias_hh_l0)
-        use_drop = self.training and self.dropout_rate > 0.0
-        seed = self._next_seed(x.device) if use_drop else None
+        if use_drop and seed is None:
+            seed = self._next_seed(x.device)
         params = blocks[0] + blocks[1]
         return SpectralHotPath.apply(h, x, self.weight_key, self.weight_query, self.multi_layer, self.alpha,
                                      self.dropout_rate, self.training, seed, *params)

@@ -18,6 +18,7 @@
 
 constexpr int TAIL_MAXW = 64;    // window sizes up to 64 / horizons up to 32 keep a row in registers
 constexpr int TAIL_MAXH = 32;    // (fully unrolled, predicated loops: two instantiations, <16,4> and <64,32>)
+constexpr int TAIL_RB = 256;     // rows per backward workgroup: the fixed-order weight-gradient walk is TAIL_RB steps long
 
 // forward: one thread per series row m = (b, n).  LDS: w0[W*W] | b0[W] | w2[H*W] | b2[H]
 template <int WM, int HM>
@@ -77,10 +78,10 @@ __global__ __launch_bounds__(256) void sg_fc_tail_bwd_kernel(const float* __rest
   for (int i = threadIdx.x; i < H * W; i += 256) sw2[i] = w2[i];
   for (int i = threadIdx.x; i < nacc; i += 256) acc[i] = 0.f;
   __syncthreads();
-  const int m = blockIdx.x * 256 + threadIdx.x;
-  const bool live = m < B * N;
+  const int m = blockIdx.x * TAIL_RB + threadIdx.x;
+  const bool live = threadIdx.x < TAIL_RB && m < B * N;
   float x[WM], a[WM], dz[WM], dy[HM];
-  {
+  if (threadIdx.x < TAIL_RB) {            // one wave: a thread per series row
     const int mc = live ? m : 0;
     const int b = mc / N, n = mc - b * N;
 #pragma unroll
@@ -106,13 +107,13 @@ __global__ __launch_bounds__(256) void sg_fc_tail_bwd_kernel(const float* __rest
       if (live && u < W) dfsum[(size_t)m * W + u] = d;
     }
   }
-  // weight-gradient partials of this block's 256 rows: stage dz / x / a / dy rows in LDS (row stride odd -> no bank
+  // weight-gradient partials of this block's TAIL_RB rows: stage dz / x / a / dy rows in LDS (row stride odd -> no bank
   // conflicts), then one thread per weight element walks the rows in a fixed order (deterministic, no atomics)
-  float* sx = acc + nacc;                 // [256][W+1]
-  float* sdz = sx + 256 * (W + 1);        // [256][W+1]
-  float* sa = sdz + 256 * (W + 1);        // [256][W+1]
-  float* sdy = sa + 256 * (W + 1);        // [256][H+1]
-  {
+  float* sx = acc + nacc;                 // [RB][W+1]
+  float* sdz = sx + TAIL_RB * (W + 1);    // [RB][W+1]
+  float* sa = sdz + TAIL_RB * (W + 1);    // [RB][W+1]
+  float* sdy = sa + TAIL_RB * (W + 1);    // [RB][H+1]
+  if (threadIdx.x < TAIL_RB) {
     const int rr = threadIdx.x;
 #pragma unroll
     for (int t = 0; t < WM; ++t)
@@ -130,16 +131,16 @@ __global__ __launch_bounds__(256) void sg_fc_tail_bwd_kernel(const float* __rest
     float sum = 0.f;
     if (e < W * W) {
       const int t = e / W, u = e - t * W;
-      for (int rr = 0; rr < 256; ++rr) sum = fmaf(sdz[rr * (W + 1) + t], sx[rr * (W + 1) + u], sum);
+      for (int rr = 0; rr < TAIL_RB; ++rr) sum = fmaf(sdz[rr * (W + 1) + t], sx[rr * (W + 1) + u], sum);
     } else if (e < W * W + W) {
       const int t = e - W * W;
-      for (int rr = 0; rr < 256; ++rr) sum += sdz[rr * (W + 1) + t];
+      for (int rr = 0; rr < TAIL_RB; ++rr) sum += sdz[rr * (W + 1) + t];
     } else if (e < W * W + W + H * W) {
       const int q = e - W * W - W, h = q / W, t = q - h * W;
-      for (int rr = 0; rr < 256; ++rr) sum = fmaf(sdy[rr * (H + 1) + h], sa[rr * (W + 1) + t], sum);
+      for (int rr = 0; rr < TAIL_RB; ++rr) sum = fmaf(sdy[rr * (H + 1) + h], sa[rr * (W + 1) + t], sum);
     } else {
       const int h = e - W * W - W - H * W;
-      for (int rr = 0; rr < 256; ++rr) sum += sdy[rr * (H + 1) + h];
+      for (int rr = 0; rr < TAIL_RB; ++rr) sum += sdy[rr * (H + 1) + h];
     }
     partial[(size_t)blockIdx.x * nacc + e] = sum;
   }
@@ -160,13 +161,13 @@ __global__ void sg_fc_tail_reduce_kernel(const float* __restrict__ partial, int 
 
 static size_t fc_tail_bwd_lds(int W, int H) {
   const int nacc = W * W + W + H * W + H;
-  return (size_t)(W * W + W + H * W + nacc + 256 * (3 * (W + 1) + H + 1)) * sizeof(float);
+  return (size_t)(W * W + W + H * W + nacc + TAIL_RB * (3 * (W + 1) + H + 1)) * sizeof(float);
 }
 extern "C" int stemgnn_fc_tail_supported(int W, int H) {
   return W > 0 && H > 0 && W <= TAIL_MAXW && H <= TAIL_MAXH && fc_tail_bwd_lds(W, H) <= 150 * 1024;
 }
 extern "C" size_t stemgnn_fc_tail_scratch_floats(int B, int N, int W, int H) {
-  return (size_t)((B * N + 255) / 256) * (W * W + W + H * W + H);
+  return (size_t)((B * N + TAIL_RB - 1) / TAIL_RB) * (W * W + W + H * W + H);
 }
 
 extern "C" int stemgnn_fc_tail_fwd(const float* fsum, const float* w0, const float* b0, const float* w2, const float* b2,
@@ -192,7 +193,7 @@ extern "C" int stemgnn_fc_tail_bwd(const float* dforecast, const float* fsum, co
     return SG_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   const int nacc = W * W + W + H * W + H;
-  const int nblocks = (B * N + 255) / 256;
+  const int nblocks = (B * N + TAIL_RB - 1) / TAIL_RB;
   const size_t lds = fc_tail_bwd_lds(W, H);
   if (!stemgnn_fc_tail_supported(W, H)) return SG_EINVAL;
   static bool attr_done = false;
