@@ -119,7 +119,8 @@ struct GluFwdEpi {
   // lane forms u, v and sigmoid(v) of its channel for BOTH subtiles (one lane^16 exchange each), then lanes 0-15
   // store subtile 0 and lanes 16-31 subtile 1: each store instruction writes 32 consecutive channels (128 B) per row
   // instead of two 64-byte pieces.
-  __device__ void whole(int r, int, int row0, int col0, int M, int N, const sg_f32x16 (&acc)[2][2], int lane) const {
+  template <int NI>
+  __device__ void whole(int r, int, int row0, int col0, int M, int N, const sg_f32x16 (&acc)[NI][2], int lane) const {
     const bool hi = (lane & 16) != 0;
     const int k = lane & 15;
     const bool live0 = col0 < N, live1 = col0 + 32 < N;
@@ -132,7 +133,7 @@ struct GluFwdEpi {
     float* pg = gate[r] + c;
     const int ld = cp[r];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < NI; ++i) {
 #pragma unroll
       for (int reg = 0; reg < 16; ++reg) {
         const float m0 = acc[i][0][reg], m1 = acc[i][1][reg];
@@ -163,13 +164,14 @@ struct GluDpreEpi {
   // (low half sends its right value, high half its left value) instruction 1 writes the first 32 and instruction 2
   // the second 32 of them: 128 contiguous bytes per row each.  The saved out / gate of a whole row group (2
   // subtiles) are loaded up front so one memory round trip covers 64 values.
-  __device__ void whole(int r, int, int row0, int col0, int M, int N, const sg_f32x16 (&acc)[2][2], int lane) const {
+  template <int NI>
+  __device__ void whole(int r, int, int row0, int col0, int M, int N, const sg_f32x16 (&acc)[NI][2], int lane) const {
     const bool hi = (lane & 16) != 0;
     const float* po = out[r];
     const float* pg = gate[r];
     float* pd = dpre[r];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < NI; ++i) {
       float y[2][16], g[2][16];
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
@@ -437,6 +439,11 @@ struct HeadsWgradOp {
 // =================================================================================================
 // host side
 // =================================================================================================
+// which GLU GEMM families use 64-row tiles (more, smaller workgroups): bit 0 forward, 1 data gradient, 2 weight gradient
+static inline int g2_bm_mask() {
+  static const int m = getenv("STEMGNN_G2_BM64") ? atoi(getenv("STEMGNN_G2_BM64")) : 3;   // measured: 1.921 -> 1.890 ms/step
+  return m;
+}
 static inline int split_chunk(int M, int S) { return ((M + S - 1) / S + 15) & ~15; }
 
 extern "C" int stemgnn_gft_fwd(const float* mul_L, const float* X, long xs_b, long xs_n, long xs_t,
@@ -486,7 +493,8 @@ extern "C" int stemgnn_spectral_glu_fwd(const float* packed, float* saved, int B
       e.cp[r] = sg_glu_cp(d, l, r);
     }
     g.nsplit = 1; g.chunk = (sg_glu_kin(d, l) + 15) & ~15; g.b_ones_col = -1;
-    SG_TRY((g2_launch<GluFwdEpi, true, false>(g, e, 2, st)));
+    if (g2_bm_mask() & 1) SG_TRY((g2_launch<GluFwdEpi, true, false, 64>(g, e, 2, st)));
+    else SG_TRY((g2_launch<GluFwdEpi, true, false>(g, e, 2, st)));
   }
   return 0;
 }
@@ -520,7 +528,8 @@ extern "C" int stemgnn_spectral_glu_bwd(const float* packed, const float* saved,
         e.part[r] = gradpart + Gl.w[r][l];
       }
       g.nsplit = nsplit; g.chunk = chunk; g.b_ones_col = sg_glu_kin(d, l);
-      SG_TRY((g2_launch<GluWgradEpi, false, false>(g, e, 2, st)));
+      if (g2_bm_mask() & 4) SG_TRY((g2_launch<GluWgradEpi, false, false, 64>(g, e, 2, st)));
+      else SG_TRY((g2_launch<GluWgradEpi, false, false>(g, e, 2, st)));
     }
     if (!(parts & 1)) continue;
     if (l > 0) {  // data gradient -> d(pre-activation) of layer l-1
@@ -538,7 +547,8 @@ extern "C" int stemgnn_spectral_glu_bwd(const float* packed, const float* saved,
       }
       e.cp = d.CP;
       g.nsplit = 1; g.chunk = (2 * d.CP + 15) & ~15; g.b_ones_col = -1;
-      SG_TRY((g2_launch<GluDpreEpi, true, true>(g, e, 2, st)));
+      if (g2_bm_mask() & 2) SG_TRY((g2_launch<GluDpreEpi, true, true, 64>(g, e, 2, st)));
+      else SG_TRY((g2_launch<GluDpreEpi, true, true>(g, e, 2, st)));
     } else {      // layer 0: both branches feed the same G -> one launch with K = Re columns then Im columns
       GluDgrad0Op op;
       for (int r = 0; r < 2; ++r) { op.dpre[r] = scratch + C.dact[r][slot]; op.wp[r] = packed + P.w[r][0]; }

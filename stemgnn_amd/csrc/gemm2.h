@@ -44,13 +44,15 @@ constexpr int G2_BM = 128, G2_BN = 128, G2_BK = 16, G2_LD = 132;
 // D layout of v_mfma_f32_32x32x2_f32: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
 __device__ __forceinline__ int g2_row_of(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
 
-template <bool KCONTIG, bool VEC>
+template <bool KCONTIG, bool VEC, int ROWS = 128>
 struct G2Loader {
-  // fetch the 2 float4 this thread stages for a (128 x 16) operand tile.  rows = i (or j) extent, kk = K limit
+  static constexpr int NT = ROWS / 64;     // float4 per thread for a (ROWS x 16) operand tile
+  static constexpr int LD = ROWS + 4;      // LDS row stride (floats) of the K-major tile
+  // fetch the NT float4 this thread stages for a (ROWS x 16) operand tile.  rows = i (or j) extent, kk = K limit
   static __device__ __forceinline__ void load(const float* __restrict__ P, int ld, int i0, int imax, int kb, int kmax,
-                                              int ones_col, int tid, float4 (&v)[2]) {
+                                              int ones_col, int tid, float4 (&v)[NT]) {
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
+    for (int t = 0; t < NT; ++t) {
       const int f = tid + 256 * t;
       float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
       if constexpr (KCONTIG) {            // element (i, k) at P[i*ld + k]; float4 = 4 k's of row i
@@ -68,7 +70,7 @@ struct G2Loader {
                           io && k + 3 < kmax ? d : 0.f);
         }
       } else {                            // element (i, k) at P[k*ld + i]; float4 = 4 i's of row k
-        const int k = kb + (f >> 5), i = i0 + ((f & 31) << 2);
+        const int k = kb + f / (ROWS / 4), i = i0 + ((f % (ROWS / 4)) << 2);
         const int idata = ones_col >= 0 ? ones_col : imax;    // columns that exist in memory
         if constexpr (VEC) {
           const bool ok = k < kmax && i < idata;                // idata % 4 == 0 is guaranteed on the VEC path
@@ -93,27 +95,31 @@ struct G2Loader {
     }
   }
   // write the staged values K-major into LDS: T[k][i]
-  static __device__ __forceinline__ void store(float* __restrict__ T, int tid, const float4 (&v)[2]) {
+  static __device__ __forceinline__ void store(float* __restrict__ T, int tid, const float4 (&v)[NT]) {
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
+    for (int t = 0; t < NT; ++t) {
       const int f = tid + 256 * t;
       if constexpr (KCONTIG) {
         const int i = f >> 2, k = (f & 3) << 2;
-        T[(k + 0) * G2_LD + i] = v[t].x;
-        T[(k + 1) * G2_LD + i] = v[t].y;
-        T[(k + 2) * G2_LD + i] = v[t].z;
-        T[(k + 3) * G2_LD + i] = v[t].w;
+        T[(k + 0) * LD + i] = v[t].x;
+        T[(k + 1) * LD + i] = v[t].y;
+        T[(k + 2) * LD + i] = v[t].z;
+        T[(k + 3) * LD + i] = v[t].w;
       } else {
-        const int k = f >> 5, i = (f & 31) << 2;
-        *reinterpret_cast<float4*>(T + k * G2_LD + i) = v[t];
+        const int k = f / (ROWS / 4), i = (f % (ROWS / 4)) << 2;
+        *reinterpret_cast<float4*>(T + k * LD + i) = v[t];
       }
     }
   }
 };
 
-template <class Epi, bool A_KC, bool B_KC, bool VEC>
+template <class Epi, bool A_KC, bool B_KC, bool VEC, int BM = 128>
 __global__ __launch_bounds__(256) void sg_gemm2(const G2Args g, const Epi epi) {
-  __shared__ __attribute__((aligned(16))) float lds[2 * 2 * G2_BK * G2_LD];
+  static_assert(BM == 64 || BM == 128, "BM");
+  constexpr int NI = BM / 64;                    // 32-row MFMA tiles per wave (2 x 2 waves, each (BM/2) x 64)
+  constexpr int LDA = BM + 4;
+  constexpr int STAGE = G2_BK * (LDA + G2_LD);   // one double-buffer stage: A tile then B tile
+  __shared__ __attribute__((aligned(16))) float lds[2 * STAGE];
   int bx, by, z;
   {
     const int L = blockIdx.x, c = L & 7, idx = L >> 3;
@@ -129,7 +135,7 @@ __global__ __launch_bounds__(256) void sg_gemm2(const G2Args g, const Epi epi) {
   }
   const int r = z / g.nsplit, s = z - r * g.nsplit;
   const int M = g.M[r], N = g.N[r], K = g.K[r];
-  const int m0 = bx * G2_BM, n0 = by * G2_BN;
+  const int m0 = bx * BM, n0 = by * G2_BN;
   if (m0 >= M || n0 >= N) return;
   const int K0 = s * g.chunk, K1 = min(K, K0 + g.chunk);
   const float* __restrict__ A = g.A[r];
@@ -138,22 +144,22 @@ __global__ __launch_bounds__(256) void sg_gemm2(const G2Args g, const Epi epi) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
 
-  sg_f32x16 acc[2][2];
+  sg_f32x16 acc[NI][2];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < NI; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  float4 ra[2], rb[2];
-  using LA = G2Loader<A_KC, VEC>;
-  using LB = G2Loader<B_KC, VEC>;
+  using LA = G2Loader<A_KC, VEC, BM>;
+  using LB = G2Loader<B_KC, VEC, 128>;
+  float4 ra[LA::NT], rb[2];
   if (K0 < K1) {
     LA::load(A, lda, m0, M, K0, K1, -1, tid, ra);
     LB::load(Bp, ldb, n0, N, K0, K1, g.b_ones_col, tid, rb);
     LA::store(lds, tid, ra);
-    LB::store(lds + G2_BK * G2_LD, tid, rb);
+    LB::store(lds + G2_BK * LDA, tid, rb);
   }
   __syncthreads();
   int buf = 0;
@@ -163,23 +169,26 @@ __global__ __launch_bounds__(256) void sg_gemm2(const G2Args g, const Epi epi) {
       LA::load(A, lda, m0, M, kb + G2_BK, K1, -1, tid, ra);
       LB::load(Bp, ldb, n0, N, kb + G2_BK, K1, g.b_ones_col, tid, rb);
     }
-    const float* As = lds + buf * (2 * G2_BK * G2_LD);
-    const float* Bs = As + G2_BK * G2_LD;
+    const float* As = lds + buf * STAGE;
+    const float* Bs = As + G2_BK * LDA;
     const int fi = lane & 31, fk = lane >> 5;
     if (!G2_DBG(g, 2))
 #pragma unroll
     for (int ks = 0; ks < G2_BK; ks += 2) {
-      const float a0 = As[(ks + fk) * G2_LD + wm * 64 + fi], a1 = As[(ks + fk) * G2_LD + wm * 64 + 32 + fi];
+      float a[NI];
+#pragma unroll
+      for (int i = 0; i < NI; ++i) a[i] = As[(ks + fk) * LDA + wm * (BM / 2) + i * 32 + fi];
       const float b0 = Bs[(ks + fk) * G2_LD + wn * 64 + fi], b1 = Bs[(ks + fk) * G2_LD + wn * 64 + 32 + fi];
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b0, acc[i][0], 0, 0, 0);
+        acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b1, acc[i][1], 0, 0, 0);
+      }
     }
     if (more) {
-      float* An = lds + (buf ^ 1) * (2 * G2_BK * G2_LD);
+      float* An = lds + (buf ^ 1) * STAGE;
       LA::store(An, tid, ra);
-      LB::store(An + G2_BK * G2_LD, tid, rb);
+      LB::store(An + G2_BK * LDA, tid, rb);
     }
     __syncthreads();
     buf ^= 1;
@@ -189,13 +198,13 @@ __global__ __launch_bounds__(256) void sg_gemm2(const G2Args g, const Epi epi) {
     return;
   }
   if constexpr (Epi::WHOLE) {
-    epi.whole(r, s, m0 + wm * 64, n0 + wn * 64, M, N, acc, lane);
+    epi.template whole<NI>(r, s, m0 + wm * (BM / 2), n0 + wn * 64, M, N, acc, lane);
   } else {
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < NI; ++i)
 #pragma unroll
       for (int j = 0; j < 2; ++j)
-        epi.tile(r, s, m0 + wm * 64 + i * 32, n0 + wn * 64 + j * 32, M, N, acc[i][j], lane);
+        epi.tile(r, s, m0 + wm * (BM / 2) + i * 32, n0 + wn * 64 + j * 32, M, N, acc[i][j], lane);
   }
 }
 
@@ -217,7 +226,7 @@ struct G2SlabEpi {
 // 16-byte alignment rules of the VEC path
 static inline bool g2_aligned(const void* p, int ld) { return (((uintptr_t)p) & 15) == 0 && (ld & 3) == 0; }
 
-template <class Epi, bool A_KC, bool B_KC>
+template <class Epi, bool A_KC, bool B_KC, int BM = 128>
 static inline hipError_t g2_launch(const G2Args& g_in, const Epi& epi, int nbranch, hipStream_t st) {
   G2Args g = g_in;
 #ifdef SG_G2_DEBUG
@@ -236,7 +245,7 @@ static inline hipError_t g2_launch(const G2Args& g_in, const Epi& epi, int nbran
     if (!A_KC) vec = vec && (g.M[r] & 3) == 0;
     if (!B_KC) vec = vec && (((g.b_ones_col >= 0 ? g.b_ones_col : g.N[r]) & 3) == 0);
   }
-  g.nx = (maxM + G2_BM - 1) / G2_BM;
+  g.nx = (maxM + BM - 1) / BM;
   g.ny = (maxN + G2_BN - 1) / G2_BN;
   g.nz = nbranch * g.nsplit;
   if (g.nx == 0 || g.ny == 0 || g.nz == 0) return hipSuccess;
@@ -244,7 +253,7 @@ static inline hipError_t g2_launch(const G2Args& g_in, const Epi& epi, int nbran
   const int ngroups = g.xcd_mode ? g.nz : g.nx * g.nz;
   const int gt = g.xcd_mode ? g.nx * g.ny : g.ny;
   dim3 grid(8 * ((ngroups + 7) / 8) * gt);
-  if (vec) hipLaunchKernelGGL((sg_gemm2<Epi, A_KC, B_KC, true>), grid, dim3(256), 0, st, g, epi);
-  else hipLaunchKernelGGL((sg_gemm2<Epi, A_KC, B_KC, false>), grid, dim3(256), 0, st, g, epi);
+  if (vec) hipLaunchKernelGGL((sg_gemm2<Epi, A_KC, B_KC, true, BM>), grid, dim3(256), 0, st, g, epi);
+  else hipLaunchKernelGGL((sg_gemm2<Epi, A_KC, B_KC, false, BM>), grid, dim3(256), 0, st, g, epi);
   return hipGetLastError();
 }
