@@ -61,9 +61,10 @@ struct GftFwdOp {
 // GFT backward dX[b][m][t] = sum_{kq,n} T_{kq+1}[n][m] dG[(b,n)][kq*W+t]
 struct GftBwdDxOp {
   const float* T;
-  const float* dG;
+  const float* dG;       // two partial slabs, `slab` floats apart; their sum is dG
   float* dX;
   int B, N, W;
+  size_t slab;
   __device__ bool setup(int, int& M, int& Nn, int& K0, int& K1) const {
     M = N; Nn = B * W; K0 = 0; K1 = 3 * N;
     return true;
@@ -71,7 +72,8 @@ struct GftBwdDxOp {
   __device__ float a(int, int i, int k) const { return T[(size_t)k * N + i]; }   // T_kq[n][m=i], k=(kq,n)
   __device__ float b(int, int k, int j) const {
     const int kq = k / N, n = k - kq * N, bb = j / W, t = j - bb * W;
-    return dG[((size_t)bb * N + n) * (3 * W) + kq * W + t];
+    const size_t o = ((size_t)bb * N + n) * (3 * W) + kq * W + t;
+    return dG[o] + dG[o + slab];
   }
   __device__ void epi(int, int i, int j, float v) const {
     const int bb = j / W, t = j - bb * W;
@@ -81,17 +83,19 @@ struct GftBwdDxOp {
 
 // GFT backward dT_{kq+1}[n][m] (+)= sum_{b,t} dG[(b,n)][kq*W+t] X[b][m][t]
 struct GftBwdDtOp {
-  const float* dG;
+  const float* dG;       // two partial slabs, `slab` floats apart
   XView X;
   float* dT;  // dmul_L slot 1
   int B, N, W, accumulate;
+  size_t slab;
   __device__ bool setup(int, int& M, int& Nn, int& K0, int& K1) const {
     M = 3 * N; Nn = N; K0 = 0; K1 = B * W;
     return true;
   }
   __device__ float a(int, int i, int k) const {
     const int kq = i / N, n = i - kq * N, bb = k / W, t = k - bb * W;
-    return dG[((size_t)bb * N + n) * (3 * W) + kq * W + t];
+    const size_t o = ((size_t)bb * N + n) * (3 * W) + kq * W + t;
+    return dG[o] + dG[o + slab];
   }
   __device__ float b(int, int k, int j) const {
     const int bb = k / W;
@@ -216,19 +220,15 @@ struct GluDgrad0Op {
   const float* wp[2];
   float* dG;
   int np0, KG, M;
+  // z = branch: the two halves of the reduction run as independent workgroups (twice the parallelism of this
+  // latency-bound product) and land in two slabs that stemgnn_gft_bwd adds while loading
   __device__ bool setup(int, int& M_, int& N_, int& K0, int& K1) const {
-    M_ = M; N_ = KG; K0 = 0; K1 = 2 * np0;
+    M_ = M; N_ = KG; K0 = 0; K1 = np0;
     return true;
   }
-  __device__ float a(int, int i, int k) const {
-    const float* p = k < np0 ? dpre[0] + (size_t)i * np0 + k : dpre[1] + (size_t)i * np0 + (k - np0);
-    return *p;
-  }
-  __device__ float b(int, int k, int j) const {
-    const float* p = k < np0 ? wp[0] + (size_t)j * np0 + k : wp[1] + (size_t)j * np0 + (k - np0);
-    return *p;
-  }
-  __device__ void epi(int, int i, int j, float v) const { dG[(size_t)i * KG + j] = v; }
+  __device__ float a(int z, int i, int k) const { return (z ? dpre[1] : dpre[0])[(size_t)i * np0 + k]; }
+  __device__ float b(int z, int k, int j) const { return (z ? wp[1] : wp[0])[(size_t)j * np0 + k]; }
+  __device__ void epi(int z, int i, int j, float v) const { dG[(size_t)z * M * KG + (size_t)i * KG + j] = v; }
 };
 
 struct GluPlainEpi {   // C (+)= acc, row-major
@@ -462,10 +462,10 @@ extern "C" int stemgnn_gft_bwd(const float* mul_L, const float* X, long xs_b, lo
   if (!mul_L || !X || !dG || !dmul_L || B <= 0 || N <= 0 || W <= 0) return SG_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   if (dX) {
-    GftBwdDxOp op{mul_L + (size_t)N * N, dG, dX, B, N, W};
+    GftBwdDxOp op{mul_L + (size_t)N * N, dG, dX, B, N, W, (size_t)B * N * 3 * W};
     SG_TRY((sg_launch_gemm<GftBwdDxOp, 32, 32, false, false, false, 64, true>(op, N, B * W, 1, st)));
   }
-  GftBwdDtOp op{dG, XView{X, xs_b, xs_n, xs_t, N}, dmul_L + (size_t)N * N, B, N, W, accumulate};
+  GftBwdDtOp op{dG, XView{X, xs_b, xs_n, xs_t, N}, dmul_L + (size_t)N * N, B, N, W, accumulate, (size_t)B * N * 3 * W};
   if (xs_t == 1) SG_TRY((sg_launch_gemm<GftBwdDtOp, 32, 32, true, true, false, 64, true>(op, 3 * N, N, 1, st)));
   else SG_TRY((sg_launch_gemm<GftBwdDtOp, 32, 32, true, false, false, 64, true>(op, 3 * N, N, 1, st)));
   return 0;
@@ -553,7 +553,7 @@ extern "C" int stemgnn_spectral_glu_bwd(const float* packed, const float* saved,
       GluDgrad0Op op;
       for (int r = 0; r < 2; ++r) { op.dpre[r] = scratch + C.dact[r][slot]; op.wp[r] = packed + P.w[r][0]; }
       op.dG = scratch + C.dG; op.np0 = sg_glu_np(d, 0, 0); op.KG = d.KG; op.M = d.M;
-      SG_TRY((sg_launch_gemm<GluDgrad0Op, 32, 64, true, true, false, 64>(op, d.M, d.KG, 1, st)));
+      SG_TRY((sg_launch_gemm<GluDgrad0Op, 32, 64, true, true, false, 64>(op, d.M, d.KG, 2, st)));
     }
   }
   return 0;

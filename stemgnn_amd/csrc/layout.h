@@ -138,7 +138,7 @@ struct SgScratchLayout {
   size_t dig;            // M x Wm
   size_t dact[2][3];     // [branch][layer]: d(pre-activation) of GLU layer l, M x 2CP in "pair" column order (one buffer per
                          // layer, so the weight-gradient GEMMs can run later / on another stream than the data-gradient chain)
-  size_t dG;             // M x KG
+  size_t dG;             // 2 x (M x KG): per-branch partials of the layer-0 data gradient
   size_t total;
 };
 SG_HD SgScratchLayout sg_scratch_layout(const SgDims& d) {
@@ -149,7 +149,7 @@ SG_HD SgScratchLayout sg_scratch_layout(const SgDims& d) {
   L.dig = off; off += M * d.Wm;
   for (int r = 0; r < 2; ++r)
     for (int p = 0; p < 3; ++p) { L.dact[r][p] = off; off += M * 2 * d.CP; }
-  L.dG = off; off += M * d.KG;
+  L.dG = off; off += 2 * M * d.KG;   // two partial slabs (Re / Im branch), summed on the fly by gft_bwd
   L.total = off;
   return L;
 }
