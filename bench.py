@@ -29,7 +29,7 @@ import torch.distributed as dist  # noqa: E402
 
 WORKLOAD = dict(N=228, W=12, H=3, multi=5, B=32)      # PEMS07 shape, BASELINE.json configs[1]
 FP32_MFMA_PEAK_TFLOPS = 157.3                          # MI355X_MICROARCH.md: v_mfma_f32_* dense peak
-ROOFLINE_TRAFFIC_BYTES = 62.4e6                        # profiles/r01_pmc_fetch_write.md (dominant kernel, per launch)
+ROOFLINE_TRAFFIC_BYTES = 36.3e6                        # profiles/r01_v7_pmc_fetch_write.md (dominant kernel, per launch)
 
 
 def glu_fwd_flops(B, N, W, multi):
@@ -200,12 +200,12 @@ def main():
     if rank == 0:
         avg_s, flops = time_dominant_kernel(cfg)
         ach = flops / avg_s / 1e12
-        out["roofline"] = {"kernel": "sg_gemm2<GluFwdEpi,true,false,true> (spectral GLU forward GEMM, 128x128x16 tiles, "
+        out["roofline"] = {"kernel": "sg_gemm2<GluFwdEpi,true,false,true,64> (spectral GLU forward GEMM, 64x128x16 tiles, "
                                      "v_mfma_f32_32x32x2_f32, exact fp32)",
                            "bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                            "frac": ach / FP32_MFMA_PEAK_TFLOPS, "avg_launch_us": avg_s * 1e6,
                            "flops_per_launch": flops,
-                           # HBM bytes per launch from the PMC passes in profiles/r01_pmc_fetch_write.md
+                           # HBM bytes per launch from the PMC passes in profiles/r01_v7_pmc_fetch_write.md
                            # (2 x FETCH_SIZE + WRITE_SIZE, gfx950 correction), not re-measured live
                            "traffic": ROOFLINE_TRAFFIC_BYTES}
         if world == 1 and not args.no_cpu_baseline:
