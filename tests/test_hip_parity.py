@@ -329,3 +329,34 @@ def test_large_config_shapes(N, W, multi, H, B):
     worst = sorted(rows, key=lambda r: -r[1])[:6]
     print("worst (name, hip-vs-fp64, fp32oracle-vs-fp64):", [(k, f"{e:.2e}", f"{eo:.2e}") for k, e, eo in worst])
     assert not bad, [(k, f"{e:.2e}", f"{eo:.2e}") for k, e, eo in bad]
+
+
+@pytest.mark.parametrize("shape", [(32, 228, 12, 5), (3, 20, 12, 5), (2, 9, 4, 2)])
+def test_fused_three_layer_glu_forward_matches_layerwise(shape, monkeypatch):
+    """STEMGNN_GLU3=1 (opt-in fused three-layer kernel, activations resident in LDS) against the default three
+    per-layer GEMM launches on the same packed weights and GFT output: every saved out / gate tensor agrees."""
+    from stemgnn_amd import _lib, ops
+    from stemgnn_amd.base_model import StockBlockLayer
+    B, N, W, multi = shape
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    torch.manual_seed(3)
+    blk = StockBlockLayer(W, N, multi, stack_cnt=0).to(dev)
+    tables = ops.dft_tables(W, multi, dev)
+    pk = torch.empty(lib.stemgnn_packed_floats(W, multi), device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    _lib.check(lib.stemgnn_block_pack(_lib.ptr_array(blk.hip_params()), tables.data_ptr(), pk.data_ptr(), W, multi, st), "pack")
+    n_saved = lib.stemgnn_saved_floats(B, N, W, multi)
+    G = torch.randn(B * N * 3 * W, device=dev)
+    outs = []
+    for flag in ("0", "1"):
+        monkeypatch.setenv("STEMGNN_GLU3", flag)
+        sv = torch.zeros(n_saved, device=dev)
+        sv[: G.numel()] = G
+        _lib.check(lib.stemgnn_spectral_glu_fwd(pk.data_ptr(), sv.data_ptr(), B, N, W, multi, st), "glu_fwd")
+        torch.cuda.synchronize()
+        outs.append(sv.clone())
+    monkeypatch.delenv("STEMGNN_GLU3")
+    ref, got = outs
+    assert float(ref[G.numel():].abs().max()) > 0
+    assert relerr(got, ref) < 1e-6
