@@ -437,11 +437,14 @@ __device__ __forceinline__ float gru_poll_lane(const gru_u64* g, unsigned tag, b
 }
 
 // forward.  LDS: part[2][3*P][64]
-template <int P, int KU>
-__global__ __launch_bounds__(3 * P * 64) void gru_fwd_cluster2_kernel(const float* __restrict__ gi, const float* __restrict__ w_hh,
+// OW = owner slices per wave: 3*P/OW waves per workgroup (OW = 2 lets P = 6 / 8 clusters -- hidden sizes up to 512 --
+// stay inside the 1024-thread limit; each wave then polls and multiplies two slices per step).
+template <int P, int KU, int OW>
+__global__ __launch_bounds__(3 * (P / OW) * 64) void gru_fwd_cluster2_kernel(const float* __restrict__ gi, const float* __restrict__ w_hh,
                                                                       const float* __restrict__ b_hh, int B, int S, int Hd,
                                                                       gru_u64* __restrict__ xbuf, int* __restrict__ status,
                                                                       float* __restrict__ h_all, float* __restrict__ reserve) {
+  static_assert(P % OW == 0, "owners per wave");
   __shared__ float part[2][3 * P][64];
   int b, p;
   gru_cluster_ids(B, P, b, p);
@@ -449,18 +452,21 @@ __global__ __launch_bounds__(3 * P * 64) void gru_fwd_cluster2_kernel(const floa
   const int U = (Hd + P - 1) / P;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = gru_uniform(tid >> 6);
-  const int g = wave / P, q = wave - g * P;            // gate, owner of the k-slice
+  const int g = wave / (P / OW), q0 = (wave - g * (P / OW)) * OW;       // gate, first owner of this wave's k-slices
   const int u0 = p * U, un = max(0, min(Hd, u0 + U) - u0);
-  const int k0 = q * U, kn = max(0, min(Hd, k0 + U) - k0);
   const int H3 = 3 * Hd;
-  gru_f2 wr[32];
-  {
+  gru_f2 wr[OW][32];
+  int k0[OW], kn[OW];
+#pragma unroll
+  for (int o = 0; o < OW; ++o) {
+    k0[o] = (q0 + o) * U;
+    kn[o] = max(0, min(Hd, k0[o] + U) - k0[o]);
     const bool lane_ok = lane < un;
-    const float* wrow = w_hh + ((size_t)g * Hd + (lane_ok ? u0 + lane : 0)) * Hd + (kn > 0 ? k0 : 0);
+    const float* wrow = w_hh + ((size_t)g * Hd + (lane_ok ? u0 + lane : 0)) * Hd + (kn[o] > 0 ? k0[o] : 0);
 #pragma unroll
     for (int kk = 0; kk < KU; ++kk) {
-      const float v = wrow[kk < kn ? kk : 0];
-      wr[kk >> 1][kk & 1] = (lane_ok && kk < kn) ? v : 0.f;
+      const float v = wrow[kk < kn[o] ? kk : 0];
+      wr[o][kk >> 1][kk & 1] = (lane_ok && kk < kn[o]) ? v : 0.f;
     }
   }
   const int gu = u0 + (tid < un ? tid : 0);            // gate-phase unit of this thread (wave 0 only)
@@ -471,10 +477,13 @@ __global__ __launch_bounds__(3 * P * 64) void gru_fwd_cluster2_kernel(const floa
     const size_t row = (size_t)s * B + b;
     const float* gip = gi + row * H3;
     const float gp0 = gip[gu], gp1 = gip[Hd + gu], gp2 = gip[2 * Hd + gu];     // prefetch for the gate phase
-    float hv = 0.f;
-    if (s > 0) hv = gru_poll_lane(xbuf + ((size_t)(s & 1) * B + b) * Hd + k0 + (lane < kn ? lane : 0), (unsigned)s,
-                                  lane < kn, status);
-    part[s & 1][wave][lane] = gru_matvec<KU>(wr, hv);
+#pragma unroll
+    for (int o = 0; o < OW; ++o) {
+      float hv = 0.f;
+      if (s > 0) hv = gru_poll_lane(xbuf + ((size_t)(s & 1) * B + b) * Hd + k0[o] + (lane < kn[o] ? lane : 0), (unsigned)s,
+                                    lane < kn[o], status);
+      part[s & 1][g * P + q0 + o][lane] = gru_matvec<KU>(wr[o], hv);
+    }
     __syncthreads();
     if (tid < un) {
       float g0 = bh0, g1 = bh1, g2 = bh2;
@@ -498,12 +507,14 @@ __global__ __launch_bounds__(3 * P * 64) void gru_fwd_cluster2_kernel(const floa
 }
 
 // backward.  LDS: part[2][3*P][64].  Wave (g, q): reduction slice j = g*Hd + units of owner q.
-template <int P, int KU>
-__global__ __launch_bounds__(3 * P * 64) void gru_bwd_cluster2_kernel(const float* __restrict__ dout, const float* __restrict__ w_hh,
+template <int P, int KU, int OW>
+__global__ __launch_bounds__(3 * (P / OW) * 64) void gru_bwd_cluster2_kernel(const float* __restrict__ dout, const float* __restrict__ w_hh,
                                                                       const float* __restrict__ h_all,
                                                                       const float* __restrict__ reserve, int B, int S, int Hd,
                                                                       gru_u64* __restrict__ xbuf, int* __restrict__ status,
                                                                       float* __restrict__ dgi, float* __restrict__ dghn) {
+  static_assert(P % OW == 0, "owners per wave");
+  constexpr int NTH = 3 * (P / OW) * 64;
   __shared__ float part[2][3 * P][64];
   int b, p;
   gru_cluster_ids(B, P, b, p);
@@ -511,23 +522,26 @@ __global__ __launch_bounds__(3 * P * 64) void gru_bwd_cluster2_kernel(const floa
   const int U = (Hd + P - 1) / P;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = gru_uniform(tid >> 6);
-  const int g = wave / P, q = wave - g * P;
+  const int g = wave / (P / OW), q0 = (wave - g * (P / OW)) * OW;
   const int u0 = p * U, un = max(0, min(Hd, u0 + U) - u0);
-  const int k0 = q * U, kn = max(0, min(Hd, k0 + U) - k0);
   const int H3 = 3 * Hd;
-  gru_f2 wr[32];
-  {
+  gru_f2 wr[OW][32];
+  int k0[OW], kn[OW];
+#pragma unroll
+  for (int o = 0; o < OW; ++o) {
+    k0[o] = (q0 + o) * U;
+    kn[o] = max(0, min(Hd, k0[o] + U) - k0[o]);
     const bool lane_ok = lane < un;
-    const float* wcol = w_hh + ((size_t)g * Hd + (kn > 0 ? k0 : 0)) * Hd + (lane_ok ? u0 + lane : 0);
+    const float* wcol = w_hh + ((size_t)g * Hd + (kn[o] > 0 ? k0[o] : 0)) * Hd + (lane_ok ? u0 + lane : 0);
 #pragma unroll
     for (int kk = 0; kk < KU; ++kk) {
-      const float v = wcol[(size_t)(kk < kn ? kk : 0) * Hd];
-      wr[kk >> 1][kk & 1] = (lane_ok && kk < kn) ? v : 0.f;
+      const float v = wcol[(size_t)(kk < kn[o] ? kk : 0) * Hd];
+      wr[o][kk >> 1][kk & 1] = (lane_ok && kk < kn[o]) ? v : 0.f;
     }
   }
   const int gu = u0 + (tid < un ? tid : 0);
   float dhz = 0.f;                                      // dh * z carried to the previous step (this thread's unit)
-  for (int i = tid; i < 2 * 3 * P * 64; i += 3 * P * 64) (&part[0][0][0])[i] = 0.f;
+  for (int i = tid; i < 2 * 3 * P * 64; i += NTH) (&part[0][0][0])[i] = 0.f;
   // inputs of the elementwise phase, prefetched one step ahead so their latency hides under the exchange + mat-vec
   size_t prow = (size_t)(S - 1) * B + b;
   float p_do = dout[prow * Hd + gu];
@@ -566,8 +580,11 @@ __global__ __launch_bounds__(3 * P * 64) void gru_bwd_cluster2_kernel(const floa
       dghn[row * Hd + gu] = dnr;
     }
     if (s == 0) break;
-    const float dv = gru_poll_lane(xb + (size_t)g * Hd + k0 + (lane < kn ? lane : 0), tag, lane < kn, status);
-    part[tag & 1][wave][lane] = gru_matvec<KU>(wr, dv);
+#pragma unroll
+    for (int o = 0; o < OW; ++o) {
+      const float dv = gru_poll_lane(xb + (size_t)g * Hd + k0[o] + (lane < kn[o] ? lane : 0), tag, lane < kn[o], status);
+      part[tag & 1][g * P + q0 + o][lane] = gru_matvec<KU>(wr[o], dv);
+    }
     __syncthreads();
   }
 }
@@ -653,8 +670,11 @@ static int gru_pick_P(int B, int Hd) {
 static int gru_pick_P2(int B, int Hd) {
   const char* e = getenv("STEMGNN_GRU_CLUSTER");
   if (e && atoi(e) != 2) return 0;
-  static const int cand[4] = {1, 2, 4, 5};
-  for (int i = 0; i < 4; ++i) {
+  // P workgroups per batch row: the slice U = ceil(Hd/P) must fit the 64 lanes, all B*P workgroups must be
+  // co-resident (one per CU, 224 leaves slack on 256 CUs).  P <= 5 runs one owner slice per wave (3P waves); P = 6, 8
+  // run two per wave (3P/2 waves) to stay inside 1024 threads.
+  static const int cand[6] = {1, 2, 4, 5, 6, 8};
+  for (int i = 0; i < 6; ++i) {
     const int P = cand[i];
     if ((Hd + P - 1) / P <= 64 && (size_t)B * P <= 224) return P;
   }
@@ -704,12 +724,13 @@ extern "C" int stemgnn_gru_fwd(const float* x, const float* w_ih, const float* w
     gru_u64* xbuf = (gru_u64*)(scratch + ((((size_t)3 * Hd * Hd + (size_t)3 * S * B * Hd) + 1) & ~(size_t)1));
     SG_TRY(hipMemsetAsync(xbuf, 0, (size_t)2 * B * Hd * sizeof(gru_u64), st));      // tags := 0 before every launch
     const dim3 grid(8 * ((B + 7) / 8) * P2);
-#define GRU_F2K(PP, KK) hipLaunchKernelGGL((gru_fwd_cluster2_kernel<PP, KK>), grid, dim3(3 * PP * 64), 0, st, gi, w_hh, b_hh, \
-                                           B, S, Hd, xbuf, status, h_all, reserve)
-#define GRU_F2(PP) do { if (KU2 == 32) GRU_F2K(PP, 32); else if (KU2 == 48) GRU_F2K(PP, 48); \
-                        else if (KU2 == 58) GRU_F2K(PP, 58); else GRU_F2K(PP, 64); } while (0)
+#define GRU_F2K(PP, KK, OO) hipLaunchKernelGGL((gru_fwd_cluster2_kernel<PP, KK, OO>), grid, dim3(3 * (PP / OO) * 64), 0, st, gi, \
+                                               w_hh, b_hh, B, S, Hd, xbuf, status, h_all, reserve)
+#define GRU_F2(PP, OO) do { if (KU2 == 32) GRU_F2K(PP, 32, OO); else if (KU2 == 48) GRU_F2K(PP, 48, OO); \
+                            else if (KU2 == 58) GRU_F2K(PP, 58, OO); else GRU_F2K(PP, 64, OO); } while (0)
     const int KU2 = gru_pick_KU(Hd, P2);
-    if (P2 == 1) GRU_F2(1); else if (P2 == 2) GRU_F2(2); else if (P2 == 4) GRU_F2(4); else GRU_F2(5);
+    if (P2 == 1) GRU_F2(1, 1); else if (P2 == 2) GRU_F2(2, 1); else if (P2 == 4) GRU_F2(4, 1);
+    else if (P2 == 5) GRU_F2(5, 1); else if (P2 == 6) GRU_F2(6, 2); else GRU_F2(8, 2);
 #undef GRU_F2
 #undef GRU_F2K
     SG_TRY(hipGetLastError());
@@ -757,13 +778,14 @@ extern "C" int stemgnn_gru_bwd(const float* dh_all, const float* x, const float*
     gru_u64* xbuf = (gru_u64*)(scratch + ((((size_t)(p_ih - scratch) + (size_t)GRU_NSPLIT * 3 * Hd * (W + 1)) + 1) & ~(size_t)1));
     SG_TRY(hipMemsetAsync(xbuf, 0, (size_t)2 * B * 3 * Hd * sizeof(gru_u64), st));
     const dim3 grid(8 * ((B + 7) / 8) * P2);
-#define GRU_B2K(PP, KK) do { const size_t hog = gru_lds_hog<PP>((const void*)gru_bwd_cluster2_kernel<PP, KK>); \
-    hipLaunchKernelGGL((gru_bwd_cluster2_kernel<PP, KK>), grid, dim3(3 * PP * 64), hog, st, dh_all, w_hh, h_all, \
+#define GRU_B2K(PP, KK, OO) do { const size_t hog = gru_lds_hog<PP>((const void*)gru_bwd_cluster2_kernel<PP, KK, OO>); \
+    hipLaunchKernelGGL((gru_bwd_cluster2_kernel<PP, KK, OO>), grid, dim3(3 * (PP / OO) * 64), hog, st, dh_all, w_hh, h_all, \
                        reserve, B, S, Hd, xbuf, status, dgi, dghn); } while (0)
-#define GRU_B2(PP) do { if (KU2 == 32) GRU_B2K(PP, 32); else if (KU2 == 48) GRU_B2K(PP, 48); \
-                        else if (KU2 == 58) GRU_B2K(PP, 58); else GRU_B2K(PP, 64); } while (0)
+#define GRU_B2(PP, OO) do { if (KU2 == 32) GRU_B2K(PP, 32, OO); else if (KU2 == 48) GRU_B2K(PP, 48, OO); \
+                            else if (KU2 == 58) GRU_B2K(PP, 58, OO); else GRU_B2K(PP, 64, OO); } while (0)
     const int KU2 = gru_pick_KU(Hd, P2);
-    if (P2 == 1) GRU_B2(1); else if (P2 == 2) GRU_B2(2); else if (P2 == 4) GRU_B2(4); else GRU_B2(5);
+    if (P2 == 1) GRU_B2(1, 1); else if (P2 == 2) GRU_B2(2, 1); else if (P2 == 4) GRU_B2(4, 1);
+    else if (P2 == 5) GRU_B2(5, 1); else if (P2 == 6) GRU_B2(6, 2); else GRU_B2(8, 2);
 #undef GRU_B2
 #undef GRU_B2K
     SG_TRY(hipGetLastError());
