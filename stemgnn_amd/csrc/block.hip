@@ -586,6 +586,8 @@ static inline int g2_bm_mask() {
   static const int m = getenv("STEMGNN_G2_BM64") ? atoi(getenv("STEMGNN_G2_BM64")) : 3;   // measured: 1.921 -> 1.890 ms/step
   return m;
 }
+// reductions longer than this use the two-level accumulating instantiations (large W*multi configurations)
+constexpr int SG_LONG_K = 640;
 static inline int split_chunk(int M, int S) { return ((M + S - 1) / S + 15) & ~15; }
 
 extern "C" int stemgnn_gft_fwd(const float* mul_L, const float* X, long xs_b, long xs_n, long xs_t,
@@ -674,7 +676,8 @@ extern "C" int stemgnn_spectral_glu_fwd(const float* packed, float* saved, int B
       e.cp[r] = sg_glu_cp(d, l, r);
     }
     g.nsplit = 1; g.chunk = (sg_glu_kin(d, l) + 15) & ~15; g.b_ones_col = -1;
-    if (g2_bm_mask() & 1) SG_TRY((g2_launch<GluFwdEpi, true, false, 64>(g, e, 2, st)));
+    if (sg_glu_kin(d, l) > SG_LONG_K) SG_TRY((g2_launch<GluFwdEpi, true, false, 64, true>(g, e, 2, st)));
+    else if (g2_bm_mask() & 1) SG_TRY((g2_launch<GluFwdEpi, true, false, 64>(g, e, 2, st)));
     else SG_TRY((g2_launch<GluFwdEpi, true, false>(g, e, 2, st)));
   }
   return 0;
@@ -728,13 +731,15 @@ extern "C" int stemgnn_spectral_glu_bwd(const float* packed, const float* saved,
       }
       e.cp = d.CP;
       g.nsplit = 1; g.chunk = (2 * d.CP + 15) & ~15; g.b_ones_col = -1;
-      if (g2_bm_mask() & 2) SG_TRY((g2_launch<GluDpreEpi, true, true, 64>(g, e, 2, st)));
+      if (2 * d.CP > SG_LONG_K) SG_TRY((g2_launch<GluDpreEpi, true, true, 64, true>(g, e, 2, st)));
+      else if (g2_bm_mask() & 2) SG_TRY((g2_launch<GluDpreEpi, true, true, 64>(g, e, 2, st)));
       else SG_TRY((g2_launch<GluDpreEpi, true, true>(g, e, 2, st)));
     } else {      // layer 0: both branches feed the same G -> one launch with K = Re columns then Im columns
       GluDgrad0Op op;
       for (int r = 0; r < 2; ++r) { op.dpre[r] = scratch + C.dact[r][slot]; op.wp[r] = packed + P.w[r][0]; }
       op.dG = scratch + C.dG; op.np0 = sg_glu_np(d, 0, 0); op.KG = d.KG; op.M = d.M;
-      SG_TRY((sg_launch_gemm<GluDgrad0Op, 32, 64, true, true, false, 64>(op, d.M, d.KG, 2, st)));
+      if (op.np0 > SG_LONG_K) SG_TRY((sg_launch_gemm<GluDgrad0Op, 32, 64, true, true, false, 64, true>(op, d.M, d.KG, 2, st)));
+      else SG_TRY((sg_launch_gemm<GluDgrad0Op, 32, 64, true, true, false, 64>(op, d.M, d.KG, 2, st)));
     }
   }
   return 0;
@@ -756,7 +761,8 @@ extern "C" int stemgnn_igft_heads_fwd(const float* const* params_host, const flo
     IgftOp op;
     for (int r = 0; r < 2; ++r) { op.a3[r] = saved + S.out[r][2]; op.cp2[r] = d.CP2[r]; }
     op.wfold = packed + P.wfold; op.ig = saved + S.ig; op.M = d.M; op.Wm = d.Wm; op.WmP = d.WmP;
-    SG_TRY((sg_launch_gemm<IgftOp, 32, 64, true, false, false, 64>(op, d.M, d.Wm, 1, st)));
+    if (d.KF > SG_LONG_K) SG_TRY((sg_launch_gemm<IgftOp, 32, 64, true, false, false, 64, true>(op, d.M, d.Wm, 1, st)));
+    else SG_TRY((sg_launch_gemm<IgftOp, 32, 64, true, false, false, 64>(op, d.M, d.Wm, 1, st)));
   }
   {
     Head1Op op{saved + S.ig, XView{X, xs_b, xs_n, xs_t, N},

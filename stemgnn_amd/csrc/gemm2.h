@@ -113,9 +113,14 @@ struct G2Loader {
   }
 };
 
-template <class Epi, bool A_KC, bool B_KC, bool VEC, int BM = 128>
+// TL ("two-level"): every G2_FLUSH K tiles the running accumulators are added into a second set and cleared, so an
+// fp32 MFMA chain is at most G2_FLUSH * 8 instructions long -- the rounding noise of a K = 2000-4000 reduction drops to
+// that of a blocked sum (used for the long reductions of the large-N configurations only; costs 32 registers at BM = 64).
+constexpr int G2_FLUSH = 16;
+template <class Epi, bool A_KC, bool B_KC, bool VEC, int BM = 128, bool TL = false>
 __global__ __launch_bounds__(256) void sg_gemm2(const G2Args g, const Epi epi) {
   static_assert(BM == 64 || BM == 128, "BM");
+  static_assert(!TL || BM == 64, "two-level accumulation is instantiated for 64-row tiles only");
   constexpr int NI = BM / 64;                    // 32-row MFMA tiles per wave (2 x 2 waves, each (BM/2) x 64)
   constexpr int LDA = BM + 4;
   constexpr int STAGE = G2_BK * (LDA + G2_LD);   // one double-buffer stage: A tile then B tile
@@ -152,6 +157,16 @@ __global__ __launch_bounds__(256) void sg_gemm2(const G2Args g, const Epi epi) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
+  sg_f32x16 acc2[TL ? NI : 1][TL ? 2 : 1];
+  if constexpr (TL) {
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc2[i][j][e] = 0.f;
+  }
+  int tl_count = 0;
   using LA = G2Loader<A_KC, VEC, BM>;
   using LB = G2Loader<B_KC, VEC, 128>;
   float4 ra[LA::NT], rb[2];
@@ -192,6 +207,25 @@ __global__ __launch_bounds__(256) void sg_gemm2(const G2Args g, const Epi epi) {
     }
     __syncthreads();
     buf ^= 1;
+    if constexpr (TL) {
+      if (++tl_count == G2_FLUSH) {
+        tl_count = 0;
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { acc2[i][j][e] += acc[i][j][e]; acc[i][j][e] = 0.f; }
+      }
+    }
+  }
+  if constexpr (TL) {
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j][e] += acc2[i][j][e];
   }
   if (G2_DBG(g, 1)) {
     if (acc[0][0][0] + acc[1][1][3] == 1.2345e-30f) lds[0] = 1.f;   // keep the accumulators alive
@@ -226,7 +260,7 @@ struct G2SlabEpi {
 // 16-byte alignment rules of the VEC path
 static inline bool g2_aligned(const void* p, int ld) { return (((uintptr_t)p) & 15) == 0 && (ld & 3) == 0; }
 
-template <class Epi, bool A_KC, bool B_KC, int BM = 128>
+template <class Epi, bool A_KC, bool B_KC, int BM = 128, bool TL = false>
 static inline hipError_t g2_launch(const G2Args& g_in, const Epi& epi, int nbranch, hipStream_t st) {
   G2Args g = g_in;
 #ifdef SG_G2_DEBUG
@@ -253,7 +287,7 @@ static inline hipError_t g2_launch(const G2Args& g_in, const Epi& epi, int nbran
   const int ngroups = g.xcd_mode ? g.nz : g.nx * g.nz;
   const int gt = g.xcd_mode ? g.nx * g.ny : g.ny;
   dim3 grid(8 * ((ngroups + 7) / 8) * gt);
-  if (vec) hipLaunchKernelGGL((sg_gemm2<Epi, A_KC, B_KC, true, BM>), grid, dim3(256), 0, st, g, epi);
-  else hipLaunchKernelGGL((sg_gemm2<Epi, A_KC, B_KC, false, BM>), grid, dim3(256), 0, st, g, epi);
+  if (vec) hipLaunchKernelGGL((sg_gemm2<Epi, A_KC, B_KC, true, BM, TL>), grid, dim3(256), 0, st, g, epi);
+  else hipLaunchKernelGGL((sg_gemm2<Epi, A_KC, B_KC, false, BM, TL>), grid, dim3(256), 0, st, g, epi);
   return hipGetLastError();
 }
