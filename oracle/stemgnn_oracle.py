@@ -104,18 +104,25 @@ def gru_front(x, sd):
     return out.permute(1, 0, 2).contiguous()  # [B, N_seq, N_hid]
 
 
-def self_graph_attention(gru_out, wk, wq, alpha=0.2, drop_mask=None, drop_p=0.0):
+def self_graph_attention(gru_out, wk, wq, alpha=0.2, drop_mask=None, drop_p=0.0, kink_pos=None):
     """models/base_model.py:151-162.
 
     gru_out [B, N_seq, N_hid]; the adjacency's node axis is the GRU *hidden* index (:152).
     ``drop_mask`` ([B,N,N] of 0/1) stands in for nn.Dropout's Bernoulli mask (:161) so
     train-mode results are reproducible; None = eval mode / p=0.
+    ``kink_pos`` (bool [B,N,N], optional): which side of the LeakyReLU kink each logit key_i+query_j is taken to be
+    on.  The gradient is discontinuous at 0; with B*N*N logits some lie closer to 0 than the fp32 rounding of
+    key/query (tools/kink_probe.py), so a test that compares against higher precision passes the decisions of the
+    implementation under test instead of letting the sign of a 1e-8 number decide.
     """
     inp = gru_out.permute(0, 2, 1)                       # :152  [B, i=hid, s=seq]
     key = torch.matmul(inp, wk)                          # :154  [B,N,1]
     query = torch.matmul(inp, wq)                        # :155  [B,N,1]
     data = key + query.transpose(1, 2)                   # :156-158  data[b,i,j] = key[b,i] + query[b,j]
-    data = F.leaky_relu(data, alpha)                     # :159
+    if kink_pos is None:
+        data = F.leaky_relu(data, alpha)                 # :159
+    else:
+        data = torch.where(kink_pos, data, alpha * data)
     att = torch.softmax(data, dim=2)                     # :160
     if drop_mask is not None and drop_p > 0.0:
         att = att * drop_mask / (1.0 - drop_p)           # :161 (inverted dropout)
@@ -200,13 +207,13 @@ def stock_block(X, mul_L, sd, s):
 # --------------------------------------------------------------------------- #
 # whole model
 # --------------------------------------------------------------------------- #
-def hot_path(gru_out, x, sd, alpha=0.2, drop_mask=None, drop_p=0.0, spectral="cheb"):
+def hot_path(gru_out, x, sd, alpha=0.2, drop_mask=None, drop_p=0.0, spectral="cheb", kink_pos=None):
     """Everything after the GRU up to the summed block forecasts (models/base_model.py:139-148, 169-174).
 
     gru_out [B,N,N] (batch-first, as after :138), x [B,W,N].
     Returns (fsum [B,N,W], attention [N,N], mul_L [4,N,N]).
     """
-    att = self_graph_attention(gru_out, sd["weight_key"], sd["weight_query"], alpha, drop_mask, drop_p)
+    att = self_graph_attention(gru_out, sd["weight_key"], sd["weight_query"], alpha, drop_mask, drop_p, kink_pos)
     L, A_s = laplacian_from_attention(att)
     mul_L = cheb_polynomial(L) if spectral == "cheb" else cheb_from_eig(L)
     X = x.unsqueeze(1).permute(0, 1, 3, 2)                # :169  [B,1,N,W]
@@ -215,10 +222,10 @@ def hot_path(gru_out, x, sd, alpha=0.2, drop_mask=None, drop_p=0.0, spectral="ch
     return f0 + f1, A_s, mul_L                            # :174
 
 
-def model_forward(x, sd, alpha=0.2, drop_mask=None, drop_p=0.0, spectral="cheb"):
+def model_forward(x, sd, alpha=0.2, drop_mask=None, drop_p=0.0, spectral="cheb", kink_pos=None):
     """models/base_model.py:167-179.  x [B,W,N] -> (forecast [B,H,N] (or [B,1,N] if H==1), attention [N,N])."""
     gru_out = gru_front(x, sd)
-    fsum, A_s, _ = hot_path(gru_out, x, sd, alpha, drop_mask, drop_p, spectral)
+    fsum, A_s, _ = hot_path(gru_out, x, sd, alpha, drop_mask, drop_p, spectral, kink_pos)
     y = F.linear(fsum, sd["fc.0.weight"], sd["fc.0.bias"])               # :175
     y = F.leaky_relu(y, 0.01)
     y = F.linear(y, sd["fc.2.weight"], sd["fc.2.bias"])

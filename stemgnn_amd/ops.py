@@ -294,6 +294,21 @@ class StockBlockFn(torch.autograd.Function):
 
 
 _prepacked = {}
+_keep_attention_state = False
+_last_attention_state = {}
+
+
+def capture_attention_state(flag=True):
+    """Test hook: keep the key / query vectors ([B,N] each) of the last SpectralHotPath.forward per device, so a
+    reference computed at higher precision can take the same LeakyReLU-kink decisions (key_i + query_j > 0)."""
+    global _keep_attention_state
+    _keep_attention_state = bool(flag)
+    if not flag:
+        _last_attention_state.clear()
+
+
+def last_attention_state(device):
+    return _last_attention_state.get(str(torch.device(device)))
 
 
 def prepack_blocks(block_params, W, multi, device):
@@ -346,6 +361,9 @@ class SpectralHotPath(torch.autograd.Function):
             h.data_ptr(), wk.data_ptr(), wq.data_ptr(), float(alpha), float(drop_p), int(bool(training)),
             seed.data_ptr() if use_drop else None, B, N, attn_saved.data_ptr(), attention.data_ptr(),
             mul_L.data_ptr(), st), "attn_laplacian_fwd")
+        if _keep_attention_state:
+            _last_attention_state[str(dev)] = (attn_saved[:B * N].view(B, N).clone(),
+                                               attn_saved[B * N:2 * B * N].view(B, N).clone())
         if os.environ.get("STEMGNN_SPECTRAL", "cheb") == "eig":
             # north-star eigen route: L = U^T diag(lam) U, T_k = sum_e p_k(lam_e) u_e u_e^T (same function of L;
             # the backward below is the polynomial one either way -- never differentiates through eigenvectors)

@@ -298,37 +298,37 @@ def test_stock_block_layer_standalone(stack_i):
 # fallback (W=48, H=12 exceeds the fused tail's LDS budget) and W*multi = 240.
 @pytest.mark.parametrize("N,W,multi,H,B", [(1024, 12, 5, 3, 3), (2048, 48, 5, 12, 2)])
 def test_large_config_shapes(N, W, multi, H, B):
-    """At N >= 1024 the softmax is nearly uniform and d loss / d weight_key,query are ~1e-8 sums of cancelling terms:
-    the reference's own fp32 arithmetic is only ~1e-3 accurate there.  So the yardstick is an fp64 run of the oracle:
-    the HIP result must be within the 1e-4 budget of it, or at least as close to it as 3x the fp32 oracle's own error."""
+    """configs[3] / configs[4] shapes against an fp64 run of the oracle, everything inside the 1e-4 budget.
+
+    With B*N*N attention logits, a few key_i + query_j land closer to 0 than the fp32 rounding of key/query (2.5e-8 and
+    5e-8 at N = 2048, tools/kink_probe.py), and LeakyReLU's derivative jumps there: flipping those two decisions moves
+    the ~1e-8 gradients of weight_key / weight_query / the GRU by 1e-3 (torch's own fp32 run flips one against fp64).
+    So the fp64 yardstick takes the kink decisions of the implementation under test (its key / query vectors, one fp32
+    add per logit exactly as the kernel does) instead of letting the sign of a 1e-8 number decide."""
+    from stemgnn_amd import ops
     sd = O.det_state_dict(N, W, multi, H, seed=N)
     torch.manual_seed(N)
     x, y = torch.randn(B, W, N), torch.randn(B, H, N)
     model = _hip_model(N, W, multi, H, sd, p=0.0, train=True)
-    loss, forecast, att = _run_hip(model, x, y)
+    ops.capture_attention_state(True)
+    try:
+        loss, forecast, att = _run_hip(model, x, y)
+        key, query = (t.cpu() for t in ops.last_attention_state("cuda:0"))
+    finally:
+        ops.capture_attention_state(False)
+    kink_pos = (key.unsqueeze(2) + query.unsqueeze(1)) > 0                        # [B,N,N], fp32 add as in the kernels
     sd64 = {k: v.double() for k, v in sd.items()}
-    _, t_forecast, t_att, t_grads = O.loss_and_grads(x.double(), y.double(), sd64)       # fp64 "truth"
-    _, o_forecast, o_att, o_grads = O.loss_and_grads(x, y, sd)                           # the reference's fp32 arithmetic
-    rows = [("forecast", relerr(forecast, t_forecast), relerr(o_forecast, t_forecast)),
-            ("attention", relerr(att, t_att), relerr(o_att, t_att))]
+    _, t_forecast, t_att, t_grads = O.loss_and_grads(x.double(), y.double(), sd64, kink_pos=kink_pos)
+    rows = [("forecast", relerr(forecast, t_forecast)), ("attention", relerr(att, t_att))]
     for k, p in model.named_parameters():
         if t_grads[k] is None:
             assert p.grad is None, k
         else:
-            rows.append(("grad." + k, relerr(p.grad, t_grads[k]), relerr(o_grads[k], t_grads[k])))
-    # Known gap (DESIGN.md section 8): at N = 2048 the gradients that pass through the softmax backward of the almost
-    # uniform attention (weight_key/query and, through dh, the GRU parameters; magnitudes ~1e-8) are differences of
-    # nearly equal numbers; the long fp32 MFMA accumulation chains upstream leave ~10x more rounding noise than MKL's
-    # blocked sums and those four tensors reach 2.4e-3 against fp64 (the fp32 reference: 8e-6).  Everything else is
-    # held to the 1e-4 budget.
-    def budget(k, eo):
-        loose = N >= 2048 and (k.startswith("grad.GRU.") or k in ("grad.weight_key", "grad.weight_query"))
-        return max(5e-3 if loose else TOL, 3 * eo)
-
-    bad = [(k, e, eo) for k, e, eo in rows if not e < budget(k, eo)]
+            rows.append(("grad." + k, relerr(p.grad, t_grads[k])))
     worst = sorted(rows, key=lambda r: -r[1])[:6]
-    print("worst (name, hip-vs-fp64, fp32oracle-vs-fp64):", [(k, f"{e:.2e}", f"{eo:.2e}") for k, e, eo in worst])
-    assert not bad, [(k, f"{e:.2e}", f"{eo:.2e}") for k, e, eo in bad]
+    print("worst (name, hip-vs-fp64):", [(k, f"{e:.2e}") for k, e in worst])
+    bad = [(k, f"{e:.2e}") for k, e in rows if not e < TOL]
+    assert not bad, bad
 
 
 @pytest.mark.parametrize("shape", [(32, 228, 12, 5), (3, 20, 12, 5), (2, 9, 4, 2)])
