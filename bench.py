@@ -136,6 +136,9 @@ def main():
     from stemgnn_amd.optim import FusedRMSprop
 
     cfg = dict(WORKLOAD)
+    if os.environ.get("STEMGNN_BENCH_WORKLOAD"):     # "N,W,H,multi,B": other BASELINE configs (reported in DESIGN.md only;
+        vals = [int(v) for v in os.environ["STEMGNN_BENCH_WORKLOAD"].split(",")]   # the default line stays configs[1])
+        cfg = dict(zip(("N", "W", "H", "multi", "B"), vals))
     torch.manual_seed(0)
     model = Model(cfg["N"], 2, cfg["W"], cfg["multi"], horizon=cfg["H"])      # defaults: dropout 0.5, leaky 0.2
     model.to(dev).train()
@@ -192,8 +195,9 @@ def main():
         "metric": "forecast-steps/sec (train)", "value": value, "unit": "forecast-steps/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "PEMS07-shape N=228 W=12 H=3 multi=5 stack=2, batch 32 per GPU, train step "
-                               "(window gather+fwd+MSE+bwd+RMSprop), dropout 0.5", "global_batch": world * cfg["B"],
+        "config": {"workload": ("PEMS07-shape " if cfg == WORKLOAD else "") +
+                               f"N={cfg['N']} W={cfg['W']} H={cfg['H']} multi={cfg['multi']} stack=2, batch {cfg['B']} per GPU, "
+                               "train step (window gather+fwd+MSE+bwd+RMSprop), dropout 0.5", "global_batch": world * cfg["B"],
                    "per_gpu_batch": cfg["B"], "parallelism": f"dp{world}", "launch": mode},
         "final_loss": final_loss,
     }
