@@ -199,3 +199,47 @@ def test_train_loop_reproduces_reference_run(tmp_path, hipgraph, monkeypatch):
         assert os.path.exists(os.path.join(str(tmp_path), fn)), fn
     test_metrics = handler.test(raw[ntrain:], args, str(tmp_path), str(tmp_path / "test"))
     np.testing.assert_allclose(test_metrics["mae"], vals[-1]["mae"], rtol=1e-6)       # same data, same best model
+
+
+def test_data_path_edge_cases():
+    """empty / ragged / degenerate inputs of the data path: a series too short for one window, a single window,
+    list statistics for min_max (the reference's own train() builds lists and then fails on them), one-row metrics,
+    a one-element MSE, a rolling inference whose last model call overshoots the horizon."""
+    from stemgnn_amd import handler, math_utils, ops
+    from stemgnn_amd.forecast_dataloader import ForecastDataset, WindowLoader
+    rng = np.random.default_rng(0)
+    W, H, N = 6, 3, 5
+    short = ForecastDataset(rng.normal(size=(W + H - 1, N)), W, H, normalize_method="z_score", device=DEV)
+    assert len(short) == 0 and list(WindowLoader(short, batch_size=4)) == []
+    one = ForecastDataset(rng.normal(size=(W + H, N)), W, H, normalize_method="z_score", device=DEV)
+    assert len(one) == 1
+    (xb, yb), = list(WindowLoader(one, batch_size=4))
+    assert xb.shape == (1, W, N) and yb.shape == (1, H, N)
+    assert torch.equal(xb[0], one.data[:W]) and torch.equal(yb[0], one.data[W:])
+    with pytest.raises(IndexError):
+        one[1]
+    raw = rng.normal(size=(40, N)) * 3 + 1
+    stat = {"min": raw.min(axis=0).tolist(), "max": raw.max(axis=0).tolist()}        # lists, as handler.py:116-119 builds
+    mm = ForecastDataset(raw, W, H, normalize_method="min_max", norm_statistic=stat, device=DEV)
+    want, _ = do.normalized(raw, "min_max", stat)
+    np.testing.assert_array_equal(mm.data.cpu().numpy(), want.astype(np.float32))
+    t, f = torch.randn(1, H, N, device=DEV), torch.randn(1, H, N, device=DEV)
+    got = math_utils.evaluate(t, f)
+    want = do.evaluate(t.cpu().numpy(), f.cpu().numpy().astype(np.float64))
+    np.testing.assert_allclose(got, want, rtol=1e-12)
+    a, b = torch.tensor([[[2.0]]], device=DEV, requires_grad=True), torch.tensor([[[0.5]]], device=DEV)
+    l = ops.mse_loss(a, b)
+    l.backward()
+    assert float(l) == 2.25 and float(a.grad) == 3.0
+    ds = ForecastDataset(raw, W, 4, normalize_method="z_score", device=DEV)          # horizon 4, model emits 3 per call
+    fr, tg = handler.inference(StubModel(3), WindowLoader(ds, batch_size=8), DEV, N, W, 4)
+    data, _ = do.normalized(do.fill_na(raw), "z_score", None)
+    fs = [do.rolling_inference(stub_np(3), xb_, W, 4) for xb_, _ in do.batches(data, do.x_end_idx(40, W, 4), 8, W, 4)]
+    np.testing.assert_array_equal(fr.cpu().numpy().astype(np.float64), np.concatenate(fs))
+
+
+def stub_np(L):
+    def fn(x):
+        Wn = x.shape[1]
+        return np.stack([np.float32(0.5) * x[:, Wn - 1 - j, :] + np.float32(0.25) for j in range(L)], axis=1)
+    return fn
