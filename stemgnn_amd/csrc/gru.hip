@@ -459,7 +459,10 @@ __global__ __launch_bounds__(3 * (P / OW) * 64) void gru_fwd_cluster2_kernel(con
   int k0[OW], kn[OW];
 #pragma unroll
   for (int o = 0; o < OW; ++o) {
-    k0[o] = (q0 + o) * U;
+    // owner of this wave's o-th k-slice, rotated by p: wave 0's first slice is the workgroup's OWN units, whose
+    // values it already holds in registers (lane = unit) -- the wave that runs the gate phase and its global
+    // prefetches never has to poll (its poll would queue behind those prefetch loads: vmcnt retires in order)
+    k0[o] = ((q0 + o + p) % P) * U;
     kn[o] = max(0, min(Hd, k0[o] + U) - k0[o]);
     const bool lane_ok = lane < un;
     const float* wrow = w_hh + ((size_t)g * Hd + (lane_ok ? u0 + lane : 0)) * Hd + (kn[o] > 0 ? k0[o] : 0);
@@ -480,8 +483,9 @@ __global__ __launch_bounds__(3 * (P / OW) * 64) void gru_fwd_cluster2_kernel(con
 #pragma unroll
     for (int o = 0; o < OW; ++o) {
       float hv = 0.f;
-      if (s > 0) hv = gru_poll_lane(xbuf + ((size_t)(s & 1) * B + b) * Hd + k0[o] + (lane < kn[o] ? lane : 0), (unsigned)s,
-                                    lane < kn[o], status);
+      if (wave == 0 && o == 0) hv = hown;                 // own slice: h_{s-1} of unit `lane` is this lane's register
+      else if (s > 0) hv = gru_poll_lane(xbuf + ((size_t)(s & 1) * B + b) * Hd + k0[o] + (lane < kn[o] ? lane : 0),
+                                         (unsigned)s, lane < kn[o], status);
       part[s & 1][g * P + q0 + o][lane] = gru_matvec<KU>(wr[o], hv);
     }
     __syncthreads();
@@ -529,7 +533,7 @@ __global__ __launch_bounds__(3 * (P / OW) * 64) void gru_bwd_cluster2_kernel(con
   int k0[OW], kn[OW];
 #pragma unroll
   for (int o = 0; o < OW; ++o) {
-    k0[o] = (q0 + o) * U;
+    k0[o] = ((q0 + o + p) % P) * U;                       // rotated by p: wave 0's first slice is the own one (see forward)
     kn[o] = max(0, min(Hd, k0[o] + U) - k0[o]);
     const bool lane_ok = lane < un;
     const float* wcol = w_hh + ((size_t)g * Hd + (kn[o] > 0 ? k0[o] : 0)) * Hd + (lane_ok ? u0 + lane : 0);
@@ -554,6 +558,7 @@ __global__ __launch_bounds__(3 * (P / OW) * 64) void gru_bwd_cluster2_kernel(con
     const size_t row = (size_t)s * B + b;
     const unsigned tag = (unsigned)(S - s);
     gru_u64* xb = xbuf + ((size_t)(tag & 1) * B + b) * H3;
+    float own_dr = 0.f;
     if (tid < un) {
       float dh = p_do + dhz;
 #pragma unroll
@@ -564,6 +569,7 @@ __global__ __launch_bounds__(3 * (P / OW) * 64) void gru_bwd_cluster2_kernel(con
       const float dz = dh * (hprev - n) * z * (1.f - z);
       const float dr = dn * ghn * r * (1.f - r);
       const float dnr = dn * r;
+      own_dr = dr;
       dhz = dh * z;
       if (s > 0) {
         gru_publish(xb + gu, tag, dr);
@@ -582,7 +588,9 @@ __global__ __launch_bounds__(3 * (P / OW) * 64) void gru_bwd_cluster2_kernel(con
     if (s == 0) break;
 #pragma unroll
     for (int o = 0; o < OW; ++o) {
-      const float dv = gru_poll_lane(xb + (size_t)g * Hd + k0[o] + (lane < kn[o] ? lane : 0), tag, lane < kn[o], status);
+      float dv;
+      if (wave == 0 && o == 0) dv = own_dr;               // gate r, own units: computed by this lane a moment ago
+      else dv = gru_poll_lane(xb + (size_t)g * Hd + k0[o] + (lane < kn[o] ? lane : 0), tag, lane < kn[o], status);
       part[tag & 1][g * P + q0 + o][lane] = gru_matvec<KU>(wr[o], dv);
     }
     __syncthreads();
