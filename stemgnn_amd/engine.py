@@ -27,7 +27,9 @@ def capture(fn, warmups=3):
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        # thread_local: only this thread's calls are policed during capture -- with torch.distributed initialised, the
+        # RCCL watchdog thread queries events concurrently, which the default global mode may treat as a capture violation
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
             fn()
         torch.cuda.synchronize()
         return g.replay
