@@ -24,16 +24,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 
 from oracle.detrand import det_normalish, det_uniform  # noqa: E402
 from oracle.ref_shim import load_reference_packages  # noqa: E402
-
-
-def synthetic_series(T, N, seed):
-    """sin(2 pi t / p_n + phi_n) * a_n + c_n + noise (SURVEY 8d shape), float64."""
-    t = np.arange(T, dtype=np.float64)[:, None]
-    p = det_uniform((N,), seed, 6.0, 30.0).astype(np.float64)
-    phi = det_uniform((N,), seed + 1, 0.0, 6.28).astype(np.float64)
-    a = det_uniform((N,), seed + 2, 0.5, 3.0).astype(np.float64)
-    c = det_uniform((N,), seed + 3, -2.0, 8.0).astype(np.float64)
-    return np.sin(2 * np.pi * t / p + phi) * a + c + 0.1 * det_normalish((T, N), seed + 4).astype(np.float64)
+from tests.util import synthetic_series  # noqa: E402
 
 
 def save(name, **kw):
@@ -121,10 +112,10 @@ def case_rolling(fd, hd):
     save("rolling", raw=raw, cfg=np.array([T, N, W, horizon, L, bs], np.int64), forecast=f, target=t)
 
 
-def case_train(fd, hd):
-    T, N, W, H, multi, bs, epochs = 150, 8, 6, 3, 2, 16, 3
+def case_train(fd, hd, name="train_e2e", T=150, N=8, W=6, H=3, multi=2, bs=16, epochs=3, ntrain=110, lr=1e-3,
+               keep_weights=True):
     raw = synthetic_series(T, N, 303)
-    train_data, valid_data = raw[:110], raw[110:]
+    train_data, valid_data = raw[:ntrain], raw[ntrain:]
     ref_model_cls = hd.Model
     log = dict(order=[], losses=[], metrics=[], init=None)
 
@@ -151,32 +142,41 @@ def case_train(fd, hd):
         log["metrics"].append(r)
         return r
 
+    saved = (hd.Model, hd.ForecastDataset, hd.validate, hd.nn)
     hd.Model, hd.ForecastDataset, hd.validate = make_model, LoggedDataset, logged_validate
     hd.nn = types.SimpleNamespace(MSELoss=LoggedMSE)
     args = types.SimpleNamespace(window_size=W, horizon=H, multi_layer=multi, device="cpu", norm_method="z_score",
-                                 optimizer="RMSProp", lr=1e-3, decay_rate=0.5, exponential_decay_step=2,
+                                 optimizer="RMSProp", lr=lr, decay_rate=0.5, exponential_decay_step=2,
                                  batch_size=bs, epoch=epochs, validate_freq=1, early_stop=False)
     torch.manual_seed(0)                                        # main.py:52
-    with tempfile.TemporaryDirectory() as d:
-        metrics, stat = hd.train(train_data, valid_data, args, d)
-        with open(os.path.join(d, "_stemgnn.pt"), "rb") as f:   # best model (handler.py:184-185); shim item 4
-            final = torch.load(f, weights_only=False)
+    try:
+        with tempfile.TemporaryDirectory() as d:
+            metrics, stat = hd.train(train_data, valid_data, args, d)
+            with open(os.path.join(d, "_stemgnn.pt"), "rb") as f:   # best model (handler.py:184-185); shim item 4
+                final = torch.load(f, weights_only=False)
+    finally:
+        hd.Model, hd.ForecastDataset, hd.validate, hd.nn = saved
     ids = []
     for i, _ in log["order"]:
         if i not in ids:
             ids.append(i)
     train_order = np.asarray([ix for i, ix in log["order"] if i == ids[0]], np.int64)
-    out = dict(raw=raw, cfg=np.array([T, N, W, H, multi, bs, epochs, 110], np.int64), lr=np.float64(1e-3),
+    out = dict(cfg=np.array([T, N, W, H, multi, bs, epochs, ntrain], np.int64), lr=np.float64(lr),
                train_order=train_order, losses=np.asarray(log["losses"], np.float64),
                stat_mean=np.asarray(stat["mean"]), stat_std=np.asarray(stat["std"]))
     for e, m in enumerate(log["metrics"]):
         for k, v in m.items():
             out[f"val{e}_{k}"] = np.asarray(v, np.float64)
-    for k, v in log["init"].items():
-        out["init." + k] = v
-    for k, v in final.state_dict().items():
-        out["final." + k] = v.detach().numpy()
-    save("train_e2e", **out)
+    if keep_weights:                       # small case: the series and both state dicts travel with the fixture
+        out["raw"] = raw
+        for k, v in log["init"].items():
+            out["init." + k] = v
+        for k, v in final.state_dict().items():
+            out["final." + k] = v.detach().numpy()
+    else:                                  # real shape: series and initial weights are regenerated from the seeds
+        out["raw_seed"] = np.int64(303)
+        out["init_sum"] = np.float64(sum(float(np.abs(v).sum()) for v in log["init"].values()))
+    save(name, **out)
     print("  losses", np.round(log["losses"][:3], 5), "...", np.round(log["losses"][-2:], 5),
           "val mae", [float(m["mae"]) for m in log["metrics"]])
 
@@ -189,3 +189,6 @@ if __name__ == "__main__":
     case_metrics(fd, mu)
     case_rolling(fd, hd)
     case_train(fd, hd)
+    # the headline shape (PEMS07: N=228, W=12, H=3, multi=5, batch 32): 2 epochs of the reference's handler.train
+    case_train(fd, hd, name="train_pems07", T=500, N=228, W=12, H=3, multi=5, bs=32, epochs=2, ntrain=350, lr=1e-4,
+               keep_weights=False)

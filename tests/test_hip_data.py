@@ -243,3 +243,29 @@ def stub_np(L):
         Wn = x.shape[1]
         return np.stack([np.float32(0.5) * x[:, Wn - 1 - j, :] + np.float32(0.25) for j in range(L)], axis=1)
     return fn
+
+
+def test_train_loop_at_pems07_shape_reproduces_reference_run(tmp_path, monkeypatch):
+    """"MAE vs ref" at the headline shape (BASELINE metric, second half): 2 epochs of the reference's handler.train at
+    N=228, W=12, H=3, multi=5, batch 32 (dropout 0) replayed through stemgnn_amd.handler.train with the same seed ->
+    same initial weights and shuffle; per-step loss and validation MAE / MAPE / RMSE agree to fp32 training drift."""
+    from stemgnn_amd import Model, handler
+    from tests.util import synthetic_series
+    z = G("train_pems07")
+    T, N, W, H, multi, bs, epochs, ntrain = (int(v) for v in z["cfg"])
+    raw = synthetic_series(T, N, int(z["raw_seed"]))
+    args = types.SimpleNamespace(window_size=W, horizon=H, multi_layer=multi, device=DEV, norm_method="z_score",
+                                 optimizer="RMSProp", lr=float(z["lr"]), decay_rate=0.5, exponential_decay_step=2,
+                                 batch_size=bs, epoch=epochs, validate_freq=1, early_stop=False, hipgraph=True)
+    losses, vals = [], []
+    real_validate = handler.validate
+    monkeypatch.setattr(handler, "validate", lambda *a, **k: vals.append(real_validate(*a, **k)) or vals[-1])
+    torch.manual_seed(0)
+    handler.train(raw[:ntrain], raw[ntrain:], args, str(tmp_path),
+                  model_factory=lambda *a, **k: Model(*a, dropout_rate=0.0, **k),
+                  step_hook=lambda e, i, st: losses.append(st.loss.clone()))
+    got = torch.stack(losses).cpu().numpy().astype(np.float64)
+    np.testing.assert_allclose(got, z["losses"], rtol=1e-3)
+    for e in range(epochs):
+        for k in ("mae", "mape", "rmse", "mae_node"):
+            np.testing.assert_allclose(vals[e][k], z[f"val{e}_{k}"], rtol=2e-3, err_msg=f"epoch {e} {k}")

@@ -30,3 +30,15 @@ def relerr(got, ref):
     den = ref.abs().max().item()
     num = (got - ref).abs().max().item()
     return num / den if den > 0 else num
+
+
+def synthetic_series(T, N, seed):
+    """sin(2 pi t / p_n + phi_n) * a_n + c_n + noise (SURVEY 8d shape), float64, from the deterministic generators of
+    oracle/detrand.py (so a fixture can name a seed instead of carrying the series)."""
+    from oracle.detrand import det_normalish, det_uniform
+    t = np.arange(T, dtype=np.float64)[:, None]
+    p = det_uniform((N,), seed, 6.0, 30.0).astype(np.float64)
+    phi = det_uniform((N,), seed + 1, 0.0, 6.28).astype(np.float64)
+    a = det_uniform((N,), seed + 2, 0.5, 3.0).astype(np.float64)
+    c = det_uniform((N,), seed + 3, -2.0, 8.0).astype(np.float64)
+    return np.sin(2 * np.pi * t / p + phi) * a + c + 0.1 * det_normalish((T, N), seed + 4).astype(np.float64)
