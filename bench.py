@@ -1,113 +1,276 @@
 #!/usr/bin/env python
 """bench.py -- forecast-steps/sec (train) of the StemGNN hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1: one rank per GPU over RCCL.  Started under torch.distributed.run (RANK / WORLD_SIZE in the environment) it is
+one rank; started plainly with --gpus N it re-launches itself through torch.distributed.run with N ranks on 127.0.0.1.
 
 A "step" is one optimizer step of the drop-in model on one synthetic PEMS07-shaped batch
-(N=228, W=12, H=3, multi=5, per-GPU batch 32 -- BASELINE.json configs[1]): zero_grad -> forward ->
-MSELoss -> backward -> (flat grad all-reduce over RCCL when N>1) -> RMSprop(lr=1e-4, eps=1e-8) step,
-exactly the reference's loop body (models/handler.py:157-165); the z-scored series is resident in HBM and the
-batch windows are gathered from it by index inside the step (stemgnn_amd.engine.TrainStep, the same object
-stemgnn_amd.handler.train drives).
+(N=228, W=12, H=3, multi=5, per-GPU batch 32 -- BASELINE.json configs[1]): window gather from the HBM-resident series
+-> zero_grad -> forward -> MSELoss -> backward -> (flat grad all-reduce over RCCL when N>1) -> RMSprop(lr=1e-4,
+eps=1e-8), the reference's loop body (models/handler.py:157-165) as stemgnn_amd.engine.TrainStep runs it (one hipGraph).
 Weak scaling: every rank trains on its own 32-sample batch ("replicas with a local graph").
 
-Rank 0 prints ONE JSON line with the throughput, a `roofline` object for the dominant kernel
-(timed live with HIP events on the launch stream) and, at N=1, a `cpu_baseline` object: the CPU oracle
-port of the same train step timed on this box's host cores.
+Rank 0 prints ONE JSON line: the throughput, a `roofline` object for the MFMA GEMM family with the largest summed GPU
+time per step (each family timed live with HIP events on the launch stream; `roofline_families` lists all of them),
+at N=1 a `cpu_baseline` object (the real reference when /root/reference is mounted, else the oracle port, timed on this
+box's host cores) and `other_configs`: short single-GPU runs of the per-GPU shards of BASELINE.json configs[0],[2],[3],[4].
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
-
 WORKLOAD = dict(N=228, W=12, H=3, multi=5, B=32)      # PEMS07 shape, BASELINE.json configs[1]
+# per-GPU shards of the other BASELINE.json configs (global batch / 8 GPUs for configs[3], [4])
+OTHER_CONFIGS = [
+    ("configs[0] ECG shape", dict(N=140, W=12, H=3, multi=5, B=32)),
+    ("configs[2] PEMS03 shape", dict(N=358, W=12, H=3, multi=5, B=32)),
+    ("configs[3] N=1024, global batch 64 on 8 GPUs -> per-GPU shard 8", dict(N=1024, W=12, H=3, multi=5, B=8)),
+    ("configs[4] N=2048 W=48 H=12, global batch 128 on 8 GPUs -> per-GPU shard 16", dict(N=2048, W=48, H=12, multi=5, B=16)),
+]
 FP32_MFMA_PEAK_TFLOPS = 157.3                          # MI355X_MICROARCH.md: v_mfma_f32_* dense peak
-ROOFLINE_TRAFFIC_BYTES = 36.3e6                        # profiles/r01_v7_pmc_fetch_write.md (dominant kernel, per launch)
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")   # HBM bytes per launch from the PMC passes
 
 
-def glu_fwd_flops(B, N, W, multi):
-    """Algorithmic FLOPs of one stemgnn_spectral_glu_fwd call (3 GEMM launches, both branches), dense count
-    of SURVEY 8d: 2*M*(C0*2C + 2C*C + 2C*C) per branch with C0 = 4W, C = 4*W*multi."""
-    M, C0, C = B * N, 4 * W, 4 * W * multi
-    return 2 * (2.0 * M * (C0 * 2 * C + C * 2 * C + C * 2 * C))
+def _self_launch(args):
+    """`python bench.py --gpus N` without a launcher: become N ranks through torch.distributed.run."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.run(cmd, env=env).returncode)
 
 
-def time_dominant_kernel(cfg, iters=20):
-    """Average launch duration of the dominant roofline kernel (sg_gemm2<GluFwdEpi>: the 3 launches of one
-    stemgnn_spectral_glu_fwd call), HIP events on the launch stream."""
-    from stemgnn_amd import _lib
+# ---------------------------------------------------------------------------------------------------------------
+# roofline: the MFMA GEMM families of the spectral GLU stack (94 % of the hot path's FLOPs)
+def glu_flops(cfg):
+    """(algorithmic, executed) FLOPs of ONE pass over the three GLU layers of one block, both branches.
+    algorithmic: dense count of SURVEY 8d, 2*M*(C0*2C + 2C*C + 2C*C) per branch, C0 = 4W, C = 4*W*multi.
+    executed: what the kernels multiply -- the zero k=0 Chebyshev slice is skipped (K 4W -> 3W), the dead C2R bins of
+    the last layer are dropped (N 2C -> 2*ceil16(4*nf)), widths padded to multiples of 16."""
+    B, N, W, multi = cfg["B"], cfg["N"], cfg["W"], cfg["multi"]
+    M, Wm = B * N, W * multi
+    C0, C = 4 * W, 4 * Wm
+
+    def c16(v):
+        return (v + 15) // 16 * 16
+    alg = 2 * (2.0 * M * (C0 * 2 * C + C * 2 * C + C * 2 * C))
+    CP = c16(C)
+    cp2 = [c16(4 * (Wm // 2 + 1)), c16(max(4 * ((Wm + 1) // 2 - 1), 1))]
+    exe = sum(2.0 * M * (3 * W * 2 * CP + CP * 2 * CP + CP * 2 * cp2[r]) for r in range(2))
+    return alg, exe
+
+
+def time_gemm_families(cfg, iters=20):
+    """Live HIP-event timing (on the launch stream) of the three GEMM families, through the C ABI on random operands.
+    Returns {family: dict(us_per_call, launches_per_call, calls_per_step, kernel)}."""
+    import torch
+    from stemgnn_amd import _lib, ops
 
     lib = _lib.load()
     B, N, W, multi = cfg["B"], cfg["N"], cfg["W"], cfg["multi"]
     dev = torch.device("cuda")
+    nsplit = ops._NSPLIT
     packed = torch.randn(lib.stemgnn_packed_floats(W, multi), device=dev) * 0.05
     saved = torch.randn(lib.stemgnn_saved_floats(B, N, W, multi), device=dev)
+    scratch = torch.randn(lib.stemgnn_scratch_floats(B, N, W, multi), device=dev) * 0.1
+    gradpart = torch.empty(lib.stemgnn_gradpart_floats(W, multi, nsplit), device=dev)
     st = torch.cuda.current_stream()
 
-    def run():
-        _lib.check(lib.stemgnn_spectral_glu_fwd(packed.data_ptr(), saved.data_ptr(), B, N, W, multi, st.cuda_stream),
-                   "spectral_glu_fwd")
+    def fwd():
+        _lib.check(lib.stemgnn_spectral_glu_fwd(packed.data_ptr(), saved.data_ptr(), B, N, W, multi, st.cuda_stream), "glu_fwd")
 
-    for _ in range(3):
-        run()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record(st)
-    for _ in range(iters):
-        run()
-    e1.record(st)
-    e1.synchronize()
-    launches = 3 * iters
-    avg_s = e0.elapsed_time(e1) * 1e-3 / launches
-    flops_per_launch = glu_fwd_flops(B, N, W, multi) / 3.0
-    return avg_s, flops_per_launch
+    def bwd(parts):
+        def run():
+            _lib.check(lib.stemgnn_spectral_glu_bwd(packed.data_ptr(), saved.data_ptr(), scratch.data_ptr(),
+                                                    gradpart.data_ptr(), nsplit, parts, B, N, W, multi, st.cuda_stream),
+                       "glu_bwd")
+        return run
+
+    fams = {
+        "glu_fwd": (fwd, 3, "sg_gemm2<GluFwdEpi> (spectral GLU forward, 3 launches per block, both branches per launch)"),
+        "glu_dgrad": (bwd(1), 3, "sg_gemm2<GluDpreEpi> x2 + sg_gemm_f32<GluDgrad0Op> (GLU data gradients)"),
+        "glu_wgrad": (bwd(2), 3, "sg_gemm2 weight-gradient GEMMs (GLU dW, reduction over the M = B*N rows)"),
+    }
+    out = {}
+    for name, (fn, launches, kernel) in fams.items():
+        for _ in range(3):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(st)
+        for _ in range(iters):
+            fn()
+        e1.record(st)
+        e1.synchronize()
+        out[name] = dict(us_per_call=e0.elapsed_time(e1) * 1e3 / iters, launches_per_call=launches, calls_per_step=2,
+                         kernel=kernel)
+    return out
 
 
+def roofline_objects(cfg):
+    fams = time_gemm_families(cfg)
+    alg, exe = glu_flops(cfg)
+    traffic = {}
+    if os.path.isfile(TRAFFIC_FILE):
+        with open(TRAFFIC_FILE) as f:
+            traffic = json.load(f)
+    rows = {}
+    for name, t in fams.items():
+        s = t["us_per_call"] * 1e-6
+        launches = t["launches_per_call"]
+        rows[name] = {
+            "kernel": t["kernel"], "bound": "mfma", "achieved": alg / s / 1e12, "achieved_executed": exe / s / 1e12,
+            "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": alg / s / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+            "frac_executed": exe / s / 1e12 / FP32_MFMA_PEAK_TFLOPS, "avg_launch_us": t["us_per_call"] / launches,
+            "launches_per_step": launches * t["calls_per_step"], "sum_us_per_step": t["us_per_call"] * t["calls_per_step"],
+            "flops_algorithmic": alg / launches, "flops_executed": exe / launches,
+            "traffic": traffic.get("kernels", {}).get(name), "traffic_source": traffic.get("source"),
+        }
+    dominant = max(rows, key=lambda k: rows[k]["sum_us_per_step"])
+    main = dict(rows[dominant])
+    main["family"] = dominant
+    main["why"] = "largest summed GPU time per step among the MFMA GEMM families (timed live, HIP events)"
+    return main, rows
+
+
+# ---------------------------------------------------------------------------------------------------------------
 def cpu_baseline(cfg, budget_s=20.0):
-    """The CPU oracle port of the same train step on this box's host cores (kind='port').
+    """The same train step on this box's host cores: the real reference (models/base_model.py Model + torch RMSprop,
+    through oracle/ref_shim.py) when /root/reference is mounted, else the oracle port -- and the reason is stated.
 
-    Thread count: the oracle is many small ops (a 228-step GRU, 228x228 softmax ...); on a many-core host
-    using every core is pathologically slow (OpenMP fork/join per tiny op), so a short calibration picks the
-    fastest of {8, 16, 32, 64} threads (<= cpu_count) and `cores` reports what was actually used."""
-    from oracle.stemgnn_oracle import OracleTrainer
+    Thread count: the step is many small ops (a 228-step GRU, 228x228 softmax ...); on a many-core host using every
+    core is pathologically slow (fork/join per tiny op), so a short calibration picks the fastest of {8, 16, 32, 64}
+    threads (<= cpu_count) and `cores` reports what was actually used."""
+    import torch
+    from oracle import ref_shim
 
     ncpu = os.cpu_count() or 1
     g = torch.Generator().manual_seed(0)
     x = torch.randn(cfg["B"], cfg["W"], cfg["N"], generator=g)
     y = torch.randn(cfg["B"], cfg["H"], cfg["N"], generator=g)
-    tr = OracleTrainer(cfg["N"], cfg["W"], cfg["multi"], cfg["H"], lr=1e-4, seed=0, dropout_rate=0.5)
+    extra = {}
+    if ref_shim.reference_available():
+        ref = ref_shim.load_reference_model_module()
+        torch.manual_seed(0)
+        model = ref.Model(cfg["N"], 2, cfg["W"], cfg["multi"], horizon=cfg["H"])      # dropout 0.5 as the driver leaves it
+        model.train()
+        opt = torch.optim.RMSprop(model.parameters(), lr=1e-4, eps=1e-8)
+        lossf = torch.nn.MSELoss(reduction="mean")
+
+        def one():
+            model.zero_grad()
+            forecast, _ = model(x)
+            loss = lossf(forecast, y)
+            loss.backward()
+            opt.step()
+        kind, what = "reference", "the reference's Model + torch.optim.RMSprop (models/handler.py:157-165 loop body)"
+    else:
+        from oracle.stemgnn_oracle import OracleTrainer
+        tr = OracleTrainer(cfg["N"], cfg["W"], cfg["multi"], cfg["H"], lr=1e-4, seed=0, dropout_rate=0.5)
+
+        def one():
+            tr.step(x, y)
+        kind, what = "port", "the torch-CPU oracle port"
+        extra["why"] = (f"{ref_shim.REFERENCE_ROOT} is not mounted on this box (it exists only in the build container), "
+                        "so the CPU restatement of the same step is timed instead")
     best_t, best_n = None, None
     for nt in sorted({min(ncpu, c) for c in (8, 16, 32, 64)}):
         torch.set_num_threads(nt)
-        tr.step(x, y)                                   # warm-up at this thread count
+        one()                                            # warm-up at this thread count
         t0 = time.perf_counter()
-        tr.step(x, y)
+        one()
         dt = time.perf_counter() - t0
         if best_t is None or dt < best_t:
             best_t, best_n = dt, nt
         if dt > 5.0:
             break
     torch.set_num_threads(best_n)
-    tr.step(x, y)
+    one()
     n, t0 = 0, time.perf_counter()
     while True:
-        tr.step(x, y)
+        one()
         n += 1
         el = time.perf_counter() - t0
         if el > budget_s or n >= 100:
             break
     sps = n / el
-    return {"value": cfg["B"] * cfg["H"] * sps, "unit": "forecast-steps/s", "cores": best_n, "kind": "port",
-            "ms_per_step": 1e3 / sps, "host_cpus": ncpu,
-            "sample": f"{n} train steps of the torch-CPU oracle port (same shape, batch {cfg['B']}, fp32, "
-                      f"RMSprop, dropout 0.5), {best_n} threads (fastest of a 8/16/32/64 calibration) on a "
-                      f"{ncpu}-cpu host"}
+    out = {"value": cfg["B"] * cfg["H"] * sps, "unit": "forecast-steps/s", "cores": best_n, "kind": kind,
+           "ms_per_step": 1e3 / sps, "host_cpus": ncpu,
+           "sample": f"{n} train steps of {what} (same shape, batch {cfg['B']}, fp32, RMSprop, dropout 0.5), "
+                     f"{best_n} threads (fastest of a 8/16/32/64 calibration) on a {ncpu}-cpu host"}
+    out.update(extra)
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------
+def run_training(cfg, steps, warmup, dev, world, rank, graph=True, T=12672):
+    """Build model + resident series, run warmup + `steps` timed train steps; returns (elapsed_s, mode, final_loss)."""
+    import torch
+    import torch.distributed as dist
+    from stemgnn_amd import Model, ops
+    from stemgnn_amd.distributed import broadcast_parameters
+    from stemgnn_amd.engine import TrainStep
+    from stemgnn_amd.optim import FusedRMSprop
+
+    torch.manual_seed(0)
+    model = Model(cfg["N"], 2, cfg["W"], cfg["multi"], horizon=cfg["H"])      # defaults: dropout 0.5, leaky 0.2
+    model.to(dev).train()
+    broadcast_parameters(model)
+    # same arithmetic as the driver's torch.optim.RMSprop (handler.py:127), one fused kernel (+ grad zeroing)
+    opt = FusedRMSprop(model.parameters(), lr=1e-4, alpha=0.99, eps=1e-8)
+    # synthetic z-scored series resident in HBM (PEMS07 length), windows gathered by index inside the step
+    g = torch.Generator().manual_seed(1234 + rank)
+    series = torch.randn(T, cfg["N"], generator=g).to(dev)
+    n_windows = T - cfg["W"] - cfg["H"] + 1
+    total = steps + warmup + 1
+    epochs = -(-total * cfg["B"] // n_windows)                       # shuffled passes over the windows, back to back
+    order = torch.cat([torch.randperm(n_windows, generator=g) for _ in range(epochs)])[: total * cfg["B"]]
+    hi_all = (order + cfg["W"]).to(dev).view(total, cfg["B"])        # window-end rows (ForecastDataset.x_end_idx)
+
+    stepper = TrainStep(model, opt, cfg["B"], cfg["W"], cfg["H"], cfg["N"], series=series, world=world, graph=graph)
+    stepper.run_indices(hi_all[0])          # eager step (lazy init of tables, seed, state) + graph capture
+    torch.cuda.synchronize()
+    it = iter(range(1, total))
+    for _ in range(warmup):
+        stepper.run_indices(hi_all[next(it)])
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        stepper.run_indices(hi_all[next(it)])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ops.check_gru_status(dev)               # outside the timed region: a lost GRU cluster partner must fail the run
+    ops.check_gather_status(dev)
+    final_loss = float(stepper.loss.item())
+    if not (final_loss == final_loss) or final_loss > 1e6:
+        raise SystemExit(f"training diverged: loss={final_loss}")
+    return elapsed, stepper.mode, final_loss
+
+
+def workload_name(cfg):
+    return (("PEMS07-shape " if cfg == WORKLOAD else "") +
+            f"N={cfg['N']} W={cfg['W']} H={cfg['H']} multi={cfg['multi']} stack=2, batch {cfg['B']} per GPU, "
+            "train step (window gather+fwd+MSE+bwd+RMSprop), dropout 0.5")
 
 
 def main():
@@ -117,105 +280,60 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        _self_launch(args)
+    import torch
+    import torch.distributed as dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    from stemgnn_amd import Model
-    from stemgnn_amd.distributed import broadcast_parameters
-    from stemgnn_amd.engine import TrainStep
-    from stemgnn_amd.optim import FusedRMSprop
-
     cfg = dict(WORKLOAD)
-    if os.environ.get("STEMGNN_BENCH_WORKLOAD"):     # "N,W,H,multi,B": other BASELINE configs (reported in DESIGN.md only;
-        vals = [int(v) for v in os.environ["STEMGNN_BENCH_WORKLOAD"].split(",")]   # the default line stays configs[1])
+    if os.environ.get("STEMGNN_BENCH_WORKLOAD"):     # "N,W,H,multi,B": another shape as the main line (experiments only)
+        vals = [int(v) for v in os.environ["STEMGNN_BENCH_WORKLOAD"].split(",")]
         cfg = dict(zip(("N", "W", "H", "multi", "B"), vals))
-    torch.manual_seed(0)
-    model = Model(cfg["N"], 2, cfg["W"], cfg["multi"], horizon=cfg["H"])      # defaults: dropout 0.5, leaky 0.2
-    model.to(dev).train()
-    broadcast_parameters(model)
-    # same arithmetic as the driver's torch.optim.RMSprop (handler.py:127), one fused kernel (+ grad zeroing)
-    opt = FusedRMSprop(model.parameters(), lr=1e-4, alpha=0.99, eps=1e-8)
-    # synthetic z-scored series resident in HBM (PEMS07 length), windows gathered by index inside the step
-    T = 12672
-    g = torch.Generator().manual_seed(1234 + rank)
-    series = torch.randn(T, cfg["N"], generator=g).to(dev)
-    n_windows = T - cfg["W"] - cfg["H"] + 1
-    total = args.steps + args.warmup + 1
-    epochs = -(-total * cfg["B"] // n_windows)                       # shuffled passes over the windows, back to back
-    order = torch.cat([torch.randperm(n_windows, generator=g) for _ in range(epochs)])[: total * cfg["B"]]
-    hi_all = (order + cfg["W"]).to(dev).view(total, cfg["B"])        # window-end rows (ForecastDataset.x_end_idx)
-
-    # TrainStep = the driver's loop body (stemgnn_amd/handler.py train): window gather -> zero_grad -> forward ->
-    # MSE -> backward (gradients written in place into the flat bucket, block weight-gradient GEMMs overlapping the
-    # GRU recurrence on a side stream) -> [RCCL all-reduce] -> RMSprop; captured into hipGraph(s) after the first step
-    stepper = TrainStep(model, opt, cfg["B"], cfg["W"], cfg["H"], cfg["N"], series=series, world=world,
-                        graph=not args.no_graph)
-    stepper.run_indices(hi_all[0])          # eager step (lazy init of tables, seed, state) + graph capture
-    torch.cuda.synchronize()
-    mode = stepper.mode
-    it = iter(range(1, total))
-
-    def step():
-        stepper.run_indices(hi_all[next(it)])
-
-    loss_buf = stepper.loss
-    for _ in range(args.warmup):
-        step()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    final_loss = float(loss_buf.item())
-    if not (final_loss == final_loss) or final_loss > 1e6:
-        raise SystemExit(f"training diverged: loss={final_loss}")
-
-    ms_per_step = elapsed / args.steps * 1e3
-    value = world * cfg["B"] * cfg["H"] / (elapsed / args.steps)
+    elapsed, mode, final_loss = run_training(cfg, args.steps, args.warmup, dev, world, rank, graph=not args.no_graph)
     out = {
-        "metric": "forecast-steps/sec (train)", "value": value, "unit": "forecast-steps/s", "n_gpus": world,
-        "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": ("PEMS07-shape " if cfg == WORKLOAD else "") +
-                               f"N={cfg['N']} W={cfg['W']} H={cfg['H']} multi={cfg['multi']} stack=2, batch {cfg['B']} per GPU, "
-                               "train step (window gather+fwd+MSE+bwd+RMSprop), dropout 0.5", "global_batch": world * cfg["B"],
-                   "per_gpu_batch": cfg["B"], "parallelism": f"dp{world}", "launch": mode},
+        "metric": "forecast-steps/sec (train)", "value": world * cfg["B"] * cfg["H"] / (elapsed / args.steps),
+        "unit": "forecast-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": workload_name(cfg), "global_batch": world * cfg["B"], "per_gpu_batch": cfg["B"],
+                   "parallelism": f"dp{world}", "launch": mode},
         "final_loss": final_loss,
     }
     if rank == 0:
-        avg_s, flops = time_dominant_kernel(cfg)
-        ach = flops / avg_s / 1e12
-        out["roofline"] = {"kernel": "sg_gemm2<GluFwdEpi,true,false,true,64> (spectral GLU forward GEMM, 64x128x16 tiles, "
-                                     "v_mfma_f32_32x32x2_f32, exact fp32)",
-                           "bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                           "frac": ach / FP32_MFMA_PEAK_TFLOPS, "avg_launch_us": avg_s * 1e6,
-                           "flops_per_launch": flops,
-                           # HBM bytes per launch from the PMC passes in profiles/r01_v7_pmc_fetch_write.md
-                           # (2 x FETCH_SIZE + WRITE_SIZE, gfx950 correction), not re-measured live
-                           "traffic": ROOFLINE_TRAFFIC_BYTES}
+        out["roofline"], out["roofline_families"] = roofline_objects(cfg)
+        if world == 1 and not args.no_other_configs:
+            others = []
+            for name, c in OTHER_CONFIGS:
+                try:
+                    torch.cuda.empty_cache()
+                    big = c["N"] >= 1024
+                    k, w = (5, 2) if big else (30, 5)
+                    el, md, _ = run_training(c, k, w, dev, 1, 0, graph=not args.no_graph, T=4096 if big else 12672)
+                    others.append({"config": name, "workload": workload_name(c), "ms_per_step": el / k * 1e3,
+                                   "value": c["B"] * c["H"] / (el / k), "unit": "forecast-steps/s", "steps": k,
+                                   "warmup": w, "n_gpus": 1, "launch": md})
+                except Exception as e:  # noqa: BLE001 -- a failing side line must not lose the headline
+                    others.append({"config": name, "error": f"{type(e).__name__}: {e}"})
+            out["other_configs"] = others
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg)
         print(json.dumps(out), flush=True)
     if world > 1:
+        dist.barrier()                      # rank 0 may still be timing the roofline kernels
         dist.destroy_process_group()
 
 

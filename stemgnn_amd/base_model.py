@@ -12,6 +12,7 @@ The ``nn.GRU`` module (models/base_model.py:92,137) is kept as the parameter con
 runs in the persistent HIP kernels of ``csrc/gru.hip`` (``STEMGNN_GRU=miopen`` selects the library GRU for
 A/B runs).  The 2-layer ``fc`` tail (:175-179) runs in the fused kernel of ``csrc/tail.hip``.
 """
+import itertools
 import os
 
 import torch
@@ -21,6 +22,7 @@ import torch.nn.functional as F
 from . import _lib, ops
 from .ops import FcTail, GruFront, SpectralHotPath, StockBlockFn
 
+_instance_counter = itertools.count()
 _BLOCK_FIELDS = ("forecast", "forecast_result", "backcast", "backcast_short_cut")
 
 
@@ -97,13 +99,24 @@ class Model(nn.Module):
             StockBlockLayer(time_step, units, multi_layer, stack_cnt=i) for i in range(stack_cnt))
         self.fc = nn.Sequential(nn.Linear(time_step, time_step), nn.LeakyReLU(), nn.Linear(time_step, horizon))
         self._seed = None          # device uint64[2] {seed, offset} of the dropout Philox stream (not a parameter)
+        self._instance = next(_instance_counter)
+        self.hot_state = ops.HotPathState()     # per-model scheduling mode (direct gradients / side-stream overlap)
         self.to(device)
 
     # -- dropout stream ------------------------------------------------------------------------------
     def _next_seed(self, device):
         if self._seed is None or self._seed.device != device:
-            s = torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item()   # drawn from torch's CPU generator
-            self._seed = torch.tensor([s, 0], dtype=torch.int64, device=device)
+            # Philox key of this model's dropout stream.  Like nn.Dropout on a GPU it follows the DEVICE generator's
+            # seed (torch.manual_seed sets it) and never consumes torch's CPU generator -- the DataLoader-compatible
+            # shuffle order (forecast_dataloader.epoch_order) draws from that one.  The construction index of the model
+            # and the data-parallel rank are folded in, so two models / two replicas never share a mask stream.
+            rank = 0
+            if torch.distributed.is_available() and torch.distributed.is_initialized():
+                rank = torch.distributed.get_rank()
+            key = (torch.cuda.default_generators[device.index if device.index is not None
+                                                 else torch.cuda.current_device()].initial_seed()
+                   + 0x9E3779B97F4A7C15 * (self._instance + 1) + 0xD1B54A32D192ED03 * rank) % (1 << 62)
+            self._seed = torch.tensor([key, 0], dtype=torch.int64, device=device)
         used = self._seed.clone()
         self._seed[1] += 1          # device-side increment: graph-capturable, no host sync
         return used
@@ -112,10 +125,16 @@ class Model(nn.Module):
         device = device or self.weight_key.device
         self._seed = torch.tensor([int(seed), int(offset)], dtype=torch.int64, device=device)
 
-    def __getstate__(self):        # keep whole-module pickling (handler.py:24) working
+    def __getstate__(self):        # keep whole-module pickling (handler.py:24) working: no streams / device scalars inside
         state = self.__dict__.copy()
         state["_seed"] = None
+        state["hot_state"] = None
         return state
+
+    def __setstate__(self, state):
+        self.__dict__.update(state)
+        self._instance = next(_instance_counter)
+        self.hot_state = ops.HotPathState()
 
     # -- forward --------------------------------------------------------------------------------------
     def hot_path(self, x):
@@ -127,8 +146,9 @@ class Model(nn.Module):
         blocks = (self.stock_block[0].hip_params(), self.stock_block[1].hip_params())
         use_drop = self.training and self.dropout_rate > 0.0
         seed = None
-        if ops._OVERLAP_WGRAD:        # side-stream mode: weight packing and the dropout-stream bookkeeping (a clone and
-            ops.prepack_blocks(blocks, self.time_step, self.multi_layer, x.device)   # an increment) overlap the GRU
+        hs = self.hot_state
+        if hs.overlap:                # side-stream mode: weight packing and the dropout-stream bookkeeping (a clone and
+            ops.prepack_blocks(hs, blocks, self.time_step, self.multi_layer, x.device)   # an increment) overlap the GRU
             if use_drop and os.environ.get("STEMGNN_SEED_SIDE", "1") == "1":
                 with torch.cuda.stream(ops._side_stream(x.device)):
                     seed = self._next_seed(x.device)
@@ -138,19 +158,20 @@ class Model(nn.Module):
             h, _ = self.GRU(x.permute(2, 0, 1).contiguous())      # [N_seq, B, N_hid]  (:137)
         else:                                                      # persistent HIP recurrence (csrc/gru.hip)
             g = self.GRU
-            h = GruFront.apply(x, g.weight_ih_l0, g.weight_hh_l0, g.bias_ih_l0, g.bias_hh_l0)
+            h = GruFront.apply(x, g.weight_ih_l0, g.weight_hh_l0, g.bias_ih_l0, g.bias_hh_l0, hs)
         if use_drop and seed is None:
             seed = self._next_seed(x.device)
         params = blocks[0] + blocks[1]
         return SpectralHotPath.apply(h, x, self.weight_key, self.weight_query, self.multi_layer, self.alpha,
-                                     self.dropout_rate, self.training, seed, *params)
+                                     self.dropout_rate, self.training, seed, hs, *params)
 
     def forward(self, x):
         fsum, attention, _ = self.hot_path(x)
         if _lib.load().stemgnn_fc_tail_supported(self.time_step, self.horizon):
             # fused fc tail (csrc/tail.hip): Linear - LeakyReLU - Linear and the permute to [B,H,N] in one kernel;
             # for H == 1 the reference's unsqueeze/squeeze (:176-177) yields the same [B,1,N] tensor
-            return FcTail.apply(fsum, self.fc[0].weight, self.fc[0].bias, self.fc[2].weight, self.fc[2].bias), attention
+            return FcTail.apply(fsum, self.fc[0].weight, self.fc[0].bias, self.fc[2].weight, self.fc[2].bias,
+                                self.hot_state), attention
         forecast = self.fc(fsum)                                   # [B,N,H]  (:175)
         if forecast.size(-1) == 1:                                 # (:176-177)
             return forecast.unsqueeze(1).squeeze(-1), attention

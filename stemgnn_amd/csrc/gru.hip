@@ -665,12 +665,26 @@ extern "C" size_t stemgnn_gru_reserve_floats(int B, int S, int Hd) { return (siz
 // cluster size: smallest P in {1,2,4,8} whose per-lane weight slice fits the register budget; 0 = use the
 // single-workgroup streaming kernels (very wide hidden states, or STEMGNN_GRU_CLUSTER=0)
 #define GRU_KC 48       // resident weights per lane (registers); the per-step loops are fully unrolled over it
+// Workgroups of a cluster kernel poll each other, so ALL of them must be resident at once: one per CU.  The bound is the
+// current device's CU count (queried once per device, never assumed) minus 1/8 slack for CUs another stream may hold.
+static int gru_resident_limit() {
+  static int cached_dev = -1, cached = 0;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 0;
+  if (dev != cached_dev) {
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+    cached = cus - cus / 8;
+    cached_dev = dev;
+  }
+  return cached;
+}
 static int gru_pick_P(int B, int Hd) {
   const char* e = getenv("STEMGNN_GRU_CLUSTER");
   if (e && atoi(e) == 0) return 0;                 // 0: streaming kernels, 1: cluster v1, 2 / unset: v2 then v1
   for (int P = 1; P <= 8; P *= 2) {
     const GruCluster c = gru_cluster_geom(Hd, P);
-    if (c.ksf >= 1 && c.ksb >= 1 && c.kcf <= GRU_KC && c.kcb <= GRU_KC && (size_t)B * P <= 224) return P;
+    if (c.ksf >= 1 && c.ksb >= 1 && c.kcf <= GRU_KC && c.kcb <= GRU_KC && B * P <= gru_resident_limit()) return P;
   }
   return 0;
 }
@@ -679,12 +693,12 @@ static int gru_pick_P2(int B, int Hd) {
   const char* e = getenv("STEMGNN_GRU_CLUSTER");
   if (e && atoi(e) != 2) return 0;
   // P workgroups per batch row: the slice U = ceil(Hd/P) must fit the 64 lanes, all B*P workgroups must be
-  // co-resident (one per CU, 224 leaves slack on 256 CUs).  P <= 5 runs one owner slice per wave (3P waves); P = 6, 8
+  // co-resident (one per CU: gru_resident_limit(), 224 on a 256-CU MI355X).  P <= 5 runs one owner slice per wave (3P waves); P = 6, 8
   // run two per wave (3P/2 waves) to stay inside 1024 threads.
   static const int cand[6] = {1, 2, 4, 5, 6, 8};
   for (int i = 0; i < 6; ++i) {
     const int P = cand[i];
-    if ((Hd + P - 1) / P <= 64 && (size_t)B * P <= 224) return P;
+    if ((Hd + P - 1) / P <= 64 && B * P <= gru_resident_limit()) return P;
   }
   return 0;
 }

@@ -16,8 +16,10 @@ from . import ops
 from .distributed import FlatGradBucket
 
 
-def capture(fn, warmups=3):
-    """Capture fn into a hipGraph (torch.cuda.CUDAGraph); returns the replay callable, or None if capture fails."""
+def capture(fn, warmups=3, on_fail=None):
+    """Capture fn into a hipGraph (torch.cuda.CUDAGraph); returns the replay callable, or None if capture fails.
+    `on_fail()` is called after a failed attempt (before returning None) so the caller can drop host-side state a
+    partially executed / partially captured step left behind (queued side-stream work, pre-packed panels)."""
     try:
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
@@ -36,6 +38,9 @@ def capture(fn, warmups=3):
     except Exception as e:  # noqa: BLE001
         print(f"[stemgnn_amd] graph capture unavailable ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
         torch.cuda.synchronize()
+        if on_fail is not None:
+            on_fail()
+        torch.cuda.synchronize()
         return None
 
 
@@ -48,7 +53,7 @@ class TrainStep:
         self.device = dev
         self.fused = hasattr(optimizer, "bucket")                       # FusedRMSprop: flat params + flat grads
         self.bucket = optimizer.bucket if self.fused else (FlatGradBucket(model.parameters()) if world > 1 else None)
-        ops.set_direct_grad(self.fused, overlap=self.fused)
+        self.state = ops.set_direct_grad(model, self.fused, overlap=self.fused)   # scoped to THIS model
         self.fuse_zero = self.fused and getattr(optimizer, "fuse_zero_grad", False)
         self.series = series                                            # [T,N] fp32 resident, or None: x/y given
         self.hi = torch.zeros(self.B, dtype=torch.int64, device=dev)    # static window-end indices
@@ -96,7 +101,7 @@ class TrainStep:
             def whole():
                 self._finish(self._fwd_bwd(self.hi, self.x, self.y))
             snap = self._snapshot()
-            rep = capture(whole)
+            rep = capture(whole, on_fail=self.state.reset)
             self._restore(snap)
             if rep is not None:
                 self._replay, self.mode = rep, "hipgraph(whole step)"
@@ -109,8 +114,8 @@ class TrainStep:
             def part_b():
                 self.opt.step()
             snap = self._snapshot()
-            ra = capture(part_a)
-            rb = capture(part_b) if ra is not None else None
+            ra = capture(part_a, on_fail=self.state.reset)
+            rb = capture(part_b, on_fail=self.state.reset) if ra is not None else None
             self._restore(snap)
             if ra is not None and rb is not None:
                 def rep():

@@ -7,16 +7,14 @@ Stage order (reference models/base_model.py): attention+Laplacian (:139-147) -> 
 -> per StockBlock: pack, GFT (:62-64), spectral GLU (:46-54), IGFT+heads (:55-58, :65-74).
 """
 import os
+import weakref
 
 import torch
 
 from . import _lib
 
 _NSPLIT = int(os.environ.get("STEMGNN_NSPLIT", "32"))     # split-M factor of the weight-gradient GEMMs
-_DIRECT_GRAD = False
-_OVERLAP_WGRAD = False
 _side_streams = {}
-_pending_join = {}
 
 
 def _side_stream(device):
@@ -28,31 +26,75 @@ def _side_stream(device):
     return st
 
 
-def join_side_streams(device=None):
-    """Make the current stream wait for weight-gradient work queued on the side stream (see
-    SpectralHotPath.backward).  Called by every consumer of the gradients; cheap no-op when nothing is pending."""
-    keys = [str(device)] if device is not None else list(_pending_join.keys())
-    for k in keys:
-        item = _pending_join.pop(k, None)
+class HotPathState:
+    """Per-model scheduling state of the hot path (one instance per ``stemgnn_amd.Model``; nothing process-global).
+
+    direct : backward WRITES the hot-path / GRU / fc parameter gradients straight into existing ``p.grad`` buffers
+             (e.g. the views of a FlatGradBucket) instead of returning them to autograd, which would launch one
+             accumulate kernel per parameter (~70 tiny launches per step).  Semantics: overwrite, i.e. equivalent to
+             ``zero_grad(); backward()`` -- not for accumulating gradients over several backward passes.
+    overlap: additionally queue the spectral blocks' weight-gradient GEMMs (and the weight packing / dropout-stream
+             bookkeeping of the forward) on a side HIP stream so they overlap the rest of the step (notably the
+             latency-bound GRU recurrence).  Gradients are then complete only after ``join_side_streams()``;
+             FusedRMSprop.step, FlatGradBucket.all_reduce_mean and GruFront.backward call it -- any other reader of
+             ``.grad`` must call it first.
+    """
+
+    def __init__(self):
+        self.direct = False
+        self.overlap = False
+        self.prepacked = None        # (packed panels, side stream, blocks) queued by prepack_blocks
+        self.pending = None          # (side stream, keep-alive objects) of weight-gradient work not yet joined
+        _states.add(self)
+
+    def set(self, direct=True, overlap=False):
+        self.direct = bool(direct)
+        self.overlap = bool(direct) and bool(overlap) and os.environ.get("STEMGNN_OVERLAP_WGRAD", "1") == "1"
+        return self
+
+    def join(self):
+        item, self.pending = self.pending, None
         if item is not None:
-            side, keep, extra = item
+            side, keep = item
             torch.cuda.current_stream().wait_stream(side)
-            del keep, extra
+            del keep
+
+    def reset(self):
+        """Drop queued side-stream work after a failed capture / aborted step (engine.capture)."""
+        for item in (self.prepacked, self.pending):
+            if item is not None:
+                (item[1] if item is self.prepacked else item[0]).synchronize()
+        self.prepacked = None
+        self.pending = None
 
 
-def set_direct_grad(flag=True, overlap=False):
-    """Opt-in: backward WRITES the hot-path / GRU parameter gradients straight into existing ``p.grad`` buffers
-    (e.g. the views of a FlatGradBucket) instead of returning them to autograd, which would launch one
-    accumulate kernel per parameter (~70 tiny launches per step).  Semantics: overwrite, i.e. equivalent to
-    ``zero_grad(); backward()`` -- do not use when accumulating gradients over several backward passes.
+_states = weakref.WeakSet()
+_NO_STATE = None
 
-    ``overlap=True`` additionally queues the spectral blocks' weight-gradient GEMMs on a side HIP stream so they
-    overlap the rest of the backward pass (notably the latency-bound GRU recurrence).  The gradients are then
-    complete only after ``join_side_streams()``; FusedRMSprop.step, FlatGradBucket.all_reduce_mean and
-    GruFront.backward call it -- any other reader of ``.grad`` must call it first."""
-    global _DIRECT_GRAD, _OVERLAP_WGRAD
-    _DIRECT_GRAD = bool(flag)
-    _OVERLAP_WGRAD = bool(flag) and bool(overlap) and os.environ.get("STEMGNN_OVERLAP_WGRAD", "1") == "1"
+
+def _state(state):
+    """Functions called without a model (stand-alone use, tests): a shared inert state (no direct writes, no overlap)."""
+    global _NO_STATE
+    if state is not None:
+        return state
+    if _NO_STATE is None:
+        _NO_STATE = HotPathState()
+    return _NO_STATE
+
+
+def join_side_streams(device=None):
+    """Make the current stream wait for weight-gradient work any model queued on a side stream (see
+    SpectralHotPath.backward).  Called by every consumer of the gradients; cheap no-op when nothing is pending."""
+    for st in list(_states):
+        if st.pending is not None and (device is None or str(st.pending[0].device) == str(torch.device(device))):
+            st.join()
+
+
+def set_direct_grad(model, flag=True, overlap=False):
+    """Switch ``model`` (a stemgnn_amd.Model) to direct-gradient mode, see HotPathState."""
+    return model.hot_state.set(flag, overlap)
+
+
 _NCHUNK = int(os.environ.get("STEMGNN_ATTN_CHUNKS", "16"))  # row chunks of the attention backward
 
 
@@ -119,8 +161,9 @@ class GruFront(torch.autograd.Function):
     recurrence kernels.  (x [B,W,N], weight_ih_l0, weight_hh_l0, bias_ih_l0, bias_hh_l0) -> h [N,B,N]."""
 
     @staticmethod
-    def forward(ctx, x, w_ih, w_hh, b_ih, b_hh):
+    def forward(ctx, x, w_ih, w_hh, b_ih, b_hh, state=None):
         lib = _lib.load()
+        ctx.state = _state(state)
         gru_params = (w_ih, w_hh, b_ih, b_hh)
         for name, t in (("x", x), ("GRU.weight_ih_l0", w_ih), ("GRU.weight_hh_l0", w_hh)):
             _require_gpu(t, name)
@@ -152,7 +195,7 @@ class GruFront(torch.autograd.Function):
         dh_all = dh_all.contiguous()
         scratch = torch.empty(lib.stemgnn_gru_bwd_scratch_floats(B, S, Hd, W), device=dev, dtype=f32)
         prm = ctx.gru_params
-        direct = _DIRECT_GRAD and all(p.grad is not None and p.grad.is_contiguous() for p in prm)
+        direct = ctx.state.direct and all(p.grad is not None and p.grad.is_contiguous() for p in prm)
         if direct:
             dw_ih, dw_hh, db_ih, db_hh = (p.grad for p in prm)
         else:
@@ -163,18 +206,19 @@ class GruFront(torch.autograd.Function):
                                        reserve.data_ptr(), B, S, Hd, W, scratch.data_ptr(), dw_ih.data_ptr(),
                                        dw_hh.data_ptr(), db_ih.data_ptr(), db_hh.data_ptr(),
                                        gru_status(dev).data_ptr(), _stream()), "gru_bwd")
-        join_side_streams(dev)          # the spectral blocks' weight gradients (side stream) overlapped this recurrence
+        ctx.state.join()                # the spectral blocks' weight gradients (side stream) overlapped this recurrence
         if direct:
-            return None, None, None, None, None
-        return None, dw_ih, dw_hh, db_ih, db_hh
+            return None, None, None, None, None, None
+        return None, dw_ih, dw_hh, db_ih, db_hh, None
 
 
 class FcTail(torch.autograd.Function):
     """fc tail of Model.forward (reference models/base_model.py:175-179): fsum [B,N,W] -> forecast [B,H,N]."""
 
     @staticmethod
-    def forward(ctx, fsum, w0, b0, w2, b2):
+    def forward(ctx, fsum, w0, b0, w2, b2, state=None):
         lib = _lib.load()
+        ctx.state = _state(state)
         fsum = fsum.contiguous()
         B, N, W = fsum.shape
         H = w2.shape[0]
@@ -195,7 +239,7 @@ class FcTail(torch.autograd.Function):
         dev, f32 = fsum.device, torch.float32
         dforecast = dforecast.contiguous()
         prm = ctx.fc_params
-        direct = _DIRECT_GRAD and all(p.grad is not None and p.grad.is_contiguous() for p in prm)
+        direct = ctx.state.direct and all(p.grad is not None and p.grad.is_contiguous() for p in prm)
         if direct:
             dw0, db0, dw2, db2 = (p.grad for p in prm)
         else:
@@ -207,8 +251,8 @@ class FcTail(torch.autograd.Function):
                                            dw0.data_ptr(), db0.data_ptr(), dw2.data_ptr(), db2.data_ptr(), _stream()),
                    "fc_tail_bwd")
         if direct:
-            return dfsum, None, None, None, None
-        return dfsum, dw0, db0, dw2, db2
+            return dfsum, None, None, None, None, None
+        return dfsum, dw0, db0, dw2, db2, None
 
 
 class StockBlockFn(torch.autograd.Function):
@@ -293,7 +337,6 @@ class StockBlockFn(torch.autograd.Function):
         return (dX, dmul_L, None, None, *grads)
 
 
-_prepacked = {}
 _keep_attention_state = False
 _last_attention_state = {}
 
@@ -311,7 +354,7 @@ def last_attention_state(device):
     return _last_attention_state.get(str(torch.device(device)))
 
 
-def prepack_blocks(block_params, W, multi, device):
+def prepack_blocks(state, block_params, W, multi, device):
     """Pack both blocks' weights (stemgnn_block_pack) on the side stream now, so that they overlap whatever the
     caller queues next on the current stream (Model.hot_path: the GRU recurrence).  The next SpectralHotPath.forward
     on this device picks the packed panels up and joins the side stream."""
@@ -325,7 +368,7 @@ def prepack_blocks(block_params, W, multi, device):
     for blk, pk in zip(blocks, packed):
         _lib.check(lib.stemgnn_block_pack(_lib.ptr_array(blk), tables.data_ptr(), pk.data_ptr(), W, multi,
                                           side.cuda_stream), "block_pack")
-    _prepacked[str(device)] = (packed, side, blocks)
+    state.prepacked = (packed, side, blocks)
 
 
 class SpectralHotPath(torch.autograd.Function):
@@ -336,8 +379,9 @@ class SpectralHotPath(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, h, x, wk, wq, multi, alpha, drop_p, training, seed, *block_params):
+    def forward(ctx, h, x, wk, wq, multi, alpha, drop_p, training, seed, state, *block_params):
         lib = _lib.load()
+        state = ctx.state = _state(state)
         for name, t in (("gru output", h), ("x", x), ("weight_key", wk), ("weight_query", wq)):
             _require_gpu(t, name)
         assert len(block_params) == 2 * _lib.SG_BLOCK_NPARAMS
@@ -357,6 +401,11 @@ class SpectralHotPath(torch.autograd.Function):
         attention = torch.empty(N, N, device=dev, dtype=f32)
         attn_saved = torch.empty(lib.stemgnn_attn_saved_floats(B, N), device=dev, dtype=f32)
         use_drop = bool(training) and drop_p > 0.0
+        # join the side stream BEFORE the first kernel that reads `seed`: in overlap mode the dropout stream's clone /
+        # increment (Model._next_seed) and the weight packing were queued there (ordering edge clone -> attention)
+        pre, state.prepacked = state.prepacked, None
+        if pre is not None:
+            torch.cuda.current_stream().wait_stream(pre[1])
         _lib.check(lib.stemgnn_attn_laplacian_fwd(
             h.data_ptr(), wk.data_ptr(), wq.data_ptr(), float(alpha), float(drop_p), int(bool(training)),
             seed.data_ptr() if use_drop else None, B, N, attn_saved.data_ptr(), attention.data_ptr(),
@@ -378,9 +427,6 @@ class SpectralHotPath(torch.autograd.Function):
         fsum = torch.empty(B, N, W, device=dev, dtype=f32)
         backcast = torch.empty(B, N, W, device=dev, dtype=f32)
         packed, saved = [], []
-        pre = _prepacked.pop(str(dev), None)
-        if pre is not None:
-            torch.cuda.current_stream().wait_stream(pre[1])      # join the side-stream packing
         n_packed = lib.stemgnn_packed_floats(W, multi)
         n_saved = lib.stemgnn_saved_floats(B, N, W, multi)
         xviews = [(x, W * N, 1, N), (backcast, N * W, W, 1)]   # X[b,n,t] strides of block 0 / block 1
@@ -416,6 +462,7 @@ class SpectralHotPath(torch.autograd.Function):
         B, N, W, multi, alpha, drop_p, training = ctx.dims
         h, x, wk, wq, seed, tables, mul_L, attn_saved, backcast, packed, saved = ctx.aux
         blocks = ctx.blocks
+        state = ctx.state
         dev, f32 = x.device, torch.float32
         st = _stream()
         dfsum = dfsum.contiguous()
@@ -432,7 +479,7 @@ class SpectralHotPath(torch.autograd.Function):
             for i, p in enumerate(blocks[s]):
                 if p is None or (s == 1 and i in (7, 8)):   # block 1's short-cut is unused (:73-74) -> grad None
                     continue
-                if _DIRECT_GRAD and p.grad is not None and p.grad.is_contiguous():
+                if state.direct and p.grad is not None and p.grad.is_contiguous():
                     grads[s][i] = p.grad          # written in place by the unpack kernel
                     direct_idx.add((s, i))
                 else:
@@ -442,7 +489,7 @@ class SpectralHotPath(torch.autograd.Function):
         # chain -- in particular the latency-bound GRU recurrence, which leaves half of the CUs idle; whoever
         # consumes the gradients (optimizer / all-reduce, or GruFront.backward at the latest) joins the stream.
         n_block_grads = sum(g is not None for blk in grads for g in blk)
-        overlap = _OVERLAP_WGRAD and len(direct_idx) == n_block_grads
+        overlap = state.overlap and len(direct_idx) == n_block_grads
         side = _side_stream(dev) if overlap else None
         main = torch.cuda.current_stream()
         keep = []
@@ -511,13 +558,13 @@ class SpectralHotPath(torch.autograd.Function):
                 mul_L.data_ptr(), X.data_ptr(), sb, sn, stt, dG.data_ptr(),
                 dbackcast.data_ptr() if s == 1 else None, dmul_L.data_ptr(), int(s == 0), B, N, W, st), "gft_bwd")
         if overlap:
-            _pending_join[str(dev)] = (side, keep, (packed, saved, backcast, dfsum, dbackcast))
+            state.pending = (side, (keep, packed, saved, backcast, dfsum, dbackcast))
         dL = torch.empty(N, N, device=dev, dtype=f32)
         cheb_scratch = torch.empty(2 * N * N, device=dev, dtype=f32)
         _lib.check(lib.stemgnn_cheb_bwd(mul_L.data_ptr(), dmul_L.data_ptr(), dL.data_ptr(), cheb_scratch.data_ptr(),
                                         N, st), "cheb_bwd")
         dh = torch.empty_like(h)
-        kq_direct = _DIRECT_GRAD and wk.grad is not None and wq.grad is not None
+        kq_direct = state.direct and wk.grad is not None and wq.grad is not None
         dwk = wk.grad if kq_direct else torch.empty_like(wk)
         dwq = wq.grad if kq_direct else torch.empty_like(wq)
         attn_scratch = torch.empty(lib.stemgnn_attn_scratch_floats(B, N, _NCHUNK), device=dev, dtype=f32)
@@ -530,7 +577,7 @@ class SpectralHotPath(torch.autograd.Function):
             grads[s_][i_] = None                  # already in p.grad: nothing for autograd to accumulate
         if kq_direct:
             dwk = dwq = None
-        return (dh, None, dwk, dwq, None, None, None, None, None, *grads[0], *grads[1])
+        return (dh, None, dwk, dwq, None, None, None, None, None, None, *grads[0], *grads[1])
 
 
 # ---------------------------------------------------------------------------------------------------------------

@@ -55,6 +55,14 @@ class FusedRMSprop(torch.optim.Optimizer):
         self.sync_lr()
         from .ops import join_side_streams
         join_side_streams(self.flat_p.device)
+        # the step reads the FLAT gradient buffer: every p.grad must still be its view (torch's default
+        # model.zero_grad(set_to_none=True) drops them -> backward would fill fresh tensors and this step would see zeros)
+        for p, view in zip(self.bucket.params, self.bucket.views):
+            if p.grad is None or p.grad.data_ptr() != view.data_ptr():
+                raise _lib.StemGNNHipError(
+                    "FusedRMSprop: a parameter's .grad is no longer the flat-bucket view (model.zero_grad() with "
+                    "set_to_none=True?).  Use optimizer.zero_grad() / model.zero_grad(set_to_none=False), or call "
+                    "optimizer.bucket.attach() before backward.")
         lib = _lib.load()
         _lib.check(lib.stemgnn_rmsprop_step(
             self.flat_p.data_ptr(), self.bucket.flat.data_ptr(), self.square_avg.data_ptr(), self.numel,

@@ -222,7 +222,7 @@ def test_checkpoint_interchange_and_pickle():
 
 @pytest.mark.parametrize("overlap", [False, True])
 def test_direct_grad_mode_matches_autograd_accumulation(overlap):
-    """ops.set_direct_grad(True): backward writes straight into pre-existing .grad buffers (flat bucket views);
+    """ops.set_direct_grad(model, True): backward writes straight into pre-existing .grad buffers (flat bucket views);
     overlap=True also runs the weight-gradient GEMMs on a side stream (joined by the consumers)."""
     from stemgnn_amd import ops
     from stemgnn_amd.distributed import FlatGradBucket
@@ -233,7 +233,7 @@ def test_direct_grad_mode_matches_autograd_accumulation(overlap):
     x, y = torch.randn(B, W, N), torch.randn(B, H, N)
     model = _hip_model(N, W, multi, H, sd, p=0.0, train=True)
     bucket = FlatGradBucket(model.parameters())
-    ops.set_direct_grad(True, overlap=overlap)
+    ops.set_direct_grad(model, True, overlap=overlap)
     try:
         for _ in range(2):                       # second pass must overwrite, not accumulate
             bucket.zero()
@@ -242,7 +242,7 @@ def test_direct_grad_mode_matches_autograd_accumulation(overlap):
             ops.join_side_streams()
         torch.cuda.synchronize()
     finally:
-        ops.set_direct_grad(False)
+        ops.set_direct_grad(model, False)
     _, _, _, o_grads = O.loss_and_grads(x, y, sd)
     for (k, p), view in zip(model.named_parameters(), bucket.views):
         assert p.grad.data_ptr() == view.data_ptr(), k          # still the flat views
@@ -293,18 +293,26 @@ def test_stock_block_layer_standalone(stack_i):
             assert relerr(p.grad, og) < TOL, k
 
 
-# BASELINE.json configs[3] and [4] shapes (large-N eig/GFT stress; long-window W=48) at a reduced batch so the CPU
-# oracle finishes in seconds: exercises the streaming GRU (hidden > 1024), N not fitting one LDS tile, the torch fc
-# fallback (W=48, H=12 exceeds the fused tail's LDS budget) and W*multi = 240.
-@pytest.mark.parametrize("N,W,multi,H,B", [(1024, 12, 5, 3, 3), (2048, 48, 5, 12, 2)])
-def test_large_config_shapes(N, W, multi, H, B):
-    """configs[3] / configs[4] shapes against an fp64 run of the oracle, everything inside the 1e-4 budget.
+# BASELINE.json configs[3] and [4] shapes (large-N eig/GFT stress; long-window W=48): at a reduced batch AND at the
+# per-GPU shard batch of the 8-GPU configurations (64/8 = 8 and 128/8 = 16) -- the batch the MFMA cluster GRU, the fc
+# tail and the W*multi = 240 GEMMs actually run at.
+KINK_GROUPS = ("weight_key", "weight_query", "GRU.")          # the only gradients a LeakyReLU-kink decision can move
 
-    With B*N*N attention logits, a few key_i + query_j land closer to 0 than the fp32 rounding of key/query (2.5e-8 and
-    5e-8 at N = 2048, tools/kink_probe.py), and LeakyReLU's derivative jumps there: flipping those two decisions moves
-    the ~1e-8 gradients of weight_key / weight_query / the GRU by 1e-3 (torch's own fp32 run flips one against fp64).
-    So the fp64 yardstick takes the kink decisions of the implementation under test (its key / query vectors, one fp32
-    add per logit exactly as the kernel does) instead of letting the sign of a 1e-8 number decide."""
+
+@pytest.mark.parametrize("N,W,multi,H,B", [(1024, 12, 5, 3, 3), (2048, 48, 5, 12, 2), (1024, 12, 5, 3, 8),
+                                           (2048, 48, 5, 12, 16)])
+def test_large_config_shapes(N, W, multi, H, B):
+    """configs[3] / configs[4] shapes against an INDEPENDENT fp64 run of the oracle, everything inside the 1e-4 budget.
+
+    With B*N*N attention logits a few key_i + query_j can land closer to 0 than the fp32 rounding of key/query
+    (tools/kink_probe.py); LeakyReLU's derivative jumps there, and flipping such a decision moves the ~1e-8 gradients of
+    weight_key / weight_query / the GRU by ~1e-3 (torch's own fp32 run flips one against fp64) -- a discontinuity of the
+    model, not arithmetic error.  The test therefore
+      1. compares every tensor with the UN-overridden fp64 oracle (no information from the implementation);
+      2. independently audits the kink: the implementation's fp32 decisions differ from the fp64 oracle's on at most a
+         handful of logits, and every one of those lies within 4 fp32 ulp of zero (the count is reported);
+      3. only if such flips exist, re-checks the three gradient groups they can move against an fp64 run that takes the
+         implementation's decisions on exactly those logits."""
     from stemgnn_amd import ops
     sd = O.det_state_dict(N, W, multi, H, seed=N)
     torch.manual_seed(N)
@@ -316,15 +324,39 @@ def test_large_config_shapes(N, W, multi, H, B):
         key, query = (t.cpu() for t in ops.last_attention_state("cuda:0"))
     finally:
         ops.capture_attention_state(False)
-    kink_pos = (key.unsqueeze(2) + query.unsqueeze(1)) > 0                        # [B,N,N], fp32 add as in the kernels
+    ops.check_gru_status("cuda:0")
     sd64 = {k: v.double() for k, v in sd.items()}
-    _, t_forecast, t_att, t_grads = O.loss_and_grads(x.double(), y.double(), sd64, kink_pos=kink_pos)
+    # -- kink audit (fp64 key / query straight from the oracle's GRU; reference models/base_model.py:152-158)
+    inp64 = O.gru_front(x.double(), sd64).permute(0, 2, 1)
+    key64 = torch.matmul(inp64, sd64["weight_key"]).squeeze(-1)
+    query64 = torch.matmul(inp64, sd64["weight_query"]).squeeze(-1)
+    logit64 = key64.unsqueeze(2) + query64.unsqueeze(1)                          # [B,N,N]
+    pos_impl = (key.unsqueeze(2) + query.unsqueeze(1)) > 0                        # fp32 add, as in the kernels
+    ulp = torch.finfo(torch.float32).eps * torch.maximum(key64.abs().unsqueeze(2), query64.abs().unsqueeze(1))
+    near = logit64.abs() < 4 * ulp
+    flips = pos_impl != (logit64 > 0)
+    n_near, n_flip = int(near.sum()), int(flips.sum())
+    print(f"kink audit: {n_near} of {logit64.numel()} logits within 4 fp32 ulp of 0, {n_flip} decision flips")
+    assert n_near <= max(16, int(2e-6 * logit64.numel())), n_near
+    assert n_flip <= 8 and bool((flips & ~near).sum() == 0), (n_flip, int((flips & ~near).sum()))
+    # -- 1. independent comparison
+    _, t_forecast, t_att, t_grads = O.loss_and_grads(x.double(), y.double(), sd64)
     rows = [("forecast", relerr(forecast, t_forecast)), ("attention", relerr(att, t_att))]
+    kink_rows = []
     for k, p in model.named_parameters():
         if t_grads[k] is None:
             assert p.grad is None, k
-        else:
-            rows.append(("grad." + k, relerr(p.grad, t_grads[k])))
+            continue
+        e = relerr(p.grad, t_grads[k])
+        (kink_rows if (n_flip and k.startswith(KINK_GROUPS)) else rows).append(("grad." + k, e))
+    # -- 3. the kink-sensitive groups, only when a decision actually differs
+    if n_flip:
+        kink_pos = torch.where(flips, pos_impl, logit64 > 0)
+        _, _, _, k_grads = O.loss_and_grads(x.double(), y.double(), sd64, kink_pos=kink_pos)
+        print("un-overridden fp64 vs hip on the kink groups:", [(k, f"{e:.2e}") for k, e in kink_rows])
+        for k, p in model.named_parameters():
+            if k.startswith(KINK_GROUPS):
+                rows.append(("grad." + k + " (impl. kink decisions)", relerr(p.grad, k_grads[k])))
     worst = sorted(rows, key=lambda r: -r[1])[:6]
     print("worst (name, hip-vs-fp64):", [(k, f"{e:.2e}") for k, e in worst])
     bad = [(k, f"{e:.2e}") for k, e in rows if not e < TOL]
