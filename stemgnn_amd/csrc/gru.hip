@@ -19,6 +19,7 @@
 #include "../../include/stemgnn_hip.h"
 #include "gemm2.h"
 #include "gemm_core.h"
+#include "gru_wide.h"
 
 #define SG_TRY(e)                                \
   do {                                           \
@@ -718,14 +719,28 @@ static int gru_pick_KU(int Hd, int P) {              // unrolled mat-vec length:
   const int U = (Hd + P - 1) / P;
   return U <= 32 ? 32 : (U <= 48 ? 48 : (U <= 58 ? 58 : 64));
 }
-static size_t gru_xbuf_floats(int B, int Hd) { return (size_t)2 * 2 * B * 3 * Hd + 2; }   // u64 granules, 2 parities
+static size_t gru_xbuf_floats(int B, int Hd) {     // u64 granules, 2 parities (per-row clusters) | wide-cluster exchange
+  const size_t a = (size_t)2 * 2 * B * 3 * Hd + 2, b = gru_wide_xbuf_floats(Hd);
+  return a > b ? a : b;
+}
+// wide cluster (gru_wide.h): hidden sizes beyond the per-row clusters; STEMGNN_GRU_WIDE=0 disables, =1 forces it
+static int gru_pick_wide(int B, int Hd, int P2, GruWide* g) {
+  const char* e = getenv("STEMGNN_GRU_WIDE");
+  const int mode = e ? atoi(e) : -1;
+  if (mode == 0) return 0;
+  const char* c = getenv("STEMGNN_GRU_CLUSTER");
+  if (c && atoi(c) == 0 && mode != 1) return 0;
+  if (P2 > 0 && mode != 1) return 0;                 // the per-row clusters are faster where they fit
+  (void)B;
+  return gru_wide_plan(Hd, gru_resident_limit(), g);
+}
 
 extern "C" size_t stemgnn_gru_fwd_scratch_floats(int B, int S, int Hd) {
-  return (size_t)3 * Hd * Hd + (size_t)3 * S * B * Hd + gru_xbuf_floats(B, Hd);   // W_hh^T | gi | granules
+  return (size_t)3 * Hd * Hd + (size_t)3 * S * B * Hd + gru_xbuf_floats(B, Hd) + 4;   // W_hh^T | gi | exchange
 }
 extern "C" size_t stemgnn_gru_bwd_scratch_floats(int B, int S, int Hd, int W) {
   return (size_t)4 * S * B * Hd + (size_t)GRU_NSPLIT * 3 * Hd * (Hd + 1) + (size_t)GRU_NSPLIT * 3 * Hd * (W + 1) +
-         gru_xbuf_floats(B, Hd);
+         gru_xbuf_floats(B, Hd) + 4;
 }
 
 extern "C" int stemgnn_gru_fwd(const float* x, const float* w_ih, const float* w_hh, const float* b_ih,
@@ -742,6 +757,12 @@ extern "C" int stemgnn_gru_fwd(const float* x, const float* w_ih, const float* w
   GruGiOp op{x, w_ih, b_ih, gi, B, S, Hd, W};
   SG_TRY((sg_launch_gemm<GruGiOp, 64, 64, true, true, false>(op, S * B, 3 * Hd, 1, st)));
   const int P2 = gru_pick_P2(B, Hd);
+  GruWide wide;
+  if (gru_pick_wide(B, Hd, P2, &wide) > 0) {
+    float* xb = scratch + ((((size_t)3 * Hd * Hd + (size_t)3 * S * B * Hd) + 3) & ~(size_t)3);      // 16-byte aligned
+    SG_TRY(gru_wide_fwd(gi, w_hh, b_hh, B, S, Hd, wide, xb, status, h_all, reserve, st));
+    return 0;
+  }
   if (P2 > 0) {
     gru_u64* xbuf = (gru_u64*)(scratch + ((((size_t)3 * Hd * Hd + (size_t)3 * S * B * Hd) + 1) & ~(size_t)1));
     SG_TRY(hipMemsetAsync(xbuf, 0, (size_t)2 * B * Hd * sizeof(gru_u64), st));      // tags := 0 before every launch
@@ -796,7 +817,11 @@ extern "C" int stemgnn_gru_bwd(const float* dh_all, const float* x, const float*
   float* p_ih = p_hh + (size_t)GRU_NSPLIT * 3 * Hd * (Hd + 1);
   const int P2 = gru_pick_P2(B, Hd);
   const int P = P2 > 0 ? 0 : gru_pick_P(B, Hd);
-  if (P2 > 0) {
+  GruWide wide;
+  if (gru_pick_wide(B, Hd, P2, &wide) > 0) {
+    float* xb = scratch + ((((size_t)(p_ih - scratch) + (size_t)GRU_NSPLIT * 3 * Hd * (W + 1)) + 3) & ~(size_t)3);
+    SG_TRY(gru_wide_bwd(dh_all, w_hh, h_all, reserve, B, S, Hd, wide, xb, status, dgi, dghn, st));
+  } else if (P2 > 0) {
     gru_u64* xbuf = (gru_u64*)(scratch + ((((size_t)(p_ih - scratch) + (size_t)GRU_NSPLIT * 3 * Hd * (W + 1)) + 1) & ~(size_t)1));
     SG_TRY(hipMemsetAsync(xbuf, 0, (size_t)2 * B * 3 * Hd * sizeof(gru_u64), st));
     const dim3 grid(8 * ((B + 7) / 8) * P2);

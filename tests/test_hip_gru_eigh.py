@@ -34,6 +34,33 @@ def test_gru_fwd_bwd_vs_torch_cpu(B, S, W, cluster, monkeypatch):
         assert relerr(mine.grad, ref.grad) < TOL
 
 
+@pytest.mark.parametrize("B,S,W,force", [(8, 1024, 12, False), (16, 2048, 48, False), (5, 100, 7, True), (3, 228, 12, True),
+                                          (20, 600, 12, False), (2, 1500, 4, False), (16, 513, 3, False)])
+def test_wide_cluster_gru_vs_torch_cpu(B, S, W, force, monkeypatch):
+    """csrc/gru_wide.h: one cluster of workgroups holding W_hh as MFMA A operands for all batch rows (hidden sizes beyond
+    the per-row clusters; the per-GPU shards of BASELINE configs[3] / [4] are the first two cases; B > 16 runs as
+    16-column passes; `force` runs small hidden sizes through it) against torch's CPU nn.GRU, forward and every gradient."""
+    if force:
+        monkeypatch.setenv("STEMGNN_GRU_WIDE", "1")
+    from stemgnn_amd.ops import GruFront, check_gru_status
+
+    torch.manual_seed(S + B)
+    gru = torch.nn.GRU(W, S)
+    x = torch.randn(B, W, S)
+    dh = torch.randn(S, B, S)
+    out, _ = gru(x.permute(2, 0, 1).contiguous())
+    out.backward(dh)
+    params = [p.detach().clone().cuda().requires_grad_(True)
+              for p in (gru.weight_ih_l0, gru.weight_hh_l0, gru.bias_ih_l0, gru.bias_hh_l0)]
+    h = GruFront.apply(x.cuda(), *params)
+    h.backward(dh.cuda())
+    torch.cuda.synchronize()
+    check_gru_status(torch.device("cuda:0"))
+    assert relerr(h, out.detach()) < TOL
+    for mine, ref in zip(params, (gru.weight_ih_l0, gru.weight_hh_l0, gru.bias_ih_l0, gru.bias_hh_l0)):
+        assert relerr(mine.grad, ref.grad) < TOL
+
+
 def _laplacian(N, B=6, seed=0):
     sd = O.det_state_dict(N, 12, 5, 3, seed=seed)
     torch.manual_seed(seed)

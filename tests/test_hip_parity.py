@@ -310,7 +310,8 @@ def test_large_config_shapes(N, W, multi, H, B):
     model, not arithmetic error.  The test therefore
       1. compares every tensor with the UN-overridden fp64 oracle (no information from the implementation);
       2. independently audits the kink: the implementation's fp32 decisions differ from the fp64 oracle's on at most a
-         handful of logits, and every one of those lies within 4 fp32 ulp of zero (the count is reported);
+         handful of logits, and every one of those is smaller than twice the (measured, rounding-class) fp32 evaluation
+         error of key / query (the count of such logits is reported and bounded);
       3. only if such flips exist, re-checks the three gradient groups they can move against an fp64 run that takes the
          implementation's decisions on exactly those logits."""
     from stemgnn_amd import ops
@@ -332,12 +333,16 @@ def test_large_config_shapes(N, W, multi, H, B):
     query64 = torch.matmul(inp64, sd64["weight_query"]).squeeze(-1)
     logit64 = key64.unsqueeze(2) + query64.unsqueeze(1)                          # [B,N,N]
     pos_impl = (key.unsqueeze(2) + query.unsqueeze(1)) > 0                        # fp32 add, as in the kernels
-    ulp = torch.finfo(torch.float32).eps * torch.maximum(key64.abs().unsqueeze(2), query64.abs().unsqueeze(1))
-    near = logit64.abs() < 4 * ulp
+    # fp32 evaluation error of key / query (dot products of N terms): measured against the fp64 oracle, and itself
+    # asserted to be of rounding class; a logit is "near the kink" when it is smaller than twice that error
+    ek, eq = float((key.double() - key64).abs().max()), float((query.double() - query64).abs().max())
+    assert relerr(key, key64) < 2e-5 and relerr(query, query64) < 2e-5, (relerr(key, key64), relerr(query, query64))
+    near = logit64.abs() <= 2 * (ek + eq)
     flips = pos_impl != (logit64 > 0)
     n_near, n_flip = int(near.sum()), int(flips.sum())
-    print(f"kink audit: {n_near} of {logit64.numel()} logits within 4 fp32 ulp of 0, {n_flip} decision flips")
-    assert n_near <= max(16, int(2e-6 * logit64.numel())), n_near
+    print(f"kink audit: key/query fp32 error {ek:.2e}/{eq:.2e}; {n_near} of {logit64.numel()} logits within twice that "
+          f"of 0, {n_flip} decision flips")
+    assert n_near <= max(16, int(2e-5 * logit64.numel())), n_near
     assert n_flip <= 8 and bool((flips & ~near).sum() == 0), (n_flip, int((flips & ~near).sum()))
     # -- 1. independent comparison
     _, t_forecast, t_att, t_grads = O.loss_and_grads(x.double(), y.double(), sd64)

@@ -1,0 +1,36 @@
+"""Time the GRU stage alone (through ops.GruFront) at the large-N shard shapes: forward and forward+backward."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from stemgnn_amd.ops import GruFront, check_gru_status
+
+dev = torch.device("cuda")
+for B, W, S in ((8, 12, 1024), (16, 48, 2048), (32, 12, 228), (32, 12, 358)):
+    g = torch.nn.GRU(W, S).to(dev)
+    x = torch.randn(B, W, S, device=dev)
+    ps = [g.weight_ih_l0, g.weight_hh_l0, g.bias_ih_l0, g.bias_hh_l0]
+    dh = torch.randn(S, B, S, device=dev)
+
+    def fb():
+        for p in ps:
+            p.grad = None
+        h = GruFront.apply(x, *ps)
+        h.backward(dh)
+    fb()
+    torch.cuda.synchronize()
+    e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    n = 3
+    with torch.no_grad():
+        e[0].record()
+        for _ in range(n):
+            GruFront.apply(x, *ps)
+        e[1].record()
+    for _ in range(n):
+        fb()
+    e[2].record()
+    torch.cuda.synchronize()
+    check_gru_status(dev)
+    f = e[0].elapsed_time(e[1]) / n
+    t = e[1].elapsed_time(e[2]) / n
+    print(f"B={B} N={S} W={W}: fwd {f:8.3f} ms ({f / S * 1e3:.2f} us/step)  fwd+bwd {t:8.3f} ms  bwd incl. wgrad {(t - f):8.3f} ms", flush=True)
