@@ -93,12 +93,34 @@ def det_state_dict(units, time_step, multi_layer, horizon, seed=0, dtype=torch.f
 # --------------------------------------------------------------------------- #
 # front: GRU -> self attention -> Laplacian -> Chebyshev
 # --------------------------------------------------------------------------- #
+def gru_manual(seq, w_ih, w_hh, b_ih, b_hh):
+    """nn.GRU(time_step, units) written out (torch.nn.GRU docs; the cell ATen's _VF.gru evaluates):
+        r = s(W_ir x + b_ir + W_hr h + b_hr),  z = s(W_iz x + b_iz + W_hz h + b_hz),
+        n = tanh(W_in x + b_in + r * (W_hn h + b_hn)),  h' = (1 - z) * n + z * h,   gate order (r, z, n), h_0 = 0.
+    seq [S,B,W] -> [S,B,H].  Device-agnostic plain torch ops: lets the LARGE parity cases evaluate the fp64 yardstick
+    through torch on the GPU (MIOpen has no fp64 RNN); pinned to _VF.gru on the CPU by tests/test_oracle_golden.py."""
+    H = w_hh.shape[1]
+    gi = torch.matmul(seq, w_ih.t()) + b_ih
+    h = torch.zeros(seq.shape[1], H, dtype=seq.dtype, device=seq.device)
+    w_hh_t = w_hh.t()
+    outs = []
+    for s in range(seq.shape[0]):
+        gh = torch.matmul(h, w_hh_t) + b_hh
+        r = torch.sigmoid(gi[s, :, :H] + gh[:, :H])
+        z = torch.sigmoid(gi[s, :, H:2 * H] + gh[:, H:2 * H])
+        n = torch.tanh(gi[s, :, 2 * H:] + r * gh[:, 2 * H:])
+        h = (1.0 - z) * n + z * h
+        outs.append(h)
+    return torch.stack(outs, dim=0)
+
+
 def gru_front(x, sd):
     """models/base_model.py:137-138.  x [B,W,N] -> GRU over the node axis -> [B,N_seq,N_hid]."""
     N = sd["weight_key"].shape[0]
-    W = x.shape[1]
     flat = [sd["GRU.weight_ih_l0"], sd["GRU.weight_hh_l0"], sd["GRU.bias_ih_l0"], sd["GRU.bias_hh_l0"]]
     seq = x.permute(2, 0, 1).contiguous()  # [N_seq, B, W]
+    if x.is_cuda:      # yardstick evaluated on a device (large cases only): written-out cell, see gru_manual
+        return gru_manual(seq, *flat).permute(1, 0, 2).contiguous()
     h0 = torch.zeros(1, x.shape[0], N, dtype=x.dtype)
     out, _ = torch._VF.gru(seq, h0, flat, True, 1, 0.0, False, False, False)
     return out.permute(1, 0, 2).contiguous()  # [B, N_seq, N_hid]

@@ -97,3 +97,22 @@ def test_oracle_matches_live_reference(N, W, multi, H, B):
             assert o_grads[k] is None or float(o_grads[k].abs().max()) == 0.0
         else:
             assert relerr(o_grads[k], p.grad) < 5 * TOL32, k
+
+
+def test_written_out_gru_cell_matches_aten_gru():
+    """oracle.gru_manual (the device-agnostic written-out cell the LARGE GPU parity cases evaluate in fp64 on the
+    device) against ATen's _VF.gru -- what the reference's nn.GRU runs (models/base_model.py:92,137): output and all
+    four parameter gradients, fp64."""
+    torch.manual_seed(5)
+    S, B, W, H = 9, 4, 5, 7
+    gru = torch.nn.GRU(W, H).double()
+    seq = torch.randn(S, B, W, dtype=torch.float64)
+    dh = torch.randn(S, B, H, dtype=torch.float64)
+    out, _ = gru(seq)
+    out.backward(dh)
+    ps = [p.detach().clone().requires_grad_(True) for p in (gru.weight_ih_l0, gru.weight_hh_l0, gru.bias_ih_l0, gru.bias_hh_l0)]
+    mine = O.gru_manual(seq, *ps)
+    mine.backward(dh)
+    assert relerr(mine.detach(), out.detach()) < 1e-13
+    for a, b in zip(ps, (gru.weight_ih_l0, gru.weight_hh_l0, gru.bias_ih_l0, gru.bias_hh_l0)):
+        assert relerr(a.grad, b.grad) < 1e-12
