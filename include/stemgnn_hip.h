@@ -57,17 +57,21 @@ int stemgnn_make_tables_host(int W, int multi, float* tables_host);
  * saved    stemgnn_attn_saved_floats(): key[B,N] | query[B,N] | rowsum[B,N] | A[N,N] (batch-mean, un-symmetrised) | deg[N]
  * attention_out [N,N] = 0.5(A+A^T)  (the tensor Model.forward returns)
  * mul_L    [4,N,N]: slot 0 := 0 (T0 is zeros, :129) and slot 1 := L are written here
+ * parts    bit 0: attention (-> A | deg, contiguous N*N + N floats at saved + 3*B*N), bit 1: Laplacian from (A, deg);
+ *          3 = both.  The batch mean (:140) is the ONE cross-sample reduction of the path: a data-parallel caller that
+ *          wants single-process semantics for a split batch runs part 1, averages A | deg over the ranks, runs part 2.
  */
 int stemgnn_attn_laplacian_fwd(const float* h, const float* wk, const float* wq, float alpha,
                                float drop_p, int training, const uint64_t* seed,
                                int B, int N, float* saved, float* attention_out, float* mul_L,
-                               void* stream);
+                               int parts, void* stream);
 /* dL [N,N] = gradient w.r.t. mul_L slot 1 (total).  Outputs dh [N,B,N], dwk [N], dwq [N].
- * scratch: stemgnn_attn_scratch_floats(B,N,nchunk). */
+ * scratch: stemgnn_attn_scratch_floats(B,N,nchunk).  parts bit 0: Laplacian backward -> dA / B in scratch[0 .. N*N)
+ * (averaged over the ranks by an exact-mode data-parallel caller), bit 1: softmax / key / query backward; 3 = both. */
 int stemgnn_attn_laplacian_bwd(const float* dL, const float* h, const float* wk, const float* wq,
                                float alpha, float drop_p, int training, const uint64_t* seed,
                                int B, int N, const float* saved, float* scratch, int nchunk,
-                               float* dh, float* dwk, float* dwq, void* stream);
+                               float* dh, float* dwk, float* dwq, int parts, void* stream);
 /* test hook: write the 0/1 keep-mask [B,N,N] the kernels above generate for `seed`. */
 int stemgnn_dropout_mask(float drop_p, const uint64_t* seed, int B, int N, float* mask, void* stream);
 
@@ -170,9 +174,10 @@ int stemgnn_fc_tail_bwd(const float* dforecast, const float* fsum, const float* 
                         float* dw2, float* db2, void* stream);
 /* RMSprop step of the reference driver (models/handler.py:127,165; torch defaults alpha=0.99, momentum 0, not
  * centered) over flat, 16-byte aligned parameter / gradient / square_avg buffers of n floats; lr is read from
- * device memory; zero_grad != 0 also clears the gradients for the next step (handler.py:160). */
+ * device memory; zero_grad != 0 also clears the gradients for the next step (handler.py:160); every gradient is
+ * multiplied by grad_scale first (1 / world_size after a SUM all-reduce of the flat bucket: no separate averaging pass). */
 int stemgnn_rmsprop_step(float* params, float* grads, float* square_avg, size_t n, const float* lr_dev,
-                         float alpha, float eps, int zero_grad, void* stream);
+                         float alpha, float eps, int zero_grad, float grad_scale, void* stream);
 
 /* ---- data path either side of the hot path ---------------------------------------------
  * normalized() (data_loader/forecast_dataloader.py:7-22): out[t,n] = (float)clip01?((raw[t,n]-sub[n])/div[n]) in IEEE

@@ -26,9 +26,9 @@ SIGNATURES = {
     "stemgnn_attn_saved_floats": (c_size_t, [c_int, c_int]),
     "stemgnn_attn_scratch_floats": (c_size_t, [c_int, c_int, c_int]),
     "stemgnn_make_tables_host": (c_int, [c_int, c_int, _P]),
-    "stemgnn_attn_laplacian_fwd": (c_int, [_P, _P, _P, c_float, c_float, c_int, _P, c_int, c_int, _P, _P, _P, _P]),
+    "stemgnn_attn_laplacian_fwd": (c_int, [_P, _P, _P, c_float, c_float, c_int, _P, c_int, c_int, _P, _P, _P, c_int, _P]),
     "stemgnn_attn_laplacian_bwd": (c_int, [_P, _P, _P, _P, c_float, c_float, c_int, _P, c_int, c_int, _P, _P, c_int,
-                                           _P, _P, _P, _P]),
+                                           _P, _P, _P, c_int, _P]),
     "stemgnn_dropout_mask": (c_int, [c_float, _P, c_int, c_int, _P, _P]),
     "stemgnn_cheb_fwd": (c_int, [_P, c_int, _P]),
     "stemgnn_cheb_bwd": (c_int, [_P, _P, _P, _P, c_int, _P]),
@@ -43,7 +43,7 @@ SIGNATURES = {
     "stemgnn_fc_tail_scratch_floats": (c_size_t, [c_int, c_int, c_int, c_int]),
     "stemgnn_fc_tail_fwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P]),
     "stemgnn_fc_tail_bwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P]),
-    "stemgnn_rmsprop_step": (c_int, [_P, _P, _P, c_size_t, _P, c_float, c_float, c_int, _P]),
+    "stemgnn_rmsprop_step": (c_int, [_P, _P, _P, c_size_t, _P, c_float, c_float, c_int, c_float, _P]),
     "stemgnn_normalize_series": (c_int, [_P, _P, _P, c_int, _P, c_long, c_int, _P]),
     "stemgnn_window_gather": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_long, _P, _P]),
     "stemgnn_mse_scratch_floats": (c_size_t, []),

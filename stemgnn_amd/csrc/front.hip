@@ -399,8 +399,8 @@ extern "C" size_t stemgnn_attn_scratch_floats(int B, int N, int nchunk) {
 
 extern "C" int stemgnn_attn_laplacian_fwd(const float* h, const float* wk, const float* wq, float alpha,
                                           float drop_p, int training, const uint64_t* seed, int B, int N,
-                                          float* saved, float* attention_out, float* mul_L, void* stream) {
-  if (!h || !wk || !wq || !saved || !attention_out || !mul_L || B <= 0 || N <= 0) return SG_EINVAL;
+                                          float* saved, float* attention_out, float* mul_L, int parts, void* stream) {
+  if (!h || !wk || !wq || !saved || !attention_out || !mul_L || B <= 0 || N <= 0 || (parts & 3) == 0) return SG_EINVAL;
   if (training && drop_p > 0.f && !seed) return SG_EINVAL;
   if (drop_p < 0.f || drop_p >= 1.f) return SG_EINVAL;
   hipStream_t st = (hipStream_t)stream;
@@ -409,29 +409,34 @@ extern "C" int stemgnn_attn_laplacian_fwd(const float* h, const float* wk, const
   float* rowsum = query + (size_t)B * N;
   float* A = rowsum + (size_t)B * N;
   float* deg = A + (size_t)N * N;
-  hipLaunchKernelGGL(sg_keyquery_kernel, dim3(B, (N + 63) / 64), dim3(256), 0, st, h, wk, wq, key, query, B, N);
-  SG_TRY(hipGetLastError());
-  float* Apart = deg + N;
-  const int nbc = B < ATTN_NBC ? B : ATTN_NBC;
-  const int bn = (B + nbc - 1) / nbc;
-  const size_t lds = (size_t)(bn + 4 * N) * sizeof(float);
-  if (lds > 64 * 1024) return SG_EINVAL;
-  hipLaunchKernelGGL(sg_attention_fwd_kernel, dim3((N + 3) / 4, (B + bn - 1) / bn), dim3(256), lds, st, key, query, alpha,
-                     drop_p, training, seed, B, N, bn, rowsum, Apart);
-  SG_TRY(hipGetLastError());
-  hipLaunchKernelGGL(sg_attention_reduce_kernel, dim3((N + 3) / 4), dim3(256), 0, st, Apart, (B + bn - 1) / bn, B, N, A, deg);
-  SG_TRY(hipGetLastError());
-  hipLaunchKernelGGL(sg_laplacian_fwd_kernel, dim3((N + 31) / 32, (N + 31) / 32), dim3(256), 0, st, A, deg,
-                     attention_out, mul_L, N);
-  SG_TRY(hipGetLastError());
+  if (parts & 1) {      // attention: key / query, softmax (+dropout), batch mean -> A [N,N] | deg [N] (contiguous)
+    hipLaunchKernelGGL(sg_keyquery_kernel, dim3(B, (N + 63) / 64), dim3(256), 0, st, h, wk, wq, key, query, B, N);
+    SG_TRY(hipGetLastError());
+    float* Apart = deg + N;
+    const int nbc = B < ATTN_NBC ? B : ATTN_NBC;
+    const int bn = (B + nbc - 1) / nbc;
+    const size_t lds = (size_t)(bn + 4 * N) * sizeof(float);
+    if (lds > 64 * 1024) return SG_EINVAL;
+    hipLaunchKernelGGL(sg_attention_fwd_kernel, dim3((N + 3) / 4, (B + bn - 1) / bn), dim3(256), lds, st, key, query, alpha,
+                       drop_p, training, seed, B, N, bn, rowsum, Apart);
+    SG_TRY(hipGetLastError());
+    hipLaunchKernelGGL(sg_attention_reduce_kernel, dim3((N + 3) / 4), dim3(256), 0, st, Apart, (B + bn - 1) / bn, B, N, A, deg);
+    SG_TRY(hipGetLastError());
+  }
+  if (parts & 2) {      // Laplacian from (A, deg); between the parts a data-parallel caller may average A | deg over ranks
+    hipLaunchKernelGGL(sg_laplacian_fwd_kernel, dim3((N + 31) / 32, (N + 31) / 32), dim3(256), 0, st, A, deg,
+                       attention_out, mul_L, N);
+    SG_TRY(hipGetLastError());
+  }
   return 0;
 }
 
 extern "C" int stemgnn_attn_laplacian_bwd(const float* dL, const float* h, const float* wk, const float* wq,
                                           float alpha, float drop_p, int training, const uint64_t* seed, int B, int N,
                                           const float* saved, float* scratch, int nchunk, float* dh, float* dwk,
-                                          float* dwq, void* stream) {
-  if (!dL || !h || !wk || !wq || !saved || !scratch || !dh || !dwk || !dwq || B <= 0 || N <= 0 || nchunk <= 0)
+                                          float* dwq, int parts, void* stream) {
+  if (!dL || !h || !wk || !wq || !saved || !scratch || !dh || !dwk || !dwq || B <= 0 || N <= 0 || nchunk <= 0 ||
+      (parts & 3) == 0)
     return SG_EINVAL;
   if (training && drop_p > 0.f && !seed) return SG_EINVAL;
   hipStream_t st = (hipStream_t)stream;
@@ -444,9 +449,12 @@ extern "C" int stemgnn_attn_laplacian_bwd(const float* dL, const float* h, const
   float* dkey = dAB + (size_t)N * N;
   float* dquery = dkey + (size_t)B * N;
   float* dqpart = dquery + (size_t)B * N;
-  hipLaunchKernelGGL(sg_laplacian_bwd_kernel, dim3((N + 3) / 4), dim3(256), 0, st, dL, A, deg, dAB, B, N,
-                     (training && drop_p > 0.f) ? 1 : 0);
-  SG_TRY(hipGetLastError());
+  if (parts & 1) {      // Laplacian backward -> dA / B in scratch[0 .. N*N)  (a data-parallel caller may average it)
+    hipLaunchKernelGGL(sg_laplacian_bwd_kernel, dim3((N + 3) / 4), dim3(256), 0, st, dL, A, deg, dAB, B, N,
+                       (training && drop_p > 0.f) ? 1 : 0);
+    SG_TRY(hipGetLastError());
+  }
+  if (!(parts & 2)) return 0;
   const size_t lds = (size_t)(4 * N) * sizeof(float);
   if (lds > 150 * 1024) return SG_EINVAL;
   hipLaunchKernelGGL(sg_attention_bwd_kernel, dim3(B, nchunk), dim3(256), lds, st, dAB, key, query, rowsum, alpha,

@@ -219,13 +219,15 @@ extern "C" int stemgnn_fc_tail_bwd(const float* dforecast, const float* fsum, co
 // torch.optim.RMSprop(momentum=0, centered=False, weight_decay=0):  sq = alpha*sq + (1-alpha)*g*g ;
 // p -= lr * g / (sqrt(sq) + eps).  lr is read from device memory so an LR scheduler can change it under graph replay.
 __global__ void sg_rmsprop_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ sq, size_t n,
-                                  const float* __restrict__ lr_dev, float alpha, float eps, int zero_grad) {
+                                  const float* __restrict__ lr_dev, float alpha, float eps, int zero_grad,
+                                  float gscale) {
   const float lr = lr_dev[0];
   size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
   const size_t stride = (size_t)gridDim.x * blockDim.x * 4;
   for (; i + 3 < n; i += stride) {
     float4 pv = *reinterpret_cast<float4*>(p + i), gv = *reinterpret_cast<float4*>(g + i),
            sv = *reinterpret_cast<float4*>(sq + i);
+    gv.x *= gscale; gv.y *= gscale; gv.z *= gscale; gv.w *= gscale;
     sv.x = alpha * sv.x + (1.f - alpha) * gv.x * gv.x; pv.x -= lr * gv.x / (sqrtf(sv.x) + eps);
     sv.y = alpha * sv.y + (1.f - alpha) * gv.y * gv.y; pv.y -= lr * gv.y / (sqrtf(sv.y) + eps);
     sv.z = alpha * sv.z + (1.f - alpha) * gv.z * gv.z; pv.z -= lr * gv.z / (sqrtf(sv.z) + eps);
@@ -236,7 +238,7 @@ __global__ void sg_rmsprop_kernel(float* __restrict__ p, float* __restrict__ g, 
   }
   if (i < n && i + 3 >= n) {          // ragged tail (at most one thread)
     for (size_t j = i; j < n; ++j) {
-      const float gv = g[j];
+      const float gv = g[j] * gscale;
       const float sv = alpha * sq[j] + (1.f - alpha) * gv * gv;
       sq[j] = sv;
       p[j] -= lr * gv / (sqrtf(sv) + eps);
@@ -246,14 +248,14 @@ __global__ void sg_rmsprop_kernel(float* __restrict__ p, float* __restrict__ g, 
 }
 
 extern "C" int stemgnn_rmsprop_step(float* params, float* grads, float* square_avg, size_t n, const float* lr_dev,
-                                    float alpha, float eps, int zero_grad, void* stream) {
+                                    float alpha, float eps, int zero_grad, float grad_scale, void* stream) {
   if (!params || !grads || !square_avg || !lr_dev || n == 0) return SG_EINVAL;
   if ((((uintptr_t)params | (uintptr_t)grads | (uintptr_t)square_avg) & 15) != 0) return SG_EINVAL;
   const size_t nvec = (n + 3) / 4;
   unsigned blocks = (unsigned)((nvec + 255) / 256);
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(sg_rmsprop_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, params, grads, square_avg, n,
-                     lr_dev, alpha, eps, zero_grad);
+                     lr_dev, alpha, eps, zero_grad, grad_scale);
   SG_TRY(hipGetLastError());
   return 0;
 }

@@ -39,13 +39,21 @@ class FlatGradBucket:
     def zero(self):
         self.flat.zero_()
 
-    def all_reduce_mean(self, group=None):
+    def all_reduce_sum(self, group=None):
+        """SUM over the ranks; the consumer scales by 1 / world (FusedRMSprop.grad_scale: inside the optimizer kernel,
+        no separate averaging pass over the bucket)."""
         if self.flat.is_cuda:
             from .ops import join_side_streams
             join_side_streams(self.flat.device)      # weight gradients may still be in flight on the side stream
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
-            self.flat.div_(dist.get_world_size(group))
+            return dist.get_world_size(group)
+        return 1
+
+    def all_reduce_mean(self, group=None):
+        world = self.all_reduce_sum(group)
+        if world > 1:
+            self.flat.div_(world)
 
 
 def shard_batch(global_batch, rank, world_size):

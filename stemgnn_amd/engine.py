@@ -45,7 +45,8 @@ def capture(fn, warmups=3, on_fail=None):
 
 
 class TrainStep:
-    def __init__(self, model, optimizer, batch_size, window_size, horizon, units, series=None, world=1, graph=True):
+    def __init__(self, model, optimizer, batch_size, window_size, horizon, units, series=None, world=1, graph=True,
+                 exact=False, group=None):
         self.model, self.opt = model, optimizer
         self.B, self.W, self.H, self.N = int(batch_size), int(window_size), int(horizon), int(units)
         self.world = world
@@ -65,6 +66,14 @@ class TrainStep:
         self.loss_sum = torch.zeros((), device=dev, dtype=torch.float64)
         self._one = torch.ones((), device=dev)
         self.want_graph = bool(graph) and self.fused
+        self.group = group
+        if world > 1 and self.fused:
+            optimizer.grad_scale = 1.0 / world          # the all-reduce SUMs; the optimizer kernel applies 1 / world
+        if exact and world > 1:
+            # exact data-parallel mode: A and dA are averaged over the ranks inside forward / backward
+            # (two host-launched [N,N] collectives), so the step cannot be one captured graph: it runs eagerly
+            self.state.exact_group = (group, world)
+            self.want_graph = False
         self.mode = "eager"
         self._replay = None
         self._armed = False
@@ -90,7 +99,10 @@ class TrainStep:
 
     def _sync(self):
         if self.world > 1:
-            self.bucket.all_reduce_mean()
+            if self.fused:
+                self.bucket.all_reduce_sum(self.group)
+            else:
+                self.bucket.all_reduce_mean(self.group)
 
     def _arm(self):
         """First full batch: one eager step happened already (lazy state), now capture."""

@@ -45,6 +45,7 @@ class HotPathState:
         self.overlap = False
         self.prepacked = None        # (packed panels, side stream, blocks) queued by prepack_blocks
         self.pending = None          # (side stream, keep-alive objects) of weight-gradient work not yet joined
+        self.exact_group = None      # data-parallel "exact mode" (SURVEY 8e-ii): (process group, world size) or None
         _states.add(self)
 
     def set(self, direct=True, overlap=False):
@@ -88,6 +89,13 @@ def join_side_streams(device=None):
     for st in list(_states):
         if st.pending is not None and (device is None or str(st.pending[0].device) == str(torch.device(device))):
             st.join()
+
+
+def _all_reduce_mean(t, group_world):
+    import torch.distributed as dist
+    group, world = group_world
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    t.div_(world)
 
 
 def set_direct_grad(model, flag=True, overlap=False):
@@ -406,10 +414,16 @@ class SpectralHotPath(torch.autograd.Function):
         pre, state.prepacked = state.prepacked, None
         if pre is not None:
             torch.cuda.current_stream().wait_stream(pre[1])
-        _lib.check(lib.stemgnn_attn_laplacian_fwd(
-            h.data_ptr(), wk.data_ptr(), wq.data_ptr(), float(alpha), float(drop_p), int(bool(training)),
-            seed.data_ptr() if use_drop else None, B, N, attn_saved.data_ptr(), attention.data_ptr(),
-            mul_L.data_ptr(), st), "attn_laplacian_fwd")
+        # exact data-parallel mode: the batch mean of the attention (:140) is the one cross-sample reduction of the path;
+        # averaging A | deg over the ranks between the two parts restores single-process semantics for a split batch
+        exact = state.exact_group
+        for part in ((3,) if exact is None else (1, 2)):
+            _lib.check(lib.stemgnn_attn_laplacian_fwd(
+                h.data_ptr(), wk.data_ptr(), wq.data_ptr(), float(alpha), float(drop_p), int(bool(training)),
+                seed.data_ptr() if use_drop else None, B, N, attn_saved.data_ptr(), attention.data_ptr(),
+                mul_L.data_ptr(), part, st), "attn_laplacian_fwd")
+            if exact is not None and part == 1:
+                _all_reduce_mean(attn_saved[3 * B * N:3 * B * N + N * N + N], exact)
         if _keep_attention_state:
             _last_attention_state[str(dev)] = (attn_saved[:B * N].view(B, N).clone(),
                                                attn_saved[B * N:2 * B * N].view(B, N).clone())
@@ -569,10 +583,16 @@ class SpectralHotPath(torch.autograd.Function):
         dwq = wq.grad if kq_direct else torch.empty_like(wq)
         attn_scratch = torch.empty(lib.stemgnn_attn_scratch_floats(B, N, _NCHUNK), device=dev, dtype=f32)
         use_drop = training and drop_p > 0.0
-        _lib.check(lib.stemgnn_attn_laplacian_bwd(
-            dL.data_ptr(), h.data_ptr(), wk.data_ptr(), wq.data_ptr(), alpha, drop_p, int(training),
-            seed.data_ptr() if use_drop else None, B, N, attn_saved.data_ptr(), attn_scratch.data_ptr(), _NCHUNK,
-            dh.data_ptr(), dwk.data_ptr(), dwq.data_ptr(), st), "attn_laplacian_bwd")
+        # exact mode: d(loss_global)/dA = mean over ranks of the local dA, and the flat gradient bucket is AVERAGED later,
+        # so every rank back-propagates the rank-mean of dA / B through its own samples
+        exact = state.exact_group
+        for part in ((3,) if exact is None else (1, 2)):
+            _lib.check(lib.stemgnn_attn_laplacian_bwd(
+                dL.data_ptr(), h.data_ptr(), wk.data_ptr(), wq.data_ptr(), alpha, drop_p, int(training),
+                seed.data_ptr() if use_drop else None, B, N, attn_saved.data_ptr(), attn_scratch.data_ptr(), _NCHUNK,
+                dh.data_ptr(), dwk.data_ptr(), dwq.data_ptr(), part, st), "attn_laplacian_bwd")
+            if exact is not None and part == 1:
+                _all_reduce_mean(attn_scratch[:N * N], exact)
         for s_, i_ in direct_idx:
             grads[s_][i_] = None                  # already in p.grad: nothing for autograd to accumulate
         if kq_direct:

@@ -36,6 +36,7 @@ class FusedRMSprop(torch.optim.Optimizer):
         self._lr_host = float(lr)
         self._lr_dev = torch.tensor([lr], device=dev, dtype=torch.float32)
         self.fuse_zero_grad = bool(fuse_zero_grad)
+        self.grad_scale = 1.0      # applied to every gradient inside the kernel (1 / world after a SUM all-reduce)
 
     def zero_grad(self, set_to_none=False):   # gradients live in the flat bucket; never drop the views
         self.bucket.zero()
@@ -67,5 +68,5 @@ class FusedRMSprop(torch.optim.Optimizer):
         _lib.check(lib.stemgnn_rmsprop_step(
             self.flat_p.data_ptr(), self.bucket.flat.data_ptr(), self.square_avg.data_ptr(), self.numel,
             self._lr_dev.data_ptr(), float(group["alpha"]), float(group["eps"]), int(self.fuse_zero_grad),
-            torch.cuda.current_stream().cuda_stream), "rmsprop_step")
+            float(self.grad_scale), torch.cuda.current_stream().cuda_stream), "rmsprop_step")
         return loss

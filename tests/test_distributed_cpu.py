@@ -68,3 +68,67 @@ def test_shard_batch_partitions(B, world):
     assert spans[0][0] == 0 and spans[-1][1] == B
     assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
     assert max(b - a for a, b in spans) - min(b - a for a, b in spans) <= 1
+
+
+class _AllReduceMean(torch.autograd.Function):
+    """What stemgnn_amd.ops does around the attention mean in exact mode: forward mean over ranks, backward mean too."""
+
+    @staticmethod
+    def forward(ctx, t):
+        t = t.clone()
+        dist.all_reduce(t)
+        return t / dist.get_world_size()
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.clone()
+        dist.all_reduce(g)
+        return g / dist.get_world_size()
+
+
+def _exact_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import stemgnn_oracle as O
+    N, W, multi, H, B = 9, 6, 2, 2, 6
+    sd = {k: v.double().requires_grad_(True) for k, v in O.det_state_dict(N, W, multi, H, seed=3).items()}
+    torch.manual_seed(11)
+    x, y = torch.randn(B, W, N, dtype=torch.float64), torch.randn(B, H, N, dtype=torch.float64)
+    lo, hi = shard_batch(B, rank, world)
+    xl, yl = x[lo:hi], y[lo:hi]
+    gru_out = O.gru_front(xl, sd)
+    att = O.self_graph_attention(gru_out, sd["weight_key"], sd["weight_query"])
+    A = _AllReduceMean.apply(att.mean(dim=0))                      # models/base_model.py:140 over the GLOBAL batch
+    L, _ = O.laplacian_from_attention(A.unsqueeze(0))
+    mul_L = O.cheb_polynomial(L)
+    X = xl.unsqueeze(1).permute(0, 1, 3, 2)
+    f0, X1 = O.stock_block(X, mul_L, sd, 0)
+    f1, _ = O.stock_block(X1, mul_L, sd, 1)
+    yhat = torch.nn.functional.linear(torch.nn.functional.leaky_relu(
+        torch.nn.functional.linear(f0 + f1, sd["fc.0.weight"], sd["fc.0.bias"]), 0.01), sd["fc.2.weight"], sd["fc.2.bias"])
+    loss = torch.nn.functional.mse_loss(yhat.permute(0, 2, 1), yl)
+    keys = list(sd.keys())
+    grads = torch.autograd.grad(loss, [sd[k] for k in keys], allow_unused=True)
+    flat = torch.cat([(g if g is not None else torch.zeros_like(sd[k])).reshape(-1) for k, g in zip(keys, grads)])
+    dist.all_reduce(flat)
+    out[rank] = flat / world                                        # what FlatGradBucket + grad_scale = 1/world applies
+    dist.destroy_process_group()
+
+
+def test_exact_mode_math_equals_single_process():
+    """with A (forward) and dA (backward) averaged over the ranks, the rank-averaged gradient of a SPLIT
+    batch equals the single-process gradient on the whole batch -- the scaling rule ops.SpectralHotPath uses
+    (mean / mean), checked here on the fp64 oracle over gloo."""
+    from oracle import stemgnn_oracle as O
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_exact_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    assert torch.equal(out[0], out[1])
+    N, W, multi, H, B = 9, 6, 2, 2, 6
+    sd = {k: v.double() for k, v in O.det_state_dict(N, W, multi, H, seed=3).items()}
+    torch.manual_seed(11)
+    x, y = torch.randn(B, W, N, dtype=torch.float64), torch.randn(B, H, N, dtype=torch.float64)
+    _, _, _, grads = O.loss_and_grads(x, y, sd)
+    ref = torch.cat([(g if g is not None else torch.zeros_like(sd[k])).reshape(-1) for k, g in grads.items()])
+    assert float((out[0] - ref).abs().max()) <= 1e-12 * float(ref.abs().max()) + 1e-15

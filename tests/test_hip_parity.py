@@ -328,7 +328,7 @@ def test_large_config_shapes(N, W, multi, H, B):
     ops.check_gru_status("cuda:0")
     # where the fp64 yardstick is evaluated: the CPU, except for the largest case (N = 2048, W = 48, batch 16: minutes on
     # the host) where the same oracle functions run through torch fp64 on the device; the N = 2048 batch-2 case
-    # evaluates BOTH and requires them to agree to 1e-9, which pins the device evaluation to the CPU oracle
+    # evaluates BOTH and requires them to agree to 1e-6, which pins the device evaluation to the CPU oracle
     on_dev = (N, B) == (2048, 16)
     where = "cuda:0" if on_dev else "cpu"
     sd64 = {k: v.double().to(where) for k, v in sd.items()}
@@ -372,10 +372,12 @@ def test_large_config_shapes(N, W, multi, H, B):
     if (N, B) == (2048, 2):                 # pin: the oracle evaluated through torch fp64 on the device == on the CPU
         dsd = {k: v.cuda() for k, v in sd64.items()}
         _, d_forecast, d_att, d_grads = O.loss_and_grads(x64.cuda(), y64.cuda(), dsd)
-        assert relerr(d_forecast, t_forecast) < 1e-9 and relerr(d_att, t_att) < 1e-9
+        # (measured 5e-11 / 5e-8: the device's fp64 transcendental / BLAS paths are not bit-identical to the host's;
+        #  1e-6 keeps two decades between this pin and the 1e-4 budget it serves)
+        assert relerr(d_forecast, t_forecast) < 1e-6 and relerr(d_att, t_att) < 1e-6
         for k, g in t_grads.items():
             if g is not None and not (n_flip and k.startswith(KINK_GROUPS)):
-                assert relerr(d_grads[k], g) < 1e-7, (k, relerr(d_grads[k], g))
+                assert relerr(d_grads[k], g) < 1e-6, (k, relerr(d_grads[k], g))
     worst = sorted(rows, key=lambda r: -r[1])[:6]
     print("worst (name, hip-vs-fp64):", [(k, f"{e:.2e}") for k, e in worst])
     bad = [(k, f"{e:.2e}") for k, e in rows if not e < TOL]

@@ -26,13 +26,13 @@ hg, wkg, wqg, dLg = h.to(dev), wk.to(dev), wq.to(dev), dL.to(dev)
 saved = torch.empty(lib.stemgnn_attn_saved_floats(B, N), device=dev)
 att = torch.empty(N, N, device=dev); mulL = torch.empty(4, N, N, device=dev)
 _lib.check(lib.stemgnn_attn_laplacian_fwd(hg.data_ptr(), wkg.data_ptr(), wqg.data_ptr(), 0.2, 0.0, 1, None, B, N,
-                                          saved.data_ptr(), att.data_ptr(), mulL.data_ptr(), st), "fwd")
+                                          saved.data_ptr(), att.data_ptr(), mulL.data_ptr(), 3, st), "fwd")
 nch = 4
 scr = torch.empty(lib.stemgnn_attn_scratch_floats(B, N, nch), device=dev)
 dh = torch.empty_like(hg); dwk = torch.empty_like(wkg); dwq = torch.empty_like(wqg)
 _lib.check(lib.stemgnn_attn_laplacian_bwd(dLg.data_ptr(), hg.data_ptr(), wkg.data_ptr(), wqg.data_ptr(), 0.2, 0.0, 1, None,
                                           B, N, saved.data_ptr(), scr.data_ptr(), nch, dh.data_ptr(), dwk.data_ptr(),
-                                          dwq.data_ptr(), st), "bwd")
+                                          dwq.data_ptr(), 3, st), "bwd")
 torch.cuda.synchronize()
 res = {}
 for dt in (torch.float64, torch.float32):
