@@ -99,17 +99,23 @@ int stemgnn_eigh_fwd(float* mul_L, float* lam, float* U, float* scratch, int N, 
  * Recurrence: P = 1..8 persistent workgroups per batch row keep their slice of w_hh resident in registers
  * for all S steps and exchange h (forward) / the gate gradients (backward) once per step through tagged
  * 8-byte granules (bounded spins; a timeout sets *status = 1, a device int the caller owns and zeroes);
- * very wide hidden states fall back to one workgroup per row streaming w_hh from L2. */
+ * hidden sizes beyond 512 run on ONE cluster of <= 224 workgroups that holds w_hh as MFMA A operands for up to 16
+ * batch rows at a time (csrc/gru_wide.h; flags + write-through stores instead of granules). */
 size_t stemgnn_gru_reserve_floats(int B, int S, int Hd);
 size_t stemgnn_gru_fwd_scratch_floats(int B, int S, int Hd);
 size_t stemgnn_gru_bwd_scratch_floats(int B, int S, int Hd, int W);
 int stemgnn_gru_fwd(const float* x, const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh,
                     int B, int S, int Hd, int W, float* scratch, float* h_ext, float* reserve, int* status,
                     void* stream);
-/* dh_all [S,B,Hd] = gradient of every output step -> dw_ih, dw_hh, db_ih, db_hh (x gets no gradient). */
+/* dh_all [S,B,Hd] = gradient of every output step -> dw_ih, dw_hh, db_ih, db_hh (x gets no gradient).
+ * side_stream / side_stream2 (both or neither; NULL = everything on `stream`): two more hipStream_t of the caller.
+ * With them the recurrence runs as STEMGNN_GRU_SEGMENTS (4) time segments and the weight-gradient reductions of a
+ * finished segment run on the side streams under the next segment's recurrence; the call forks from and joins back to
+ * `stream` with events (capturable), so on return everything is again ordered on `stream`. */
 int stemgnn_gru_bwd(const float* dh_all, const float* x, const float* w_hh, const float* h_ext,
                     const float* reserve, int B, int S, int Hd, int W, float* scratch,
-                    float* dw_ih, float* dw_hh, float* db_ih, float* db_hh, int* status, void* stream);
+                    float* dw_ih, float* dw_hh, float* db_ih, float* db_hh, int* status, void* stream,
+                    void* side_stream, void* side_stream2);
 
 /* ---- weight packing (per StockBlock, once per optimizer step) -----------------------------------
  * Folds the length-W DFT (:49-51) into the first GLU layer, drops the dead C2R bins,

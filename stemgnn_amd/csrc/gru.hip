@@ -517,7 +517,12 @@ __global__ __launch_bounds__(3 * (P / OW) * 64) void gru_bwd_cluster2_kernel(con
                                                                       const float* __restrict__ h_all,
                                                                       const float* __restrict__ reserve, int B, int S, int Hd,
                                                                       gru_u64* __restrict__ xbuf, int* __restrict__ status,
-                                                                      float* __restrict__ dgi, float* __restrict__ dghn) {
+                                                                      float* __restrict__ dgi, float* __restrict__ dghn,
+                                                                      int s_hi, int s_lo, float* __restrict__ carry) {
+  // Steps s_hi .. s_lo (descending) of the backward recurrence: the host may cut the S steps into time segments (one
+  // launch each) so the weight-gradient GEMMs of a finished segment overlap the recurrence of the next.  `carry`
+  // [B][Hd] hands the recurrent part of dh (dh * z + W_hh^T dgh) from one segment to the next; granule tags keep
+  // counting across segments, so the exchange buffer is zeroed before the FIRST segment only.
   static_assert(P % OW == 0, "owners per wave");
   constexpr int NTH = 3 * (P / OW) * 64;
   __shared__ float part[2][3 * P][64];
@@ -545,17 +550,17 @@ __global__ __launch_bounds__(3 * (P / OW) * 64) void gru_bwd_cluster2_kernel(con
     }
   }
   const int gu = u0 + (tid < un ? tid : 0);
-  float dhz = 0.f;                                      // dh * z carried to the previous step (this thread's unit)
+  float dhz = s_hi < S - 1 ? carry[(size_t)b * Hd + gu] : 0.f;   // recurrent part of dh carried to the previous step
   for (int i = tid; i < 2 * 3 * P * 64; i += NTH) (&part[0][0][0])[i] = 0.f;
   // inputs of the elementwise phase, prefetched one step ahead so their latency hides under the exchange + mat-vec
-  size_t prow = (size_t)(S - 1) * B + b;
+  size_t prow = (size_t)s_hi * B + b;
   float p_do = dout[prow * Hd + gu];
   float p_r = reserve[prow * 4 * Hd + gu], p_z = reserve[prow * 4 * Hd + Hd + gu];
   float p_n = reserve[prow * 4 * Hd + 2 * Hd + gu], p_g = reserve[prow * 4 * Hd + 3 * Hd + gu];
-  float p_h = h_all[(S > 1 ? prow - B : prow) * Hd + gu];
+  float p_h = h_all[(s_hi > 0 ? prow - B : prow) * Hd + gu];
   __syncthreads();
 
-  for (int s = S - 1; s >= 0; --s) {
+  for (int s = s_hi; s >= s_lo; --s) {
     const size_t row = (size_t)s * B + b;
     const unsigned tag = (unsigned)(S - s);
     gru_u64* xb = xbuf + ((size_t)(tag & 1) * B + b) * H3;
@@ -596,6 +601,13 @@ __global__ __launch_bounds__(3 * (P / OW) * 64) void gru_bwd_cluster2_kernel(con
     }
     __syncthreads();
   }
+  if (s_lo > 0 && tid < un) {                             // hand the recurrent part of dh_{s_lo - 1} to the next segment
+    const unsigned tag = (unsigned)(S - s_lo);
+    float c = dhz;
+#pragma unroll
+    for (int w = 0; w < 3 * P; ++w) c += part[tag & 1][w][tid];
+    carry[(size_t)b * Hd + gu] = c;
+  }
 }
 
 // ---- weight gradients: reductions over all (s,b) rows as split-K GEMMs ----------------------------------------
@@ -621,10 +633,11 @@ struct GruWhhGradOp {
 };
 struct GruWihGradOp {
   const float *dgi, *x;
-  float* part;
+  float* part;              // slab of split 0 of THIS launch
   int B, S, Hd, W, nsplit, chunk;
+  int row0, rows;           // the launch reduces rows [row0, row0 + rows) of the S*B (step, batch) rows
   __device__ bool setup(int z, int& M, int& N, int& K0, int& K1) const {
-    M = 3 * Hd; N = W + 1; K0 = z * chunk; K1 = min(S * B, K0 + chunk);
+    M = 3 * Hd; N = W + 1; K0 = row0 + z * chunk; K1 = min(row0 + rows, K0 + chunk);
     return true;
   }
   __device__ float a(int, int i, int k) const { return dgi[(size_t)k * 3 * Hd + i]; }
@@ -740,7 +753,7 @@ extern "C" size_t stemgnn_gru_fwd_scratch_floats(int B, int S, int Hd) {
 }
 extern "C" size_t stemgnn_gru_bwd_scratch_floats(int B, int S, int Hd, int W) {
   return (size_t)4 * S * B * Hd + (size_t)GRU_NSPLIT * 3 * Hd * (Hd + 1) + (size_t)GRU_NSPLIT * 3 * Hd * (W + 1) +
-         gru_xbuf_floats(B, Hd) + 4;
+         gru_xbuf_floats(B, Hd) + 4 + (size_t)B * Hd;     // ... | exchange | carry (time segments)
 }
 
 extern "C" int stemgnn_gru_fwd(const float* x, const float* w_ih, const float* w_hh, const float* b_ih,
@@ -803,9 +816,45 @@ extern "C" int stemgnn_gru_fwd(const float* x, const float* w_ih, const float* w
   return 0;
 }
 
+// weight-gradient GEMMs of the rows [row0, row0 + rows) of the recurrence: dW_hh | db_hh and dW_ih | db_ih as split slabs
+// `slab0` .. `slab0 + nsplit - 1` of the GRU_NSPLIT slabs the final fixed-order reduce sums
+static int gru_wgrad_rows(const float* dgi, const float* dghn, const float* h_ext, const float* x, float* p_hh, float* p_ih,
+                          int B, int S, int Hd, int W, int row0, int rows, int slab0, int nsplit, hipStream_t st_hh,
+                          hipStream_t st_ih) {
+  const int chunk = ((rows + nsplit - 1) / nsplit + 15) & ~15;
+  {  // dW_hh | db_hh = dgh^T [3Hd x rows] * [h_prev | 1]: rows 0..2Hd-1 of dgh are dgi's r,z gates, rows 2Hd..3Hd-1 = dghn
+     // (two "branches" of one 128x128 MFMA GEMM launch); h_prev of row (s,b) is row (s,b) of h_ext (slab 0 = zeros)
+    G2Args g;
+    G2SlabEpi e;
+    g.A[0] = dgi + (size_t)row0 * 3 * Hd;  g.lda[0] = 3 * Hd; g.M[0] = 2 * Hd;
+    g.A[1] = dghn + (size_t)row0 * Hd;     g.lda[1] = Hd;     g.M[1] = Hd;
+    for (int r = 0; r < 2; ++r) { g.B[r] = h_ext + (size_t)row0 * Hd; g.ldb[r] = Hd; g.N[r] = Hd + 1; g.K[r] = rows; }
+    g.nsplit = nsplit; g.chunk = chunk; g.b_ones_col = Hd;
+    e.part[0] = p_hh + (size_t)slab0 * 2 * Hd * (Hd + 1);
+    e.part[1] = p_hh + (size_t)GRU_NSPLIT * 2 * Hd * (Hd + 1) + (size_t)slab0 * Hd * (Hd + 1);
+    SG_TRY((g2_launch<G2SlabEpi, false, false>(g, e, 2, st_hh)));
+  }
+  GruWihGradOp o2{dgi, x, p_ih + (size_t)slab0 * 3 * Hd * (W + 1), B, S, Hd, W, nsplit, chunk, row0, rows};
+  SG_TRY((sg_launch_gemm<GruWihGradOp, 64, 32, false, false, false, 64>(o2, 3 * Hd, W + 1, nsplit, st_ih)));
+  return 0;
+}
+// events for the fork / join between the recurrence stream and the weight-gradient side streams (created once per
+// process; record / wait are stream-ordered and capturable: inside a hipGraph capture they become dependency edges)
+static hipEvent_t* gru_events() {
+  static hipEvent_t ev[12];
+  static bool ready = false;
+  if (!ready) {
+    for (int i = 0; i < 12; ++i)
+      if (hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) != hipSuccess) return nullptr;
+    ready = true;
+  }
+  return ev;
+}
+
 extern "C" int stemgnn_gru_bwd(const float* dh_all, const float* x, const float* w_hh, const float* h_ext,
                                const float* reserve, int B, int S, int Hd, int W, float* scratch, float* dw_ih,
-                               float* dw_hh, float* db_ih, float* db_hh, int* status, void* stream) {
+                               float* dw_hh, float* db_ih, float* db_hh, int* status, void* stream, void* side_stream,
+                               void* side_stream2) {
   if (!dh_all || !x || !w_hh || !h_ext || !reserve || !scratch || !dw_ih || !dw_hh || !db_ih || !db_hh || !status ||
       B <= 0 || S <= 0 || Hd <= 0 || W <= 0)
     return SG_EINVAL;
@@ -817,25 +866,59 @@ extern "C" int stemgnn_gru_bwd(const float* dh_all, const float* x, const float*
   float* p_ih = p_hh + (size_t)GRU_NSPLIT * 3 * Hd * (Hd + 1);
   const int P2 = gru_pick_P2(B, Hd);
   const int P = P2 > 0 ? 0 : gru_pick_P(B, Hd);
+  bool segmented = false;
   GruWide wide;
   if (gru_pick_wide(B, Hd, P2, &wide) > 0) {
     float* xb = scratch + ((((size_t)(p_ih - scratch) + (size_t)GRU_NSPLIT * 3 * Hd * (W + 1)) + 3) & ~(size_t)3);
     SG_TRY(gru_wide_bwd(dh_all, w_hh, h_all, reserve, B, S, Hd, wide, xb, status, dgi, dghn, st));
   } else if (P2 > 0) {
-    gru_u64* xbuf = (gru_u64*)(scratch + ((((size_t)(p_ih - scratch) + (size_t)GRU_NSPLIT * 3 * Hd * (W + 1)) + 1) & ~(size_t)1));
+    // Time segmentation (side streams given): the S steps run as T launches; as soon as a segment's gate gradients are
+    // complete its share of the dW_hh / dW_ih reductions starts on the side streams and overlaps the next segment's
+    // (latency-bound) recurrence, so only the last segment's share is left on the critical path after the recurrence.
+    hipStream_t s1 = (hipStream_t)side_stream, s2 = (hipStream_t)side_stream2;
+    int T = 1;
+    if (s1 && s2 && S >= 64) {
+      static const int env_t = getenv("STEMGNN_GRU_SEGMENTS") ? atoi(getenv("STEMGNN_GRU_SEGMENTS")) : 4;
+      T = env_t == 2 || env_t == 4 || env_t == 8 ? env_t : 1;
+    }
+    hipEvent_t* ev = T > 1 ? gru_events() : nullptr;
+    if (T > 1 && !ev) T = 1;
+    float* xtail = scratch + ((((size_t)(p_ih - scratch) + (size_t)GRU_NSPLIT * 3 * Hd * (W + 1)) + 1) & ~(size_t)1);
+    gru_u64* xbuf = (gru_u64*)xtail;
+    float* carry = xtail + gru_xbuf_floats(B, Hd);
     SG_TRY(hipMemsetAsync(xbuf, 0, (size_t)2 * B * 3 * Hd * sizeof(gru_u64), st));
     const dim3 grid(8 * ((B + 7) / 8) * P2);
+    const int KU2 = gru_pick_KU(Hd, P2);
+    const int nsplit_seg = GRU_NSPLIT / T;
+    for (int seg = 0; seg < T; ++seg) {
+      // segment seg covers steps s_hi .. s_lo (descending in time: the backward pass starts at step S - 1)
+      const int s_hi = S - 1 - (int)((long)S * seg / T), s_lo = S - (int)((long)S * (seg + 1) / T);
 #define GRU_B2K(PP, KK, OO) do { const size_t hog = gru_lds_hog<PP>((const void*)gru_bwd_cluster2_kernel<PP, KK, OO>); \
     hipLaunchKernelGGL((gru_bwd_cluster2_kernel<PP, KK, OO>), grid, dim3(3 * (PP / OO) * 64), hog, st, dh_all, w_hh, h_all, \
-                       reserve, B, S, Hd, xbuf, status, dgi, dghn); } while (0)
+                       reserve, B, S, Hd, xbuf, status, dgi, dghn, s_hi, s_lo, carry); } while (0)
 #define GRU_B2(PP, OO) do { if (KU2 == 32) GRU_B2K(PP, 32, OO); else if (KU2 == 48) GRU_B2K(PP, 48, OO); \
                             else if (KU2 == 58) GRU_B2K(PP, 58, OO); else GRU_B2K(PP, 64, OO); } while (0)
-    const int KU2 = gru_pick_KU(Hd, P2);
-    if (P2 == 1) GRU_B2(1, 1); else if (P2 == 2) GRU_B2(2, 1); else if (P2 == 4) GRU_B2(4, 1);
-    else if (P2 == 5) GRU_B2(5, 1); else if (P2 == 6) GRU_B2(6, 2); else GRU_B2(8, 2);
+      if (P2 == 1) GRU_B2(1, 1); else if (P2 == 2) GRU_B2(2, 1); else if (P2 == 4) GRU_B2(4, 1);
+      else if (P2 == 5) GRU_B2(5, 1); else if (P2 == 6) GRU_B2(6, 2); else GRU_B2(8, 2);
 #undef GRU_B2
 #undef GRU_B2K
-    SG_TRY(hipGetLastError());
+      SG_TRY(hipGetLastError());
+      if (T > 1) {                                   // this segment's rows are final: reduce them on the side streams
+        SG_TRY(hipEventRecord(ev[seg], st));
+        SG_TRY(hipStreamWaitEvent(s1, ev[seg], 0));
+        SG_TRY(hipStreamWaitEvent(s2, ev[seg], 0));
+        const int rc = gru_wgrad_rows(dgi, dghn, h_ext, x, p_hh, p_ih, B, S, Hd, W, s_lo * B, (s_hi - s_lo + 1) * B,
+                                      seg * nsplit_seg, nsplit_seg, s1, s2);
+        if (rc) return rc;
+      }
+    }
+    if (T > 1) {                                     // join both side streams before the fixed-order reduce
+      SG_TRY(hipEventRecord(ev[8], s1));
+      SG_TRY(hipEventRecord(ev[9], s2));
+      SG_TRY(hipStreamWaitEvent(st, ev[8], 0));
+      SG_TRY(hipStreamWaitEvent(st, ev[9], 0));
+    }
+    segmented = T > 1;
   } else if (P > 0) {
     const GruCluster c = gru_cluster_geom(Hd, P);
     gru_u64* xbuf = (gru_u64*)(scratch + ((((size_t)(p_ih - scratch) + (size_t)GRU_NSPLIT * 3 * Hd * (W + 1)) + 1) & ~(size_t)1));
@@ -853,22 +936,10 @@ extern "C" int stemgnn_gru_bwd(const float* dh_all, const float* x, const float*
     hipLaunchKernelGGL(gru_bwd_kernel, dim3(B), dim3(1024), lds, st, dh_all, w_hh, h_all, reserve, B, S, Hd, dgi, dghn);
     SG_TRY(hipGetLastError());
   }
-  const int rows = S * B;
-  const int chunk = ((rows + GRU_NSPLIT - 1) / GRU_NSPLIT + 15) & ~15;
-  {  // dW_hh | db_hh = dgh^T [3Hd x rows] * [h_prev | 1]: rows 0..2Hd-1 of dgh are dgi's r,z gates, rows 2Hd..3Hd-1 = dghn
-     // (two "branches" of one 128x128 MFMA GEMM launch); h_prev of row (s,b) is row (s,b) of h_ext (slab 0 = zeros)
-    G2Args g;
-    G2SlabEpi e;
-    g.A[0] = dgi;  g.lda[0] = 3 * Hd; g.M[0] = 2 * Hd;
-    g.A[1] = dghn; g.lda[1] = Hd;     g.M[1] = Hd;
-    for (int r = 0; r < 2; ++r) { g.B[r] = h_ext; g.ldb[r] = Hd; g.N[r] = Hd + 1; g.K[r] = rows; }
-    g.nsplit = GRU_NSPLIT; g.chunk = chunk; g.b_ones_col = Hd;
-    e.part[0] = p_hh;
-    e.part[1] = p_hh + (size_t)GRU_NSPLIT * 2 * Hd * (Hd + 1);
-    SG_TRY((g2_launch<G2SlabEpi, false, false>(g, e, 2, st)));
+  if (!segmented) {
+    const int rc = gru_wgrad_rows(dgi, dghn, h_ext, x, p_hh, p_ih, B, S, Hd, W, 0, S * B, 0, GRU_NSPLIT, st, st);
+    if (rc) return rc;
   }
-  GruWihGradOp o2{dgi, x, p_ih, B, S, Hd, W, GRU_NSPLIT, chunk};
-  SG_TRY((sg_launch_gemm<GruWihGradOp, 64, 32, false, false, false, 64>(o2, 3 * Hd, W + 1, GRU_NSPLIT, st)));
   {
     const size_t n0 = (size_t)2 * Hd * (Hd + 1);
     GruReduceJobs J;

@@ -17,8 +17,8 @@ _NSPLIT = int(os.environ.get("STEMGNN_NSPLIT", "32"))     # split-M factor of th
 _side_streams = {}
 
 
-def _side_stream(device):
-    key = str(device)
+def _side_stream(device, index=0):
+    key = (str(device), index)
     st = _side_streams.get(key)
     if st is None:
         st = torch.cuda.Stream(device=device)
@@ -210,10 +210,13 @@ class GruFront(torch.autograd.Function):
             dw_ih, dw_hh = torch.empty_like(w_ih), torch.empty_like(w_hh)
             db_ih = torch.empty(3 * Hd, device=dev, dtype=f32)
             db_hh = torch.empty(3 * Hd, device=dev, dtype=f32)
+        # overlap mode: the recurrence runs as time segments whose weight-gradient GEMMs go to two side streams (forked
+        # from and joined back to the current stream inside the call)
+        sides = (_side_stream(dev).cuda_stream, _side_stream(dev, 1).cuda_stream) if ctx.state.overlap else (None, None)
         _lib.check(lib.stemgnn_gru_bwd(dh_all.data_ptr(), x.data_ptr(), w_hh.data_ptr(), h_ext.data_ptr(),
                                        reserve.data_ptr(), B, S, Hd, W, scratch.data_ptr(), dw_ih.data_ptr(),
                                        dw_hh.data_ptr(), db_ih.data_ptr(), db_hh.data_ptr(),
-                                       gru_status(dev).data_ptr(), _stream()), "gru_bwd")
+                                       gru_status(dev).data_ptr(), _stream(), *sides), "gru_bwd")
         ctx.state.join()                # the spectral blocks' weight gradients (side stream) overlapped this recurrence
         if direct:
             return None, None, None, None, None, None

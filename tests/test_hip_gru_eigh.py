@@ -34,6 +34,37 @@ def test_gru_fwd_bwd_vs_torch_cpu(B, S, W, cluster, monkeypatch):
         assert relerr(mine.grad, ref.grad) < TOL
 
 
+@pytest.mark.parametrize("B,S,W", [(32, 228, 12), (9, 358, 12), (3, 140, 12), (2, 64, 5)])
+def test_gru_backward_time_segments_vs_torch_cpu(B, S, W):
+    """Overlap mode: the backward recurrence runs as 4 time segments (one launch each, recurrent dh carried through
+    global memory, granule tags counting on) and each segment's dW_hh / dW_ih reductions run on two side streams under
+    the next segment -- same result as torch's CPU GRU, and bitwise reproducible."""
+    from stemgnn_amd import ops
+    from stemgnn_amd.ops import GruFront, check_gru_status
+
+    torch.manual_seed(S + B)
+    gru = torch.nn.GRU(W, S)
+    x = torch.randn(B, W, S)
+    dh = torch.randn(S, B, S)
+    out, _ = gru(x.permute(2, 0, 1).contiguous())
+    out.backward(dh)
+    ref = (gru.weight_ih_l0, gru.weight_hh_l0, gru.bias_ih_l0, gru.bias_hh_l0)
+    state = ops.HotPathState()
+    state.overlap = True                                   # side streams on: segmentation active (S >= 64)
+    runs = []
+    for _ in range(2):
+        params = [p.detach().clone().cuda().requires_grad_(True) for p in ref]
+        h = GruFront.apply(x.cuda(), *params, state)
+        h.backward(dh.cuda())
+        torch.cuda.synchronize()
+        runs.append([p.grad.clone() for p in params])
+    check_gru_status(torch.device("cuda:0"))
+    assert relerr(h, out.detach()) < TOL
+    for mine, again, r in zip(runs[0], runs[1], ref):
+        assert relerr(mine, r.grad) < TOL
+        assert torch.equal(mine, again)
+
+
 @pytest.mark.parametrize("B,S,W,force", [(8, 1024, 12, False), (16, 2048, 48, False), (5, 100, 7, True), (3, 228, 12, True),
                                           (20, 600, 12, False), (2, 1500, 4, False), (16, 513, 3, False)])
 def test_wide_cluster_gru_vs_torch_cpu(B, S, W, force, monkeypatch):
@@ -77,12 +108,12 @@ def _laplacian(N, B=6, seed=0):
     return O.laplacian_from_attention(att)[0]
 
 
-@pytest.mark.parametrize("N", [228, 33, 64, 140])
+@pytest.mark.parametrize("N", [228, 33, 64, 140, 1024, 2048])
 def test_eigh_stage_reproduces_chebyshev_basis(N):
     from stemgnn_amd import _lib
 
     lib = _lib.load()
-    L = _laplacian(N)
+    L = _laplacian(N, B=6 if N <= 256 else 2)
     mul_L = torch.zeros(4, N, N, device="cuda")
     mul_L[1] = L.cuda()
     lam = torch.empty(N, device="cuda")
@@ -119,6 +150,32 @@ def test_model_eig_route_matches_oracle(monkeypatch):
     for k, p in model.named_parameters():
         if o_grads[k] is not None:
             assert relerr(p.grad, o_grads[k]) < TOL, k
+
+
+def test_model_eig_route_train_mode_with_dropout(monkeypatch):
+    """The eigen route in TRAIN mode with the kernels' own Philox dropout: same seed -> the eig and the Chebyshev
+    routes see the same mask, so forecast, attention and every gradient must agree (the basis is the same function of
+    L; the backward is the polynomial one either way) -- and the Chebyshev route is pinned to the oracle with the
+    exported mask by test_train_mode_dropout_matches_oracle_with_exported_mask."""
+    from stemgnn_amd import Model
+
+    N, W, multi, H, B = 60, 12, 5, 3, 8
+    sd = O.det_state_dict(N, W, multi, H, seed=9)
+    torch.manual_seed(6)
+    x, y = torch.randn(B, W, N).cuda(), torch.randn(B, H, N).cuda()
+    res = {}
+    for route in ("cheb", "eig"):
+        monkeypatch.setenv("STEMGNN_SPECTRAL", route)
+        model = Model(N, 2, W, multi, horizon=H, dropout_rate=0.5)
+        model.load_state_dict(sd)
+        model.cuda().train()
+        model.set_dropout_seed(1234, 7)
+        forecast, att = model(x)
+        torch.nn.functional.mse_loss(forecast, y).backward()
+        res[route] = (forecast.detach(), att.detach(), {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None})
+    assert relerr(res["eig"][0], res["cheb"][0]) < TOL and relerr(res["eig"][1], res["cheb"][1]) < TOL
+    for k, g in res["cheb"][2].items():
+        assert relerr(res["eig"][2][k], g) < TOL, k
 
 
 def test_miopen_gru_switch_gives_same_result(monkeypatch):
