@@ -82,13 +82,20 @@ int stemgnn_cheb_fwd(float* mul_L, int N, void* stream);
 int stemgnn_cheb_bwd(const float* mul_L, const float* dmul_L, float* dL, float* scratch, int N, void* stream);
 
 /* ---- Laplacian eigendecomposition route (north-star; same function of L as stemgnn_cheb_fwd) --------
- * Symmetric N x N eigensolver L = U^T diag(lam) U: parallel one-sided Jacobi (one launch per tournament
- * round, fp64 rotation parameters), one Newton-Schulz re-orthogonalisation on MFMA, Rayleigh-quotient
- * eigenvalues; then slot k := sum_e p_k(lam_e) u_e u_e^T for k = 2,3 with p = (2 l^2, 4 l^3 - l)
- * (slot 0 = zeros and slot 1 = L are left as attn_laplacian_fwd wrote them).
- * lam [N]; U [N,N] with the eigenvectors in ROWS; scratch: stemgnn_eigh_scratch_floats(N); nsweeps ~ 9. */
+ * Symmetric N x N eigensolver L = U^T diag(lam) U, then slot k := sum_e p_k(lam_e) u_e u_e^T for k = 2,3 with
+ * p = (2 l^2, 4 l^3 - l) (slot 0 = zeros and slot 1 = L are left as attn_laplacian_fwd wrote them).
+ *   nsweeps <= 0 : direct solver, 7 launches, 3 <= N <= 2048: Householder tridiagonalisation as ONE persistent cluster
+ *                  kernel (pending rank-2 update fused with the next symmetric mat-vec, one grid barrier per column) ->
+ *                  fp64 multisection (Sturm counts, 16 lanes per eigenvalue) -> fp64 inverse iteration (pivoted
+ *                  tridiagonal LU) -> reflector back-transform -> rebuild on the MFMA GEMM core;
+ *   nsweeps  > 0 : parallel one-sided Jacobi (one launch per tournament round, fp64 rotation parameters), one
+ *                  Newton-Schulz re-orthogonalisation and Rayleigh quotients on MFMA.
+ * lam [N] (ascending for the direct solver); U [N,N] with the eigenvectors in ROWS; scratch:
+ * stemgnn_eigh_scratch_floats(N) (16-byte aligned).  stemgnn_eigh_status(): host-synchronous read of the solver's
+ * device status word (0 ok, 2 = a grid-barrier wait of the tridiagonalisation timed out). */
 size_t stemgnn_eigh_scratch_floats(int N);
 int stemgnn_eigh_fwd(float* mul_L, float* lam, float* U, float* scratch, int N, int nsweeps, void* stream);
+int stemgnn_eigh_status(void);
 
 /* ---- GRU front (models/base_model.py:92,137: nn.GRU(time_step, units) over the node axis) ------------
  * seq_len S (= N nodes), batch B, input size W, hidden size Hd (= N).  PyTorch gate order (r,z,n).

@@ -131,12 +131,403 @@ struct EigRebuildOp {
   __device__ void epi(int z, int i, int j, float v) const { mulL[(size_t)(z + 2) * N * N + (size_t)i * N + j] = v; }
 };
 
-extern "C" size_t stemgnn_eigh_scratch_floats(int N) { return (size_t)3 * N * N; }
+// =================================================================================================
+// Direct solver (default):  L = Q T Q^T (Householder)  ->  T = Z diag(lam) Z^T  ->  U = (Q Z)^T rows.
+//
+//   1. eig_tridiag_kernel     ONE persistent launch.  G workgroups own the rows of the trailing matrix cyclically
+//      (G = 1 for N <= 320).  Per column step every workgroup forms the Householder vector itself from the pivot row
+//      (published by its owner through a write-through row buffer) and makes ONE fused pass over its own rows:
+//      apply the PENDING rank-2 update of the previous step, then the symmetric mat-vec p = tau A v of this step --
+//      each row is read and written once per step, and a step costs one grid barrier (monotonic counter, data
+//      exchanged through sc1 stores / loads: no fences).  v / w / the pivot row live in LDS.
+//   2. eig_bisect_kernel      eigenvalues of T by 17-way multisection of Sturm counts in fp64, 16 lanes per
+//      eigenvalue (12 rounds -> 1e-15 of the Gershgorin width).
+//   3. eig_invit_kernel       eigenvectors of T by inverse iteration in fp64 (pivoted LU of T - lam I as in LAPACK
+//      gttrf/gtts2, three solves, first one started behind the forward substitution), one thread per eigenvalue,
+//      work arrays laid out [row][eigenvalue] (coalesced).  In fp64 the vectors of this spectrum (N - 1 eigenvalues
+//      packed into [0.99, 1.01], gaps down to 1e-11) come out orthogonal to ~1e-12 with no re-orthogonalisation.
+//   4. eig_backtransform_kernel   U = Z^T H_{N-3} ... H_0, 16 eigenvectors per workgroup in registers, each reflector
+//      staged once per workgroup in LDS.
+//   5. the spectral basis is rebuilt on the MFMA GEMM core as before (EigRebuildOp).
+// =================================================================================================
+__device__ __forceinline__ float et_ld(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void et_st(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float et_wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+// fixed-order block sum (16 waves); every thread gets the result.  Contains two barriers.
+__device__ __forceinline__ float et_block_sum(float v, float* red, int tid) {
+  v = et_wave_sum(v);
+  __syncthreads();
+  if ((tid & 63) == 0) red[tid >> 6] = v;
+  __syncthreads();
+  float s = 0.f;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) s += red[w];
+  return s;
+}
+
+// A [N,N] (destroyed), V [N,N]: row k = Householder vector of step k (zeros up to k, 1 at k+1), dvec / evec / tauv [N],
+// pbuf / prow [2][N] exchange vectors (two parities), counter: grid barrier word (zeroed before the launch)
+__global__ __launch_bounds__(1024) void eig_tridiag_kernel(float* __restrict__ A, int N, int G, float* __restrict__ V,
+                                                           float* __restrict__ dvec, float* __restrict__ evec,
+                                                           float* __restrict__ tauv, float* __restrict__ pbuf,
+                                                           float* __restrict__ prow, unsigned* __restrict__ counter,
+                                                           int* __restrict__ status) {
+  extern __shared__ __attribute__((aligned(16))) float et_sm[];
+  float* vprev = et_sm;
+  float* wprev = et_sm + N;
+  float* vcur = et_sm + 2 * N;
+  float* red = et_sm + 3 * N;
+  const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float tau_prev = 0.f;
+  for (int k = 0; k < N; ++k) {
+    // 1. w_{k-1} = p - (tau/2 (p.v)) v   (p = tau A v of the previous step, gathered from all workgroups)
+    if (k > 0) {
+      float part = 0.f;
+      const float* pb = pbuf + (size_t)((k - 1) & 1) * N;
+      for (int j = k + tid; j < N; j += 1024) {
+        const float pj = et_ld(pb + j);
+        wprev[j] = pj;
+        part += pj * vprev[j];
+      }
+      const float alpha = 0.5f * tau_prev * et_block_sum(part, red, tid);
+      for (int j = k + tid; j < N; j += 1024) wprev[j] -= alpha * vprev[j];
+      __syncthreads();
+    }
+    // 2. pivot row k with the pending update applied -> d_k, Householder vector v_k (LAPACK larfg convention)
+    const float vk = k > 0 ? vprev[k] : 0.f, wk = k > 0 ? wprev[k] : 0.f;
+    float part = 0.f;
+    {
+      const float* src = k == 0 ? A : prow + (size_t)(k & 1) * N;
+      for (int j = k + tid; j < N; j += 1024) {
+        float a = k == 0 ? src[j] : et_ld(src + j);
+        if (k > 0) a -= vk * wprev[j] + wk * vprev[j];
+        vcur[j] = a;
+        if (j > k + 1) part += a * a;
+      }
+    }
+    const float sigma = et_block_sum(part, red, tid);       // (barriers inside: vcur is visible)
+    const float rk = vcur[k], r1 = k + 1 < N ? vcur[k + 1] : 0.f;
+    float tau = 0.f, beta = r1, scale = 0.f;
+    if (k < N - 2 && sigma > 0.f) {
+      beta = -copysignf(sqrtf(r1 * r1 + sigma), r1);
+      tau = (beta - r1) / beta;
+      scale = 1.f / (r1 - beta);
+    }
+    __syncthreads();
+    for (int j = k + tid; j < N; j += 1024) vcur[j] = j <= k ? 0.f : (j == k + 1 ? 1.f : vcur[j] * scale);
+    if (g == 0 && tid == 0) {
+      dvec[k] = rk;
+      if (k + 1 < N) evec[k] = beta;
+      tauv[k] = tau;
+    }
+    __syncthreads();
+    if (g == 0)
+      for (int j = tid; j < N; j += 1024) V[(size_t)k * N + j] = j <= k ? 0.f : vcur[j];
+    // 3. fused pass over the own rows i > k: pending update, then p_i = tau * (row_i . v_k)
+    {
+      const int first = k + 1 + (((g - (k + 1)) % G) + G) % G;      // smallest own row > k
+      float* pk = pbuf + (size_t)(k & 1) * N;
+      float* pr = prow + (size_t)((k + 1) & 1) * N;
+      for (int i = first + G * wave; i < N; i += G * 16) {
+        const float vi = k > 0 ? vprev[i] : 0.f, wi = k > 0 ? wprev[i] : 0.f;
+        float* row = A + (size_t)i * N;
+        float dot = 0.f;
+        for (int j = k + 1 + lane; j < N; j += 64) {
+          float a = row[j];
+          if (k > 0) {
+            a -= vi * wprev[j] + wi * vprev[j];
+            row[j] = a;
+          }
+          if (i == k + 1) et_st(pr + j, a);                          // next pivot row: write-through copy for everybody
+          dot += a * vcur[j];
+        }
+        dot = et_wave_sum(dot);
+        if (lane == 0) et_st(pk + i, tau * dot);
+      }
+    }
+    // 4. grid barrier: every p entry and the next pivot row are published
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (G > 1) {
+      if (tid == 0) {
+        __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned target = (unsigned)G * (unsigned)(k + 1);
+        unsigned spins = 0;
+        while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+          __builtin_amdgcn_s_sleep(2);
+          if (++spins > (1u << 24)) { atomicExch(status, 2); break; }
+        }
+      }
+      __syncthreads();
+    }
+    tau_prev = tau;
+    float* t = vprev; vprev = vcur; vcur = t;
+  }
+}
+
+// eigenvalue j (ascending) of the symmetric tridiagonal (dvec, evec) by multisection: lane m of the 16-lane group
+// counts the eigenvalues below x_m = lo + (m + 1) w / 17 with the Sturm recurrence q_i = d_i - x - e_{i-1}^2 / q_{i-1}.
+// aux[0] := a norm of T (perturbation scale of the inverse iteration).
+__global__ __launch_bounds__(256) void eig_bisect_kernel(const float* __restrict__ dvec, const float* __restrict__ evec,
+                                                         int N, double* __restrict__ lam64, float* __restrict__ lam32,
+                                                         double* __restrict__ aux) {
+  const int gid = blockIdx.x * 256 + threadIdx.x;
+  const int j = gid >> 4, m = gid & 15, lane = threadIdx.x & 63;
+  const int jj = j < N ? j : N - 1;
+  double lo = 1e300, hi = -1e300, emax = 0.0;
+  for (int i = 0; i < N; ++i) {
+    const double r = (i > 0 ? fabs((double)evec[i - 1]) : 0.0) + (i + 1 < N ? fabs((double)evec[i]) : 0.0);
+    const double di = dvec[i];
+    lo = fmin(lo, di - r);
+    hi = fmax(hi, di + r);
+    emax = fmax(emax, r);
+  }
+  const double tnorm = fmax(fabs(lo), fabs(hi));
+  const double pivmin = 1e-290 * fmax(1.0, emax * emax);
+  lo -= 1e-12 * tnorm + 1e-300;
+  hi += 1e-12 * tnorm + 1e-300;
+  for (int it = 0; it < 13; ++it) {
+    const double w = hi - lo;
+    const double x = lo + w * (double)(m + 1) * (1.0 / 17.0);
+    double q = (double)dvec[0] - x;
+    int cnt = q < 0.0;
+    for (int i = 1; i < N; ++i) {
+      const double e = evec[i - 1];
+      if (fabs(q) < pivmin) q = -pivmin;
+      q = (double)dvec[i] - x - e * e / q;
+      cnt += q < 0.0;
+    }
+    const bool le = cnt <= jj;                                  // fewer than j + 1 eigenvalues below x_m: lam_j >= x_m
+    const unsigned long long b = __ballot(le);
+    const unsigned grp = (unsigned)(b >> (lane & 48)) & 0xffffu;
+    const int ms = __builtin_ctz(~grp | 0x10000u);              // points at or below lam_j (monotone prefix)
+    const double nlo = ms == 0 ? lo : lo + w * (double)ms * (1.0 / 17.0);
+    const double nhi = ms == 16 ? hi : lo + w * (double)(ms + 1) * (1.0 / 17.0);
+    lo = nlo;
+    hi = nhi;
+  }
+  if (m == 0 && j < N) {
+    const double l = 0.5 * (lo + hi);
+    lam64[j] = l;
+    lam32[j] = (float)l;
+  }
+  if (gid == 0) aux[0] = tnorm;
+}
+
+// inverse iteration, one thread per eigenvalue.  work: FL | RD | DU | DU2 | X, each [N][N] doubles indexed [row][eig];
+// then the pivot flags [N][N] bytes.  Z [eig][row] fp32 (unit 2-norm rows).
+__global__ __launch_bounds__(64) void eig_invit_kernel(const float* __restrict__ dvec, const float* __restrict__ evec,
+                                                       const double* __restrict__ lam64, const double* __restrict__ aux,
+                                                       int N, double* __restrict__ work, float* __restrict__ Z) {
+  const int j = blockIdx.x * 64 + threadIdx.x;
+  if (j >= N) return;
+  const size_t NN = (size_t)N * N;
+  double* FL = work + j;
+  double* RD = work + NN + j;
+  double* DU = work + 2 * NN + j;
+  double* DU2 = work + 3 * NN + j;
+  double* X = work + 4 * NN + j;
+  unsigned char* PV = reinterpret_cast<unsigned char*>(work + 5 * NN) + j;
+  const double lam = lam64[j];
+  const double eps3 = 2.3e-16 * fmax(aux[0], 1e-300);
+  // pivoted LU of T - lam I (LAPACK gttrf): row i is finished when row i + 1 has been looked at
+  double dcur = (double)dvec[0] - lam, ducur = N > 1 ? (double)evec[0] : 0.0;
+  for (int i = 0; i + 1 < N; ++i) {
+    const double dl = evec[i], dnext = (double)dvec[i + 1] - lam, dunext = i + 2 < N ? (double)evec[i + 1] : 0.0;
+    const bool swap = fabs(dcur) < fabs(dl);
+    double piv = swap ? dl : dcur;
+    if (piv == 0.0) piv = eps3;
+    const double rpiv = 1.0 / piv;
+    const double fact = (swap ? dcur : dl) * rpiv;
+    FL[(size_t)i * N] = fact;
+    RD[(size_t)i * N] = rpiv;
+    DU[(size_t)i * N] = swap ? dnext : ducur;
+    DU2[(size_t)i * N] = swap ? dunext : 0.0;
+    PV[(size_t)i * N] = swap ? 1 : 0;
+    const double nd = swap ? ducur - fact * dnext : dnext - fact * ducur;
+    const double ndu = swap ? -fact * dunext : dunext;
+    dcur = nd;
+    ducur = ndu;
+  }
+  if (fabs(dcur) < eps3) dcur = dcur < 0.0 ? -eps3 : eps3;
+  RD[(size_t)(N - 1) * N] = 1.0 / dcur;
+  DU[(size_t)(N - 1) * N] = 0.0;
+  DU2[(size_t)(N - 1) * N] = 0.0;
+  double scale = 1.0;
+  for (int iter = 0; iter < 3; ++iter) {
+    if (iter > 0) {      // forward substitution  L y = P (scale * x)
+      double carry = X[0] * scale;
+      for (int i = 0; i + 1 < N; ++i) {
+        const double bn = X[(size_t)(i + 1) * N] * scale, f = FL[(size_t)i * N];
+        const bool swap = PV[(size_t)i * N] != 0;
+        const double out = swap ? bn : carry;
+        carry = swap ? carry - f * bn : bn - f * carry;
+        X[(size_t)i * N] = out;
+      }
+      X[(size_t)(N - 1) * N] = carry;
+    }
+    // back substitution  U x = y   (first iteration: y = ones, i.e. the start vector is P^T L * ones)
+    double x1 = 0.0, x2 = 0.0, amax = 0.0;
+    for (int i = N - 1; i >= 0; --i) {
+      const double b = iter > 0 ? X[(size_t)i * N] : 1.0;
+      const double xi = (b - DU[(size_t)i * N] * x1 - DU2[(size_t)i * N] * x2) * RD[(size_t)i * N];
+      X[(size_t)i * N] = xi;
+      x2 = x1;
+      x1 = xi;
+      amax = fmax(amax, fabs(xi));
+    }
+    scale = amax > 0.0 ? 1.0 / amax : 1.0;                       // applied lazily by the next pass
+  }
+  double nrm = 0.0;
+  for (int i = 0; i < N; ++i) {
+    const double xi = X[(size_t)i * N] * scale;
+    nrm += xi * xi;
+  }
+  const double inv = scale / sqrt(nrm);
+  float* z = Z + (size_t)j * N;
+  for (int i = 0; i < N; ++i) z[i] = (float)(X[(size_t)i * N] * inv);
+}
+
+// U[e][:] = H_0 H_1 ... H_{N-3} z_e : reflectors applied from the last to the first.  Workgroup = 4 waves x JW = 4
+// eigenvectors held in registers (NC chunks of 64 entries per lane); each reflector is staged once per workgroup in LDS
+// (double buffered: one barrier per reflector).
+template <int NC>
+__global__ __launch_bounds__(256) void eig_backtransform_kernel(const float* __restrict__ Z, const float* __restrict__ V,
+                                                                const float* __restrict__ tauv, int N,
+                                                                float* __restrict__ U) {
+  constexpr int JW = 4;
+  extern __shared__ __attribute__((aligned(16))) float bt_sm[];      // 2 x NP, NP = 64 * NC (zero padded beyond N:
+  constexpr int NP = 64 * NC;                                         // every lane reads its NC entries unconditionally)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int e0 = (blockIdx.x * 4 + wave) * JW;
+  float z[JW][NC];
+#pragma unroll
+  for (int q = 0; q < JW; ++q)
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const int i = lane + 64 * c, e = e0 + q;
+      z[q][c] = (e < N && i < N) ? Z[(size_t)e * N + i] : 0.f;
+    }
+  const int klast = N - 3;
+  for (int i = tid; i < 2 * NP; i += 256) bt_sm[i] = 0.f;
+  __syncthreads();
+  if (klast >= 0)
+    for (int i = tid; i < N; i += 256) bt_sm[(klast & 1) * NP + i] = V[(size_t)klast * N + i];
+  __syncthreads();
+  for (int k = klast; k >= 0; --k) {
+    if (k > 0)                                                        // stage the next reflector in the other buffer
+      for (int i = tid; i < N; i += 256) bt_sm[((k - 1) & 1) * NP + i] = V[(size_t)(k - 1) * N + i];
+    const float* v = bt_sm + (k & 1) * NP;
+    const float tau = tauv[k];
+    float vr[NC];                                                     // (v is stored with zeros up to index k)
+#pragma unroll
+    for (int c = 0; c < NC; ++c) vr[c] = v[lane + 64 * c];
+#pragma unroll
+    for (int q = 0; q < JW; ++q) {
+      float dot = 0.f;
+#pragma unroll
+      for (int c = 0; c < NC; ++c) dot += vr[c] * z[q][c];
+      dot = tau * et_wave_sum(dot);
+#pragma unroll
+      for (int c = 0; c < NC; ++c) z[q][c] -= dot * vr[c];
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int q = 0; q < JW; ++q)
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const int i = lane + 64 * c, e = e0 + q;
+      if (e < N && i < N) U[(size_t)e * N + i] = z[q][c];
+    }
+}
+
+static inline size_t eig_direct_floats(int N) {
+  const size_t nn = (size_t)N * N;
+  // A | V | Z | small vectors (d, e, tau, pbuf[2], prow[2], lam32: 8N) | counter + pad | fp64: lam64[N] + aux[8] | work 5 NN | flags
+  return 3 * nn + 8 * (size_t)N + 64 + 2 * ((size_t)N + 8) + 2 * 5 * nn + (nn + 3) / 4 + 16;
+}
+extern "C" size_t stemgnn_eigh_scratch_floats(int N) {
+  const size_t a = (size_t)3 * N * N, b = eig_direct_floats(N);
+  return a > b ? a : b;
+}
+
+static int eig_direct(float* mul_L, float* lam, float* U, float* scratch, int N, int* status, hipStream_t st) {
+  const size_t nn = (size_t)N * N;
+  float* L = mul_L + nn;
+  float* A = scratch;
+  float* V = A + nn;
+  float* Z = V + nn;
+  float* dvec = Z + nn;
+  float* evec = dvec + N;
+  float* tauv = evec + N;
+  float* pbuf = tauv + N;
+  float* prow = pbuf + 2 * (size_t)N;
+  unsigned* counter = (unsigned*)(prow + 2 * (size_t)N + ((size_t)N & 1 ? 1 : 0));
+  double* lam64 = (double*)(scratch + ((3 * nn + 8 * (size_t)N + 64 + 1) & ~(size_t)1));
+  double* aux = lam64 + N;
+  double* work = aux + 8;
+  SG_TRY(hipMemcpyAsync(A, L, nn * sizeof(float), hipMemcpyDeviceToDevice, st));
+  SG_TRY(hipMemsetAsync(counter, 0, 16 * sizeof(unsigned), st));
+  int G = 1;
+  if (N > 320) { G = N / 16; if (G > 128) G = 128; }
+  const size_t lds = (size_t)(3 * N + 32) * sizeof(float);
+  if (lds > 150 * 1024) return SG_EINVAL;
+  static bool attr = false;
+  if (!attr) {
+    SG_TRY(hipFuncSetAttribute((const void*)eig_tridiag_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    attr = true;
+  }
+  hipLaunchKernelGGL(eig_tridiag_kernel, dim3(G), dim3(1024), lds, st, A, N, G, V, dvec, evec, tauv, pbuf, prow, counter, status);
+  SG_TRY(hipGetLastError());
+  hipLaunchKernelGGL(eig_bisect_kernel, dim3((unsigned)(((size_t)N * 16 + 255) / 256)), dim3(256), 0, st, dvec, evec, N, lam64,
+                     lam, aux);
+  SG_TRY(hipGetLastError());
+  hipLaunchKernelGGL(eig_invit_kernel, dim3((N + 63) / 64), dim3(64), 0, st, dvec, evec, lam64, aux, N, work, Z);
+  SG_TRY(hipGetLastError());
+  const dim3 bgrid((N + 15) / 16);
+  if (N <= 256) hipLaunchKernelGGL(eig_backtransform_kernel<4>, bgrid, dim3(256), 2 * 64 * 4 * sizeof(float), st, Z, V, tauv, N, U);
+  else if (N <= 1024) hipLaunchKernelGGL(eig_backtransform_kernel<16>, bgrid, dim3(256), 2 * 64 * 16 * sizeof(float), st, Z, V, tauv, N, U);
+  else if (N <= 2048) hipLaunchKernelGGL(eig_backtransform_kernel<32>, bgrid, dim3(256), 2 * 64 * 32 * sizeof(float), st, Z, V, tauv, N, U);
+  else return SG_EINVAL;
+  SG_TRY(hipGetLastError());
+  EigRebuildOp rb{U, lam, mul_L, N};
+  SG_TRY((sg_launch_gemm<EigRebuildOp, 64, 64, false, false, false>(rb, N, N, 2, st)));
+  return 0;
+}
+
+
+static int* eig_status_word() {      // device int set to 2 if a grid-barrier spin of the tridiagonalisation timed out
+  static int* w = nullptr;
+  if (!w) {
+    if (hipMalloc((void**)&w, sizeof(int)) != hipSuccess) return nullptr;
+    (void)hipMemset(w, 0, sizeof(int));
+  }
+  return w;
+}
+extern "C" int stemgnn_eigh_status(void) {
+  int* w = eig_status_word();
+  int v = -1;
+  if (!w || hipMemcpy(&v, w, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  return v;
+}
 
 extern "C" int stemgnn_eigh_fwd(float* mul_L, float* lam, float* U, float* scratch, int N, int nsweeps,
                                 void* stream) {
-  if (!mul_L || !lam || !U || !scratch || N <= 0 || nsweeps <= 0 || nsweeps > 64) return SG_EINVAL;
+  if (!mul_L || !lam || !U || !scratch || N <= 0 || nsweeps > 64) return SG_EINVAL;
   hipStream_t st = (hipStream_t)stream;
+  // nsweeps <= 0 (default): direct solver (Householder + multisection + inverse iteration, 7 launches);
+  // nsweeps  > 0: the one-sided Jacobi solver of round 1 with that many sweeps (one launch per tournament round)
+  if (nsweeps <= 0) {
+    if (N < 3 || N > 2048) return SG_EINVAL;
+    int* status = eig_status_word();
+    if (!status) return SG_EINVAL;
+    return eig_direct(mul_L, lam, U, scratch, N, status, st);
+  }
   const size_t nn = (size_t)N * N;
   float* L = mul_L + nn;
   float* Bt = scratch;

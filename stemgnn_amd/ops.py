@@ -157,6 +157,13 @@ def gru_status(device):
     return t
 
 
+def check_eigh_status():
+    """Host sync + raise if a grid-barrier wait of the direct eigensolver timed out (STEMGNN_SPECTRAL=eig only)."""
+    rc = _lib.load().stemgnn_eigh_status()
+    if rc != 0:
+        raise _lib.StemGNNHipError(f"eigensolver status {rc}: a workgroup of the tridiagonalisation cluster was not resident")
+
+
 def check_gru_status(device):
     """Host sync + raise if a GRU exchange timed out (call outside timed regions / in tests)."""
     if int(gru_status(device).item()) != 0:
@@ -437,7 +444,7 @@ class SpectralHotPath(torch.autograd.Function):
             U = torch.empty(N, N, device=dev, dtype=f32)
             escr = torch.empty(lib.stemgnn_eigh_scratch_floats(N), device=dev, dtype=f32)
             _lib.check(lib.stemgnn_eigh_fwd(mul_L.data_ptr(), lam.data_ptr(), U.data_ptr(), escr.data_ptr(), N,
-                                            int(os.environ.get("STEMGNN_EIG_SWEEPS", "9")), st), "eigh_fwd")
+                                            int(os.environ.get("STEMGNN_EIG_SWEEPS", "0")), st), "eigh_fwd")
         else:
             _lib.check(lib.stemgnn_cheb_fwd(mul_L.data_ptr(), N, st), "cheb_fwd")
 

@@ -108,9 +108,13 @@ def _laplacian(N, B=6, seed=0):
     return O.laplacian_from_attention(att)[0]
 
 
-@pytest.mark.parametrize("N", [228, 33, 64, 140, 1024, 2048])
-def test_eigh_stage_reproduces_chebyshev_basis(N):
-    from stemgnn_amd import _lib
+@pytest.mark.parametrize("N,sweeps", [(228, 0), (33, 0), (64, 0), (140, 0), (5, 0), (321, 0), (1024, 0), (2048, 0),
+                                      (228, 9), (33, 9), (64, 9), (140, 9)])
+def test_eigh_stage_reproduces_chebyshev_basis(N, sweeps):
+    """stemgnn_eigh_fwd at the sizes of every BASELINE config: sweeps = 0 is the direct solver (Householder cluster
+    kernel -> fp64 multisection -> fp64 inverse iteration -> back-transform; N = 321 / 1024 / 2048 use several
+    workgroups with the grid barrier), sweeps = 9 the one-sided Jacobi of round 1."""
+    from stemgnn_amd import _lib, ops
 
     lib = _lib.load()
     L = _laplacian(N, B=6 if N <= 256 else 2)
@@ -120,8 +124,9 @@ def test_eigh_stage_reproduces_chebyshev_basis(N):
     U = torch.empty(N, N, device="cuda")
     scratch = torch.empty(lib.stemgnn_eigh_scratch_floats(N), device="cuda")
     st = torch.cuda.current_stream().cuda_stream
-    assert lib.stemgnn_eigh_fwd(mul_L.data_ptr(), lam.data_ptr(), U.data_ptr(), scratch.data_ptr(), N, 9, st) == 0
+    assert lib.stemgnn_eigh_fwd(mul_L.data_ptr(), lam.data_ptr(), U.data_ptr(), scratch.data_ptr(), N, sweeps, st) == 0
     torch.cuda.synchronize()
+    ops.check_eigh_status()
     ref = O.cheb_polynomial(L.double())
     assert relerr(mul_L[2], ref[2]) < TOL and relerr(mul_L[3], ref[3]) < TOL
     assert torch.equal(mul_L[1].cpu(), L) and float(mul_L[0].abs().max()) == 0.0

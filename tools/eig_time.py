@@ -1,0 +1,44 @@
+"""Time the spectral-basis stage: Chebyshev route (stemgnn_cheb_fwd) vs the eigensolver route (direct solver, and the
+round-1 Jacobi at N = 228), per phase through rocprof-free HIP events around the whole call."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from stemgnn_amd import _lib, ops
+
+lib = _lib.load()
+dev = torch.device("cuda")
+st = torch.cuda.current_stream().cuda_stream
+for N in (228, 358, 1024, 2048):
+    g = torch.Generator().manual_seed(N)
+    A = torch.rand(N, N, generator=g) * (2.0 / N)
+    A = 0.5 * (A + A.T)
+    d = A.sum(1)
+    L = (torch.diag(d) - A) / torch.sqrt(d)[:, None] / torch.sqrt(d)[None, :]
+    mul_L = torch.zeros(4, N, N, device=dev)
+    mul_L[1] = L.to(dev)
+    lam = torch.empty(N, device=dev)
+    U = torch.empty(N, N, device=dev)
+    scratch = torch.empty(lib.stemgnn_eigh_scratch_floats(N), device=dev)
+
+    def timed(fn, n):
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record()
+        e1.synchronize()
+        return e0.elapsed_time(e1) / n * 1e3
+
+    t_cheb = timed(lambda: _lib.check(lib.stemgnn_cheb_fwd(mul_L.data_ptr(), N, st), "cheb"), 20)
+    ref = mul_L.clone()
+    t_dir = timed(lambda: _lib.check(lib.stemgnn_eigh_fwd(mul_L.data_ptr(), lam.data_ptr(), U.data_ptr(), scratch.data_ptr(), N, 0, st), "eig"), 3)
+    ops.check_eigh_status()
+    err = float((mul_L[3] - ref[3]).abs().max() / ref[3].abs().max())
+    line = f"N={N}: cheb {t_cheb:9.1f} us | eig direct {t_dir:10.1f} us (T3 vs cheb {err:.1e})"
+    if N <= 358:
+        t_jac = timed(lambda: _lib.check(lib.stemgnn_eigh_fwd(mul_L.data_ptr(), lam.data_ptr(), U.data_ptr(), scratch.data_ptr(), N, 9, st), "eig"), 2)
+        line += f" | eig jacobi(9 sweeps) {t_jac:10.1f} us"
+    print(line, flush=True)
