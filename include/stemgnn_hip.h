@@ -97,6 +97,17 @@ size_t stemgnn_eigh_scratch_floats(int N);
 int stemgnn_eigh_fwd(float* mul_L, float* lam, float* U, float* scratch, int N, int nsweeps, void* stream);
 int stemgnn_eigh_status(void);
 
+/* ---- split-bf16 GLU GEMM (experiment; BASELINE configs[1] "bf16/fp32", SURVEY 8b `_bf16` entry points) -----------
+ * C[M,N] = A[M,K] B[N,K]^T -- the shape of one GLU layer (models/base_model.py:12-13, x W^T) -- with every fp32 operand
+ * taken as the sum of `splits` bf16 numbers and the cross products evaluated on the bf16 MFMA pipe with fp32
+ * accumulation: splits = 3 -> 6 products (~2^-24 relative, fp32 class), 2 -> 3 products (~2^-16), 1 -> plain bf16.
+ * B is pre-split by stemgnn_split_weights_bf16 into `planes` (stemgnn_split_planes_floats floats, 16-byte aligned);
+ * A is split on the fly.  K % 4 == 0.  stemgnn_glu_gemm_f32 is the same product on the exact-fp32 MFMA core. */
+size_t stemgnn_split_planes_floats(int N, int K, int splits);
+int stemgnn_split_weights_bf16(const float* B, int N, int K, int splits, void* planes, void* stream);
+int stemgnn_glu_gemm_bf16(const float* A, const void* planes, float* C, int M, int N, int K, int splits, void* stream);
+int stemgnn_glu_gemm_f32(const float* A, const float* B, float* C, int M, int N, int K, void* stream);
+
 /* ---- GRU front (models/base_model.py:92,137: nn.GRU(time_step, units) over the node axis) ------------
  * seq_len S (= N nodes), batch B, input size W, hidden size Hd (= N).  PyTorch gate order (r,z,n).
  * x [B,W,S] is the model input read in place (x_s[b,t] = x[b,t,s]); w_ih [3Hd,W], w_hh [3Hd,Hd],

@@ -197,15 +197,35 @@ def spe_seq_cell(gfted, sd, prefix):
     """
     B, k, _, N, W = gfted.shape
     x = gfted.reshape(B, -1, N, W)                        # :48
-    ff = torch.fft.fft(x, dim=-1)                         # :49
-    real = ff.real.permute(0, 2, 1, 3).reshape(B, N, -1)  # :50  column = k*W + f
-    img = ff.imag.permute(0, 2, 1, 3).reshape(B, N, -1)   # :51
+    on_dev = x.is_cuda     # device evaluation of the yardstick (largest parity cases): the two transforms as explicit DFT
+    if on_dev:             # matrices instead of library FFT plans (rocFFT compiles kernels at run time: minutes on a fresh box)
+        t = torch.arange(W, dtype=x.dtype, device=x.device)
+        ang = 2.0 * math.pi * torch.outer(t, t) / W
+        ff_real, ff_imag = x @ torch.cos(ang), -(x @ torch.sin(ang))
+    else:
+        ff = torch.fft.fft(x, dim=-1)                     # :49
+        ff_real, ff_imag = ff.real, ff.imag
+    real = ff_real.permute(0, 2, 1, 3).reshape(B, N, -1)  # :50  column = k*W + f
+    img = ff_imag.permute(0, 2, 1, 3).reshape(B, N, -1)   # :51
     for i in range(3):                                    # :52-54
         real = glu(real, sd, prefix + f"GLUs.{2 * i}.")
         img = glu(img, sd, prefix + f"GLUs.{2 * i + 1}.")
     real = real.reshape(B, N, 4, -1).permute(0, 2, 1, 3)  # :55
     img = img.reshape(B, N, 4, -1).permute(0, 2, 1, 3)    # :56
     n = real.shape[-1]
+    if on_dev:             # C2R of bins 0..n/2 written out: y = (1/n) [sum c_f Re cos - sum s_f Im sin]
+        h = n // 2
+        f = torch.arange(h + 1, dtype=x.dtype, device=x.device)
+        tau = torch.arange(n, dtype=x.dtype, device=x.device)
+        ang = 2.0 * math.pi * torch.outer(f, tau) / n
+        c = torch.full((h + 1,), 2.0, dtype=x.dtype, device=x.device)
+        c[0] = 1.0
+        sfac = c.clone()
+        sfac[0] = 0.0
+        if n % 2 == 0:
+            c[h] = 1.0
+            sfac[h] = 0.0
+        return (real[..., : h + 1] @ (c[:, None] * torch.cos(ang)) - img[..., : h + 1] @ (sfac[:, None] * torch.sin(ang))) / n
     z = torch.complex(real, img)[..., : n // 2 + 1]       # :57
     return torch.fft.irfft(z, n=n, dim=-1)                # :58
 

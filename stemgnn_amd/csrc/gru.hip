@@ -878,7 +878,10 @@ extern "C" int stemgnn_gru_bwd(const float* dh_all, const float* x, const float*
     hipStream_t s1 = (hipStream_t)side_stream, s2 = (hipStream_t)side_stream2;
     int T = 1;
     if (s1 && s2 && S >= 64) {
-      static const int env_t = getenv("STEMGNN_GRU_SEGMENTS") ? atoi(getenv("STEMGNN_GRU_SEGMENTS")) : 4;
+      // measured on MI355X (profiles/r02_gru_segments.md): every extra launch of the recurrence costs more than the
+      // overlap returns -- the LDS-reserving cluster kernel has to wait for the side streams' GEMM workgroups to drain
+      // from its CUs (+15-20 us per boundary, +30 us per segment) -- so segmentation is OFF by default
+      static const int env_t = getenv("STEMGNN_GRU_SEGMENTS") ? atoi(getenv("STEMGNN_GRU_SEGMENTS")) : 1;
       T = env_t == 2 || env_t == 4 || env_t == 8 ? env_t : 1;
     }
     hipEvent_t* ev = T > 1 ? gru_events() : nullptr;
@@ -937,8 +940,21 @@ extern "C" int stemgnn_gru_bwd(const float* dh_all, const float* x, const float*
     SG_TRY(hipGetLastError());
   }
   if (!segmented) {
-    const int rc = gru_wgrad_rows(dgi, dghn, h_ext, x, p_hh, p_ih, B, S, Hd, W, 0, S * B, 0, GRU_NSPLIT, st, st);
+    // the two reductions are independent: with a side stream the small dW_ih product runs beside the dW_hh GEMM
+    hipStream_t s2 = (hipStream_t)side_stream2;
+    hipEvent_t* ev = s2 ? gru_events() : nullptr;
+    static const bool tail_par = !(getenv("STEMGNN_GRU_TAIL_PAR") && atoi(getenv("STEMGNN_GRU_TAIL_PAR")) == 0);
+    if (ev && tail_par) {
+      SG_TRY(hipEventRecord(ev[10], st));
+      SG_TRY(hipStreamWaitEvent(s2, ev[10], 0));
+    }
+    const int rc = gru_wgrad_rows(dgi, dghn, h_ext, x, p_hh, p_ih, B, S, Hd, W, 0, S * B, 0, GRU_NSPLIT, st,
+                                  ev && tail_par ? s2 : st);
     if (rc) return rc;
+    if (ev && tail_par) {
+      SG_TRY(hipEventRecord(ev[11], s2));
+      SG_TRY(hipStreamWaitEvent(st, ev[11], 0));
+    }
   }
   {
     const size_t n0 = (size_t)2 * Hd * (Hd + 1);

@@ -1,5 +1,7 @@
 """GPU parity of the two stages added around the spectral blocks: the persistent-kernel GRU front
 (reference nn.GRU, models/base_model.py:92,137) and the Laplacian eigensolver route (north-star a-4)."""
+import os
+
 import pytest
 import torch
 
@@ -35,7 +37,7 @@ def test_gru_fwd_bwd_vs_torch_cpu(B, S, W, cluster, monkeypatch):
 
 
 @pytest.mark.parametrize("B,S,W", [(32, 228, 12), (9, 358, 12), (3, 140, 12), (2, 64, 5)])
-def test_gru_backward_time_segments_vs_torch_cpu(B, S, W):
+def test_gru_backward_time_segments_vs_torch_cpu(B, S, W, monkeypatch):
     """Overlap mode: the backward recurrence runs as 4 time segments (one launch each, recurrent dh carried through
     global memory, granule tags counting on) and each segment's dW_hh / dW_ih reductions run on two side streams under
     the next segment -- same result as torch's CPU GRU, and bitwise reproducible."""
@@ -49,6 +51,13 @@ def test_gru_backward_time_segments_vs_torch_cpu(B, S, W):
     out, _ = gru(x.permute(2, 0, 1).contiguous())
     out.backward(dh)
     ref = (gru.weight_ih_l0, gru.weight_hh_l0, gru.bias_ih_l0, gru.bias_hh_l0)
+    import subprocess, sys
+    if os.environ.get("STEMGNN_GRU_SEGMENTS") != "4":      # the library reads the switch once per process: re-run this
+        env = dict(os.environ, STEMGNN_GRU_SEGMENTS="4")    # test in a child process with segmentation switched on
+        r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", f"{__file__}::test_gru_backward_time_segments_vs_torch_cpu[{B}-{S}-{W}]"],
+                           env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        return
     state = ops.HotPathState()
     state.overlap = True                                   # side streams on: segmentation active (S >= 64)
     runs = []
