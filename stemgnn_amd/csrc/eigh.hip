@@ -11,6 +11,7 @@
 //   slot k := V^T-form  sum_e p_k(lam_e) v_e v_e^T,   p = (0, l, 2 l^2, 4 l^3 - l)  (T0 = zeros, :129)
 // which is the same function of L as stemgnn_cheb_fwd (checked to ~3e-6 in tests).
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 
 #include "../../include/stemgnn_hip.h"
 #include "gemm_core.h"
@@ -236,14 +237,28 @@ __global__ __launch_bounds__(1024) void eig_tridiag_kernel(float* __restrict__ A
         const float vi = k > 0 ? vprev[i] : 0.f, wi = k > 0 ? wprev[i] : 0.f;
         float* row = A + (size_t)i * N;
         float dot = 0.f;
-        for (int j = k + 1 + lane; j < N; j += 64) {
-          float a = row[j];
-          if (k > 0) {
-            a -= vi * wprev[j] + wi * vprev[j];
-            row[j] = a;
+        // 8 row segments of 64 floats per round: all loads of a round are issued before the first use (the
+        // load -> update -> store chain of one segment would otherwise serialise on the L2 round trip)
+        for (int j0 = k + 1 + lane; j0 < N; j0 += 8 * 64) {
+          float a[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int j = j0 + 64 * u;
+            a[u] = row[j < N ? j : N - 1];
           }
-          if (i == k + 1) et_st(pr + j, a);                          // next pivot row: write-through copy for everybody
-          dot += a * vcur[j];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int j = j0 + 64 * u;
+            if (j < N) {
+              float x = a[u];
+              if (k > 0) {
+                x -= vi * wprev[j] + wi * vprev[j];
+                row[j] = x;
+              }
+              if (i == k + 1) et_st(pr + j, x);                      // next pivot row: write-through copy for everybody
+              dot += x * vcur[j];
+            }
+          }
         }
         dot = et_wave_sum(dot);
         if (lane == 0) et_st(pk + i, tau * dot);
@@ -266,6 +281,103 @@ __global__ __launch_bounds__(1024) void eig_tridiag_kernel(float* __restrict__ A
     }
     tau_prev = tau;
     float* t = vprev; vprev = vcur; vcur = t;
+  }
+}
+
+// N <= 256: ONE workgroup, the matrix never leaves the registers.  Wave w owns rows w, w + 16, ... (16 row slots x 4
+// column chunks of 64 = 64 registers per lane); p, the pivot row, v and w live in LDS; same algorithm as above (pending
+// update fused with the symmetric mat-vec), ~8 workgroup barriers per column and no global traffic inside the loop.
+__global__ __launch_bounds__(1024) void eig_tridiag_small_kernel(const float* __restrict__ A, int N, float* __restrict__ V,
+                                                                 float* __restrict__ dvec, float* __restrict__ evec,
+                                                                 float* __restrict__ tauv) {
+  __shared__ float vbuf[2][256], wprev[256], pvec[256], prow[256], red[16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float a[16][4];
+#pragma unroll
+  for (int r = 0; r < 16; ++r)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int i = wave + 16 * r, j = lane + 64 * c;
+      a[r][c] = (i < N && j < N) ? A[(size_t)i * N + j] : 0.f;
+    }
+  for (int j = tid; j < 256; j += 1024) {
+    vbuf[0][j] = 0.f; vbuf[1][j] = 0.f; wprev[j] = 0.f; pvec[j] = 0.f;
+    prow[j] = j < N ? A[j] : 0.f;                                     // pivot row of step 0 = row 0
+  }
+  __syncthreads();
+  float tau_prev = 0.f;
+  for (int k = 0; k < N; ++k) {
+    float* vprev = vbuf[(k + 1) & 1];
+    float* vcur = vbuf[k & 1];
+    if (k > 0) {                                                      // w_{k-1} = p - (tau/2 (p.v)) v
+      float part = 0.f;
+      if (tid < 256) part = (tid >= k && tid < N) ? pvec[tid] * vprev[tid] : 0.f;
+      const float alpha = 0.5f * tau_prev * et_block_sum(part, red, tid);
+      if (tid < 256) wprev[tid] = (tid >= k && tid < N) ? pvec[tid] - alpha * vprev[tid] : 0.f;
+      __syncthreads();
+    }
+    // pivot row k (published by its owner in the previous pass, pending update still to be applied)
+    float rj = 0.f, part = 0.f;
+    if (tid < 256) {
+      const float vk = k > 0 ? vprev[k] : 0.f, wk = k > 0 ? wprev[k] : 0.f;
+      if (tid >= k && tid < N) {
+        rj = prow[tid];
+        if (k > 0) rj -= vk * wprev[tid] + wk * vprev[tid];
+        if (tid > k + 1) part = rj * rj;
+      }
+    }
+    const float sigma = et_block_sum(part, red, tid);
+    if (tid < 256) vcur[tid] = rj;
+    __syncthreads();
+    const float rk = vcur[k], r1 = k + 1 < N ? vcur[k + 1] : 0.f;
+    float tau = 0.f, beta = r1, scale = 0.f;
+    if (k < N - 2 && sigma > 0.f) {
+      beta = -copysignf(sqrtf(r1 * r1 + sigma), r1);
+      tau = (beta - r1) / beta;
+      scale = 1.f / (r1 - beta);
+    }
+    __syncthreads();
+    if (tid < 256) {
+      const float v = tid <= k || tid >= N ? 0.f : (tid == k + 1 ? 1.f : rj * scale);
+      vcur[tid] = v;
+      if (tid < N) V[(size_t)k * N + tid] = v;
+    }
+    if (tid == 0) {
+      dvec[k] = rk;
+      if (k + 1 < N) evec[k] = beta;
+      tauv[k] = tau;
+    }
+    __syncthreads();
+    // fused pass over the own rows i > k (register resident)
+    float vc[4], vp[4], wp[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int j = lane + 64 * c;
+      vc[c] = j > k ? vcur[j] : 0.f;                                  // (entries at or beyond N are zero)
+      vp[c] = vprev[j];
+      wp[c] = wprev[j];
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int i = wave + 16 * r;
+      if (i > k && i < N) {                                           // wave-uniform
+        const float vi = vprev[i], wi = wprev[i];
+        float dot = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          if (k > 0) a[r][c] -= vi * wp[c] + wi * vp[c];
+          dot += a[r][c] * vc[c];
+        }
+        if (i == k + 1) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) prow[lane + 64 * c] = a[r][c];
+        }
+        dot = et_wave_sum(dot);
+        if (lane == 0) pvec[i] = tau * dot;
+      }
+    }
+    __syncthreads();
+    tau_prev = tau;
   }
 }
 
@@ -357,39 +469,85 @@ __global__ __launch_bounds__(64) void eig_invit_kernel(const float* __restrict__
   RD[(size_t)(N - 1) * N] = 1.0 / dcur;
   DU[(size_t)(N - 1) * N] = 0.0;
   DU2[(size_t)(N - 1) * N] = 0.0;
+  // The three passes below are recurrences over the rows with every operand in global memory ([row][eigenvalue]
+  // arrays).  Rows are taken in blocks of IB: all operands of a block are loaded first (independent loads, one memory
+  // round trip per block), then the dependent arithmetic runs from registers, then the block's results are stored.
+  constexpr int IB = 8;
   double scale = 1.0;
   for (int iter = 0; iter < 3; ++iter) {
-    if (iter > 0) {      // forward substitution  L y = P (scale * x)
+    if (iter > 0) {      // forward substitution  L y = P (scale * x), in place
       double carry = X[0] * scale;
-      for (int i = 0; i + 1 < N; ++i) {
-        const double bn = X[(size_t)(i + 1) * N] * scale, f = FL[(size_t)i * N];
-        const bool swap = PV[(size_t)i * N] != 0;
-        const double out = swap ? bn : carry;
-        carry = swap ? carry - f * bn : bn - f * carry;
-        X[(size_t)i * N] = out;
+      for (int i0 = 0; i0 + 1 < N; i0 += IB) {
+        double bn[IB], f[IB], out[IB];
+        bool sw[IB];
+#pragma unroll
+        for (int u = 0; u < IB; ++u) {
+          const int i = i0 + u < N - 1 ? i0 + u : N - 2;
+          bn[u] = X[(size_t)(i + 1) * N];
+          f[u] = FL[(size_t)i * N];
+          sw[u] = PV[(size_t)i * N] != 0;
+        }
+#pragma unroll
+        for (int u = 0; u < IB; ++u) {
+          if (i0 + u < N - 1) {
+            const double b1 = bn[u] * scale;
+            out[u] = sw[u] ? b1 : carry;
+            carry = sw[u] ? carry - f[u] * b1 : b1 - f[u] * carry;
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < IB; ++u)
+          if (i0 + u < N - 1) X[(size_t)(i0 + u) * N] = out[u];
       }
       X[(size_t)(N - 1) * N] = carry;
     }
     // back substitution  U x = y   (first iteration: y = ones, i.e. the start vector is P^T L * ones)
     double x1 = 0.0, x2 = 0.0, amax = 0.0;
-    for (int i = N - 1; i >= 0; --i) {
-      const double b = iter > 0 ? X[(size_t)i * N] : 1.0;
-      const double xi = (b - DU[(size_t)i * N] * x1 - DU2[(size_t)i * N] * x2) * RD[(size_t)i * N];
-      X[(size_t)i * N] = xi;
-      x2 = x1;
-      x1 = xi;
-      amax = fmax(amax, fabs(xi));
+    for (int i0 = N - 1; i0 >= 0; i0 -= IB) {
+      double b[IB], du[IB], du2[IB], rd[IB], xo[IB];
+#pragma unroll
+      for (int u = 0; u < IB; ++u) {
+        const int i = i0 - u >= 0 ? i0 - u : 0;
+        b[u] = iter > 0 ? X[(size_t)i * N] : 1.0;
+        du[u] = DU[(size_t)i * N];
+        du2[u] = DU2[(size_t)i * N];
+        rd[u] = RD[(size_t)i * N];
+      }
+#pragma unroll
+      for (int u = 0; u < IB; ++u) {
+        if (i0 - u >= 0) {
+          const double xi = (b[u] - du[u] * x1 - du2[u] * x2) * rd[u];
+          xo[u] = xi;
+          x2 = x1;
+          x1 = xi;
+          amax = fmax(amax, fabs(xi));
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < IB; ++u)
+        if (i0 - u >= 0) X[(size_t)(i0 - u) * N] = xo[u];
     }
     scale = amax > 0.0 ? 1.0 / amax : 1.0;                       // applied lazily by the next pass
   }
   double nrm = 0.0;
-  for (int i = 0; i < N; ++i) {
-    const double xi = X[(size_t)i * N] * scale;
-    nrm += xi * xi;
+  for (int i0 = 0; i0 < N; i0 += IB) {
+    double xv[IB];
+#pragma unroll
+    for (int u = 0; u < IB; ++u) xv[u] = X[(size_t)(i0 + u < N ? i0 + u : N - 1) * N];
+#pragma unroll
+    for (int u = 0; u < IB; ++u)
+      if (i0 + u < N) nrm += (xv[u] * scale) * (xv[u] * scale);
   }
   const double inv = scale / sqrt(nrm);
   float* z = Z + (size_t)j * N;
-  for (int i = 0; i < N; ++i) z[i] = (float)(X[(size_t)i * N] * inv);
+  for (int i0 = 0; i0 < N; i0 += IB) {
+    double xv[IB];
+#pragma unroll
+    for (int u = 0; u < IB; ++u) xv[u] = X[(size_t)(i0 + u < N ? i0 + u : N - 1) * N];
+#pragma unroll
+    for (int u = 0; u < IB; ++u)
+      if (i0 + u < N) z[i0 + u] = (float)(xv[u] * inv);
+  }
 }
 
 // U[e][:] = H_0 H_1 ... H_{N-3} z_e : reflectors applied from the last to the first.  Workgroup = 4 waves x JW = 4
@@ -482,7 +640,11 @@ static int eig_direct(float* mul_L, float* lam, float* U, float* scratch, int N,
     SG_TRY(hipFuncSetAttribute((const void*)eig_tridiag_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     attr = true;
   }
-  hipLaunchKernelGGL(eig_tridiag_kernel, dim3(G), dim3(1024), lds, st, A, N, G, V, dvec, evec, tauv, pbuf, prow, counter, status);
+  static const bool small_on = !(getenv("STEMGNN_EIG_SMALL") && atoi(getenv("STEMGNN_EIG_SMALL")) == 0);
+  if (N <= 256 && small_on)     // register-resident single-workgroup kernel (reads L directly, no working copy)
+    hipLaunchKernelGGL(eig_tridiag_small_kernel, dim3(1), dim3(1024), 0, st, L, N, V, dvec, evec, tauv);
+  else
+    hipLaunchKernelGGL(eig_tridiag_kernel, dim3(G), dim3(1024), lds, st, A, N, G, V, dvec, evec, tauv, pbuf, prow, counter, status);
   SG_TRY(hipGetLastError());
   hipLaunchKernelGGL(eig_bisect_kernel, dim3((unsigned)(((size_t)N * 16 + 255) / 256)), dim3(256), 0, st, dvec, evec, N, lam64,
                      lam, aux);

@@ -832,7 +832,9 @@ static int gru_wgrad_rows(const float* dgi, const float* dghn, const float* h_ex
     g.nsplit = nsplit; g.chunk = chunk; g.b_ones_col = Hd;
     e.part[0] = p_hh + (size_t)slab0 * 2 * Hd * (Hd + 1);
     e.part[1] = p_hh + (size_t)GRU_NSPLIT * 2 * Hd * (Hd + 1) + (size_t)slab0 * Hd * (Hd + 1);
-    SG_TRY((g2_launch<G2SlabEpi, false, false>(g, e, 2, st_hh)));
+    static const bool bm64 = getenv("STEMGNN_GRU_WG_BM64") && atoi(getenv("STEMGNN_GRU_WG_BM64")) == 1;
+    if (bm64) SG_TRY((g2_launch<G2SlabEpi, false, false, 64>(g, e, 2, st_hh)));
+    else SG_TRY((g2_launch<G2SlabEpi, false, false>(g, e, 2, st_hh)));
   }
   GruWihGradOp o2{dgi, x, p_ih + (size_t)slab0 * 3 * Hd * (W + 1), B, S, Hd, W, nsplit, chunk, row0, rows};
   SG_TRY((sg_launch_gemm<GruWihGradOp, 64, 32, false, false, false, 64>(o2, 3 * Hd, W + 1, nsplit, st_ih)));
@@ -943,7 +945,7 @@ extern "C" int stemgnn_gru_bwd(const float* dh_all, const float* x, const float*
     // the two reductions are independent: with a side stream the small dW_ih product runs beside the dW_hh GEMM
     hipStream_t s2 = (hipStream_t)side_stream2;
     hipEvent_t* ev = s2 ? gru_events() : nullptr;
-    static const bool tail_par = !(getenv("STEMGNN_GRU_TAIL_PAR") && atoi(getenv("STEMGNN_GRU_TAIL_PAR")) == 0);
+    static const bool tail_par = getenv("STEMGNN_GRU_TAIL_PAR") && atoi(getenv("STEMGNN_GRU_TAIL_PAR")) == 1;   // measured: no gain
     if (ev && tail_par) {
       SG_TRY(hipEventRecord(ev[10], st));
       SG_TRY(hipStreamWaitEvent(s2, ev[10], 0));
