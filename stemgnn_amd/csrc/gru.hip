@@ -518,7 +518,8 @@ __global__ __launch_bounds__(3 * (P / OW) * 64) void gru_bwd_cluster2_kernel(con
                                                                       const float* __restrict__ reserve, int B, int S, int Hd,
                                                                       gru_u64* __restrict__ xbuf, int* __restrict__ status,
                                                                       float* __restrict__ dgi, float* __restrict__ dghn,
-                                                                      int s_hi, int s_lo, float* __restrict__ carry) {
+                                                                      int s_hi, int s_lo, float* __restrict__ carry,
+                                                                      int s_mark, unsigned* __restrict__ progress) {
   // Steps s_hi .. s_lo (descending) of the backward recurrence: the host may cut the S steps into time segments (one
   // launch each) so the weight-gradient GEMMs of a finished segment overlap the recurrence of the next.  `carry`
   // [B][Hd] hands the recurrent part of dh (dh * z + W_hh^T dgh) from one segment to the next; granule tags keep
@@ -600,6 +601,19 @@ __global__ __launch_bounds__(3 * (P / OW) * 64) void gru_bwd_cluster2_kernel(con
       part[tag & 1][g * P + q0 + o][lane] = gru_matvec<KU>(wr[o], dv);
     }
     __syncthreads();
+    if (s == s_mark) {
+      // progress mark: every gate-gradient row of the steps >= s_mark is written.  Publish them to kernels of OTHER
+      // streams while this one keeps running: drain, write the XCD's dirty L2 lines back (agent-scope release), count.
+      // A spin kernel on the side stream waits for all workgroups, then the weight-gradient GEMMs of those rows start
+      // under the rest of the recurrence (stemgnn_gru_bwd).
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_fetch_add(progress, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
   }
   if (s_lo > 0 && tid < un) {                             // hand the recurrent part of dh_{s_lo - 1} to the next segment
     const unsigned tag = (unsigned)(S - s_lo);
@@ -753,7 +767,7 @@ extern "C" size_t stemgnn_gru_fwd_scratch_floats(int B, int S, int Hd) {
 }
 extern "C" size_t stemgnn_gru_bwd_scratch_floats(int B, int S, int Hd, int W) {
   return (size_t)4 * S * B * Hd + (size_t)GRU_NSPLIT * 3 * Hd * (Hd + 1) + (size_t)GRU_NSPLIT * 3 * Hd * (W + 1) +
-         gru_xbuf_floats(B, Hd) + 4 + (size_t)B * Hd;     // ... | exchange | carry (time segments)
+         gru_xbuf_floats(B, Hd) + 4 + (size_t)B * Hd + 8;     // ... | exchange | carry (time segments) | progress
 }
 
 extern "C" int stemgnn_gru_fwd(const float* x, const float* w_ih, const float* w_hh, const float* b_ih,
@@ -840,6 +854,15 @@ static int gru_wgrad_rows(const float* dgi, const float* dghn, const float* h_ex
   SG_TRY((sg_launch_gemm<GruWihGradOp, 64, 32, false, false, false, 64>(o2, 3 * Hd, W + 1, nsplit, st_ih)));
   return 0;
 }
+// one wave that returns when `progress` has reached `want` (bounded): the stream it is launched on resumes then
+__global__ void gru_wait_progress_kernel(const unsigned* __restrict__ progress, unsigned want, int* __restrict__ status) {
+  if (threadIdx.x != 0) return;
+  unsigned spins = 0;
+  while (__hip_atomic_load(progress, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+    __builtin_amdgcn_s_sleep(32);
+    if (++spins > (1u << 24)) { atomicExch(status, 3); break; }
+  }
+}
 // events for the fork / join between the recurrence stream and the weight-gradient side streams (created once per
 // process; record / wait are stream-ordered and capturable: inside a hipGraph capture they become dependency edges)
 static hipEvent_t* gru_events() {
@@ -891,7 +914,26 @@ extern "C" int stemgnn_gru_bwd(const float* dh_all, const float* x, const float*
     float* xtail = scratch + ((((size_t)(p_ih - scratch) + (size_t)GRU_NSPLIT * 3 * Hd * (W + 1)) + 1) & ~(size_t)1);
     gru_u64* xbuf = (gru_u64*)xtail;
     float* carry = xtail + gru_xbuf_floats(B, Hd);
+    unsigned* progress = (unsigned*)(carry + (size_t)B * Hd);
     SG_TRY(hipMemsetAsync(xbuf, 0, (size_t)2 * B * 3 * Hd * sizeof(gru_u64), st));
+    // Early weight gradients (single launch of the recurrence): when every workgroup has passed step s_mark the rows of
+    // the steps >= s_mark are final; a spin kernel on side stream 1 waits for that mark and the dW_hh / dW_ih reductions
+    // of those rows run there under the REST of the recurrence -- only the rows below the mark are left for afterwards.
+    // The mark sits at 30 % of the steps: in the train step the side stream is busy with block weight gradients until
+    // ~70 % of the recurrence has run (profiles/r02_step_timeline.txt).
+    int s_mark = -1;
+    if (T == 1 && s1 && s2 && S >= 64) {
+      static const int env_m = getenv("STEMGNN_GRU_MARK") ? atoi(getenv("STEMGNN_GRU_MARK")) : 30;
+      if (env_m > 0 && env_m < 100) s_mark = (int)((long)S * env_m / 100);
+      if (s_mark < 1) s_mark = -1;
+    }
+    if (s_mark > 0 && !ev) ev = gru_events();
+    if (s_mark > 0 && !ev) s_mark = -1;
+    if (s_mark > 0) {
+      SG_TRY(hipMemsetAsync(progress, 0, 4 * sizeof(unsigned), st));
+      SG_TRY(hipEventRecord(ev[10], st));                       // fork: the side stream may start waiting for the mark
+      SG_TRY(hipStreamWaitEvent(s1, ev[10], 0));
+    }
     const dim3 grid(8 * ((B + 7) / 8) * P2);
     const int KU2 = gru_pick_KU(Hd, P2);
     const int nsplit_seg = GRU_NSPLIT / T;
@@ -900,7 +942,7 @@ extern "C" int stemgnn_gru_bwd(const float* dh_all, const float* x, const float*
       const int s_hi = S - 1 - (int)((long)S * seg / T), s_lo = S - (int)((long)S * (seg + 1) / T);
 #define GRU_B2K(PP, KK, OO) do { const size_t hog = gru_lds_hog<PP>((const void*)gru_bwd_cluster2_kernel<PP, KK, OO>); \
     hipLaunchKernelGGL((gru_bwd_cluster2_kernel<PP, KK, OO>), grid, dim3(3 * (PP / OO) * 64), hog, st, dh_all, w_hh, h_all, \
-                       reserve, B, S, Hd, xbuf, status, dgi, dghn, s_hi, s_lo, carry); } while (0)
+                       reserve, B, S, Hd, xbuf, status, dgi, dghn, s_hi, s_lo, carry, s_mark, progress); } while (0)
 #define GRU_B2(PP, OO) do { if (KU2 == 32) GRU_B2K(PP, 32, OO); else if (KU2 == 48) GRU_B2K(PP, 48, OO); \
                             else if (KU2 == 58) GRU_B2K(PP, 58, OO); else GRU_B2K(PP, 64, OO); } while (0)
       if (P2 == 1) GRU_B2(1, 1); else if (P2 == 2) GRU_B2(2, 1); else if (P2 == 4) GRU_B2(4, 1);
@@ -917,13 +959,26 @@ extern "C" int stemgnn_gru_bwd(const float* dh_all, const float* x, const float*
         if (rc) return rc;
       }
     }
-    if (T > 1) {                                     // join both side streams before the fixed-order reduce
+    if (s_mark > 0) {
+      int n_early = (int)((long)GRU_NSPLIT * (S - s_mark) / S);
+      if (n_early < 1) n_early = 1;
+      if (n_early > GRU_NSPLIT - 1) n_early = GRU_NSPLIT - 1;
+      hipLaunchKernelGGL(gru_wait_progress_kernel, dim3(1), dim3(64), 0, s1, progress, (unsigned)(B * P2), status);
+      SG_TRY(hipGetLastError());
+      SG_TRY(hipEventRecord(ev[11], s1));
+      SG_TRY(hipStreamWaitEvent(s2, ev[11], 0));
+      int rc = gru_wgrad_rows(dgi, dghn, h_ext, x, p_hh, p_ih, B, S, Hd, W, s_mark * B, (S - s_mark) * B, 0, n_early, s1, s2);
+      if (rc) return rc;
+      rc = gru_wgrad_rows(dgi, dghn, h_ext, x, p_hh, p_ih, B, S, Hd, W, 0, s_mark * B, n_early, GRU_NSPLIT - n_early, st, st);
+      if (rc) return rc;
+    }
+    if (T > 1 || s_mark > 0) {                       // join both side streams before the fixed-order reduce
       SG_TRY(hipEventRecord(ev[8], s1));
       SG_TRY(hipEventRecord(ev[9], s2));
       SG_TRY(hipStreamWaitEvent(st, ev[8], 0));
       SG_TRY(hipStreamWaitEvent(st, ev[9], 0));
     }
-    segmented = T > 1;
+    segmented = T > 1 || s_mark > 0;
   } else if (P > 0) {
     const GruCluster c = gru_cluster_geom(Hd, P);
     gru_u64* xbuf = (gru_u64*)(scratch + ((((size_t)(p_ih - scratch) + (size_t)GRU_NSPLIT * 3 * Hd * (W + 1)) + 1) & ~(size_t)1));

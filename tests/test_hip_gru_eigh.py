@@ -36,11 +36,16 @@ def test_gru_fwd_bwd_vs_torch_cpu(B, S, W, cluster, monkeypatch):
         assert relerr(mine.grad, ref.grad) < TOL
 
 
+@pytest.mark.parametrize("mode", ["mark", "segments"])
 @pytest.mark.parametrize("B,S,W", [(32, 228, 12), (9, 358, 12), (3, 140, 12), (2, 64, 5)])
-def test_gru_backward_time_segments_vs_torch_cpu(B, S, W, monkeypatch):
-    """Overlap mode: the backward recurrence runs as 4 time segments (one launch each, recurrent dh carried through
-    global memory, granule tags counting on) and each segment's dW_hh / dW_ih reductions run on two side streams under
-    the next segment -- same result as torch's CPU GRU, and bitwise reproducible."""
+def test_gru_backward_time_segments_vs_torch_cpu(B, S, W, mode):
+    """Overlap mode (side streams given) of the GRU backward, both schedules against torch's CPU GRU + bitwise
+    reproducibility:
+      mark      (default) one launch; when every workgroup has passed the progress mark (30 % of the steps) a spin kernel
+                releases the dW_hh / dW_ih reductions of the finished rows on the side streams, under the rest of the
+                recurrence;
+      segments  STEMGNN_GRU_SEGMENTS=4: four launches with the recurrent dh carried through global memory (measured
+                slower, kept switchable)."""
     from stemgnn_amd import ops
     from stemgnn_amd.ops import GruFront, check_gru_status
 
@@ -52,9 +57,9 @@ def test_gru_backward_time_segments_vs_torch_cpu(B, S, W, monkeypatch):
     out.backward(dh)
     ref = (gru.weight_ih_l0, gru.weight_hh_l0, gru.bias_ih_l0, gru.bias_hh_l0)
     import subprocess, sys
-    if os.environ.get("STEMGNN_GRU_SEGMENTS") != "4":      # the library reads the switch once per process: re-run this
-        env = dict(os.environ, STEMGNN_GRU_SEGMENTS="4")    # test in a child process with segmentation switched on
-        r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", f"{__file__}::test_gru_backward_time_segments_vs_torch_cpu[{B}-{S}-{W}]"],
+    if mode == "segments" and os.environ.get("STEMGNN_GRU_SEGMENTS") != "4":   # the library reads the switch once per
+        env = dict(os.environ, STEMGNN_GRU_SEGMENTS="4")    # process: re-run this test in a child with segmentation on
+        r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", f"{__file__}::test_gru_backward_time_segments_vs_torch_cpu[{B}-{S}-{W}-segments]"],
                            env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
         return
