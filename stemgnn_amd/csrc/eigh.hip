@@ -153,10 +153,24 @@ struct EigRebuildOp {
 // =================================================================================================
 __device__ __forceinline__ float et_ld(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void et_st(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// wave64 sum on the VALU: four DPP butterflies inside each row of 16 lanes (quad swaps, half-row mirror, row mirror),
+// then the four row sums are read with v_readlane.  ~10 instructions and no LDS round trips -- the ds_bpermute
+// butterfly (6 dependent LDS-crossbar hops) was the whole cost of the tridiagonalisation's per-row dot products.
+// All 64 lanes must be active; every lane gets the result.
+template <int CTRL>
+__device__ __forceinline__ float et_dpp(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
 __device__ __forceinline__ float et_wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  v += et_dpp<0xB1>(v);      // quad_perm [1,0,3,2]
+  v += et_dpp<0x4E>(v);      // quad_perm [2,3,0,1]
+  v += et_dpp<0x141>(v);     // row_half_mirror
+  v += et_dpp<0x140>(v);     // row_mirror
+  const float a = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
+  const float b = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16));
+  const float c = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32));
+  const float d = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
+  return (a + b) + (c + d);
 }
 // fixed-order block sum (16 waves); every thread gets the result.  Contains two barriers.
 __device__ __forceinline__ float et_block_sum(float v, float* red, int tid) {
@@ -402,7 +416,51 @@ __global__ __launch_bounds__(256) void eig_bisect_kernel(const float* __restrict
   const double pivmin = 1e-290 * fmax(1.0, emax * emax);
   lo -= 1e-12 * tnorm + 1e-300;
   hi += 1e-12 * tnorm + 1e-300;
-  for (int it = 0; it < 13; ++it) {
+  // Head in fp32 (division ~10x cheaper than fp64): 5 rounds narrow the bracket to ~7e-7 of the width.  An fp32 Sturm
+  // count is the exact count of a matrix perturbed by a few 1e-7 |T|, so the bracket is widened by 1e-5 |T| and then
+  // VERIFIED with two fp64 counts; if it does not hold the eigenvalue the full-width fp64 multisection runs instead.
+  int rounds64 = 13;
+  {
+    const double glo = lo, ghi = hi;
+    float flo = (float)lo, fhi = (float)hi;
+    const float fpiv = 1e-30f;
+    for (int it = 0; it < 5; ++it) {
+      const float w = fhi - flo;
+      const float x = flo + w * (float)(m + 1) * (1.0f / 17.0f);
+      float q = dvec[0] - x;
+      int cnt = q < 0.f;
+      for (int i = 1; i < N; ++i) {
+        const float e = evec[i - 1];
+        if (fabsf(q) < fpiv) q = -fpiv;
+        q = dvec[i] - x - e * e / q;
+        cnt += q < 0.f;
+      }
+      const unsigned long long b = __ballot(cnt <= jj);
+      const unsigned grp = (unsigned)(b >> (lane & 48)) & 0xffffu;
+      const int ms = __builtin_ctz(~grp | 0x10000u);
+      const float nlo = ms == 0 ? flo : flo + w * (float)ms * (1.0f / 17.0f);
+      const float nhi = ms == 16 ? fhi : flo + w * (float)(ms + 1) * (1.0f / 17.0f);
+      flo = nlo;
+      fhi = nhi;
+    }
+    const double margin = 1e-5 * tnorm + 1e-300;
+    const double clo = fmax(glo, (double)flo - margin), chi = fmin(ghi, (double)fhi + margin);
+    // verification: even lanes count below clo, odd lanes below chi
+    const double x = (m & 1) ? chi : clo;
+    double q = (double)dvec[0] - x;
+    int cnt = q < 0.0;
+    for (int i = 1; i < N; ++i) {
+      const double e = evec[i - 1];
+      if (fabs(q) < pivmin) q = -pivmin;
+      q = (double)dvec[i] - x - e * e / q;
+      cnt += q < 0.0;
+    }
+    const bool good = (m & 1) ? (cnt > jj || chi >= ghi) : (cnt <= jj);
+    const unsigned long long b = __ballot(good);
+    const unsigned grp = (unsigned)(b >> (lane & 48)) & 0xffffu;
+    if (grp == 0xffffu) { lo = clo; hi = chi; rounds64 = 9; }
+  }
+  for (int it = 0; it < rounds64; ++it) {
     const double w = hi - lo;
     const double x = lo + w * (double)(m + 1) * (1.0 / 17.0);
     double q = (double)dvec[0] - x;
