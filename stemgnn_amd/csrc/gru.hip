@@ -208,6 +208,32 @@ __device__ __forceinline__ float gru_consume(const gru_u64* g, unsigned tag, int
   return __uint_as_float((unsigned)x);
 }
 
+// Same-XCD fast path of the granule exchange.  A write-through (sc1) store drops the line from the producer XCD's L2, so
+// even a partner on the SAME XCD reads it back at the cross-XCD (fabric) rate; a PLAIN 8-byte store keeps the line in that
+// L2, where the partner's sc1 (L1-bypassing, L2-served) poll finds it after an L2 round trip.  Plain stores are only
+// correct when every partner shares the producer's XCD (L2s of different XCDs are not coherent), and HIP guarantees
+// nothing about placement -- so each cluster CHECKS it at run time: every workgroup publishes its XCC id through the
+// slow path once, and the plain-store flavour is used only if all P ids of the row agree (block ids equal mod 8 make
+// that the observed case).  STEMGNN_GRU_FAST_XCD=0 forces the slow path.
+__device__ __forceinline__ void gru_publish_x(gru_u64* g, unsigned tag, float v, bool same_xcd) {
+  const gru_u64 x = ((gru_u64)tag << 32) | (gru_u64)__float_as_uint(v);
+  // one PLAIN global_store_dwordx2 (a `volatile` C++ store is emitted `sc0 sc1`, an atomic one `sc1`: both leave the L2)
+  if (same_xcd) asm volatile("global_store_dwordx2 %0, %1, off" : : "v"(g), "v"(x) : "memory");
+  else __hip_atomic_store(g, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// returns true when all P workgroups of batch row b run on one XCD.  xid: P granules of this row, zeroed before launch.
+__device__ __forceinline__ bool gru_same_xcd(gru_u64* xid, int p, int P, int allow, int* status, int* s_flag, int tid) {
+  if (tid == 0) {
+    const unsigned xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 0xfu;     // HW_REG_XCC_ID[3:0]
+    gru_publish(xid + p, 1u, (float)(xcc + 1));
+    int same = allow;
+    for (int q = 0; q < P; ++q) same &= gru_consume(xid + q, 1u, status) == (float)(xcc + 1);
+    *s_flag = same;
+  }
+  __syncthreads();
+  return *s_flag != 0;
+}
+
 struct GruCluster {   // geometry shared by host and device
   int P, U, ncb, ksf, kcf, ksb, kcb;
 };
@@ -444,12 +470,15 @@ template <int P, int KU, int OW>
 __global__ __launch_bounds__(3 * (P / OW) * 64) void gru_fwd_cluster2_kernel(const float* __restrict__ gi, const float* __restrict__ w_hh,
                                                                       const float* __restrict__ b_hh, int B, int S, int Hd,
                                                                       gru_u64* __restrict__ xbuf, int* __restrict__ status,
-                                                                      float* __restrict__ h_all, float* __restrict__ reserve) {
+                                                                      float* __restrict__ h_all, float* __restrict__ reserve,
+                                                                      gru_u64* __restrict__ xid, int allow_fast) {
   static_assert(P % OW == 0, "owners per wave");
   __shared__ float part[2][3 * P][64];
+  __shared__ int s_fast;
   int b, p;
   gru_cluster_ids(B, P, b, p);
   if (b >= B) return;
+  const bool fast = P > 1 && gru_same_xcd(xid + (size_t)b * P, p, P, allow_fast, status, &s_fast, threadIdx.x);
   const int U = (Hd + P - 1) / P;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = gru_uniform(tid >> 6);
@@ -503,7 +532,7 @@ __global__ __launch_bounds__(3 * (P / OW) * 64) void gru_fwd_cluster2_kernel(con
       const float n = tanhf(gp2 + r * g2);
       const float hn = (1.f - z) * n + z * hown;
       hown = hn;
-      if (s + 1 < S) gru_publish(xbuf + ((size_t)((s + 1) & 1) * B + b) * Hd + gu, (unsigned)(s + 1), hn);
+      if (s + 1 < S) gru_publish_x(xbuf + ((size_t)((s + 1) & 1) * B + b) * Hd + gu, (unsigned)(s + 1), hn, fast);
       float* rs = reserve + row * 4 * Hd;
       rs[gu] = r; rs[Hd + gu] = z; rs[2 * Hd + gu] = n; rs[3 * Hd + gu] = g2;
       h_all[row * Hd + gu] = hn;
@@ -519,7 +548,8 @@ __global__ __launch_bounds__(3 * (P / OW) * 64) void gru_bwd_cluster2_kernel(con
                                                                       gru_u64* __restrict__ xbuf, int* __restrict__ status,
                                                                       float* __restrict__ dgi, float* __restrict__ dghn,
                                                                       int s_hi, int s_lo, float* __restrict__ carry,
-                                                                      int s_mark, unsigned* __restrict__ progress) {
+                                                                      int s_mark, unsigned* __restrict__ progress,
+                                                                      gru_u64* __restrict__ xid, int allow_fast) {
   // Steps s_hi .. s_lo (descending) of the backward recurrence: the host may cut the S steps into time segments (one
   // launch each) so the weight-gradient GEMMs of a finished segment overlap the recurrence of the next.  `carry`
   // [B][Hd] hands the recurrent part of dh (dh * z + W_hh^T dgh) from one segment to the next; granule tags keep
@@ -527,9 +557,12 @@ __global__ __launch_bounds__(3 * (P / OW) * 64) void gru_bwd_cluster2_kernel(con
   static_assert(P % OW == 0, "owners per wave");
   constexpr int NTH = 3 * (P / OW) * 64;
   __shared__ float part[2][3 * P][64];
+  __shared__ int s_fast;
   int b, p;
   gru_cluster_ids(B, P, b, p);
   if (b >= B) return;
+  // (every segment launch re-checks the placement: its granules live in the segment's own slot of xid)
+  const bool fast = P > 1 && gru_same_xcd(xid + (size_t)b * P, p, P, allow_fast, status, &s_fast, threadIdx.x);
   const int U = (Hd + P - 1) / P;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = gru_uniform(tid >> 6);
@@ -579,9 +612,9 @@ __global__ __launch_bounds__(3 * (P / OW) * 64) void gru_bwd_cluster2_kernel(con
       own_dr = dr;
       dhz = dh * z;
       if (s > 0) {
-        gru_publish(xb + gu, tag, dr);
-        gru_publish(xb + Hd + gu, tag, dz);
-        gru_publish(xb + 2 * Hd + gu, tag, dnr);
+        gru_publish_x(xb + gu, tag, dr, fast);
+        gru_publish_x(xb + Hd + gu, tag, dz, fast);
+        gru_publish_x(xb + 2 * Hd + gu, tag, dnr, fast);
         const size_t rn = row - B;                      // prefetch the next (earlier) step
         p_do = dout[rn * Hd + gu];
         p_r = reserve[rn * 4 * Hd + gu]; p_z = reserve[rn * 4 * Hd + Hd + gu];
@@ -747,7 +780,7 @@ static int gru_pick_KU(int Hd, int P) {              // unrolled mat-vec length:
   return U <= 32 ? 32 : (U <= 48 ? 48 : (U <= 58 ? 58 : 64));
 }
 static size_t gru_xbuf_floats(int B, int Hd) {     // u64 granules, 2 parities (per-row clusters) | wide-cluster exchange
-  const size_t a = (size_t)2 * 2 * B * 3 * Hd + 2, b = gru_wide_xbuf_floats(Hd);
+  const size_t a = (size_t)2 * 2 * B * 3 * Hd + 2 + (size_t)2 * 8 * 8 * B, b = gru_wide_xbuf_floats(Hd);   // + XCC-id granules
   return a > b ? a : b;
 }
 // wide cluster (gru_wide.h): hidden sizes beyond the per-row clusters; STEMGNN_GRU_WIDE=0 disables, =1 forces it
@@ -792,10 +825,12 @@ extern "C" int stemgnn_gru_fwd(const float* x, const float* w_ih, const float* w
   }
   if (P2 > 0) {
     gru_u64* xbuf = (gru_u64*)(scratch + ((((size_t)3 * Hd * Hd + (size_t)3 * S * B * Hd) + 1) & ~(size_t)1));
-    SG_TRY(hipMemsetAsync(xbuf, 0, (size_t)2 * B * Hd * sizeof(gru_u64), st));      // tags := 0 before every launch
+    gru_u64* xid = xbuf + (size_t)2 * B * Hd;                                       // P XCC-id granules per batch row
+    SG_TRY(hipMemsetAsync(xbuf, 0, ((size_t)2 * B * Hd + (size_t)8 * B) * sizeof(gru_u64), st));   // tags := 0 every launch
+    static const int allow_fast = !(getenv("STEMGNN_GRU_FAST_XCD") && atoi(getenv("STEMGNN_GRU_FAST_XCD")) == 0);
     const dim3 grid(8 * ((B + 7) / 8) * P2);
 #define GRU_F2K(PP, KK, OO) hipLaunchKernelGGL((gru_fwd_cluster2_kernel<PP, KK, OO>), grid, dim3(3 * (PP / OO) * 64), 0, st, gi, \
-                                               w_hh, b_hh, B, S, Hd, xbuf, status, h_all, reserve)
+                                               w_hh, b_hh, B, S, Hd, xbuf, status, h_all, reserve, xid, allow_fast)
 #define GRU_F2(PP, OO) do { if (KU2 == 32) GRU_F2K(PP, 32, OO); else if (KU2 == 48) GRU_F2K(PP, 48, OO); \
                             else if (KU2 == 58) GRU_F2K(PP, 58, OO); else GRU_F2K(PP, 64, OO); } while (0)
     const int KU2 = gru_pick_KU(Hd, P2);
@@ -915,7 +950,9 @@ extern "C" int stemgnn_gru_bwd(const float* dh_all, const float* x, const float*
     gru_u64* xbuf = (gru_u64*)xtail;
     float* carry = xtail + gru_xbuf_floats(B, Hd);
     unsigned* progress = (unsigned*)(carry + (size_t)B * Hd);
-    SG_TRY(hipMemsetAsync(xbuf, 0, (size_t)2 * B * 3 * Hd * sizeof(gru_u64), st));
+    gru_u64* xid0 = xbuf + (size_t)2 * B * 3 * Hd;           // P XCC-id granules per batch row and per segment launch
+    SG_TRY(hipMemsetAsync(xbuf, 0, ((size_t)2 * B * 3 * Hd + (size_t)8 * 8 * B) * sizeof(gru_u64), st));
+    static const int allow_fast = !(getenv("STEMGNN_GRU_FAST_XCD") && atoi(getenv("STEMGNN_GRU_FAST_XCD")) == 0);
     // Early weight gradients (single launch of the recurrence): when every workgroup has passed step s_mark the rows of
     // the steps >= s_mark are final; a spin kernel on side stream 1 waits for that mark and the dW_hh / dW_ih reductions
     // of those rows run there under the REST of the recurrence -- only the rows below the mark are left for afterwards.
@@ -942,7 +979,8 @@ extern "C" int stemgnn_gru_bwd(const float* dh_all, const float* x, const float*
       const int s_hi = S - 1 - (int)((long)S * seg / T), s_lo = S - (int)((long)S * (seg + 1) / T);
 #define GRU_B2K(PP, KK, OO) do { const size_t hog = gru_lds_hog<PP>((const void*)gru_bwd_cluster2_kernel<PP, KK, OO>); \
     hipLaunchKernelGGL((gru_bwd_cluster2_kernel<PP, KK, OO>), grid, dim3(3 * (PP / OO) * 64), hog, st, dh_all, w_hh, h_all, \
-                       reserve, B, S, Hd, xbuf, status, dgi, dghn, s_hi, s_lo, carry, s_mark, progress); } while (0)
+                       reserve, B, S, Hd, xbuf, status, dgi, dghn, s_hi, s_lo, carry, s_mark, progress, \
+                       xid0 + (size_t)seg * 8 * B, allow_fast); } while (0)
 #define GRU_B2(PP, OO) do { if (KU2 == 32) GRU_B2K(PP, 32, OO); else if (KU2 == 48) GRU_B2K(PP, 48, OO); \
                             else if (KU2 == 58) GRU_B2K(PP, 58, OO); else GRU_B2K(PP, 64, OO); } while (0)
       if (P2 == 1) GRU_B2(1, 1); else if (P2 == 2) GRU_B2(2, 1); else if (P2 == 4) GRU_B2(4, 1);
