@@ -196,7 +196,8 @@ __global__ __launch_bounds__(1024) void eig_tridiag_kernel(float* __restrict__ A
   float* wprev = et_sm + N;
   float* vcur = et_sm + 2 * N;
   float* red = et_sm + 3 * N;
-  const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   float tau_prev = 0.f;
   for (int k = 0; k < N; ++k) {
     // 1. w_{k-1} = p - (tau/2 (p.v)) v   (p = tau A v of the previous step, gathered from all workgroups)
@@ -304,8 +305,9 @@ __global__ __launch_bounds__(1024) void eig_tridiag_kernel(float* __restrict__ A
 __global__ __launch_bounds__(1024) void eig_tridiag_small_kernel(const float* __restrict__ A, int N, float* __restrict__ V,
                                                                  float* __restrict__ dvec, float* __restrict__ evec,
                                                                  float* __restrict__ tauv) {
-  __shared__ float vbuf[2][256], wprev[256], pvec[256], prow[256], red[16];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  __shared__ float vbuf[2][256], wprev[256], pvec[256], prow[256], red[16], piv[2];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);         // scalar: row-ownership tests become SALU compares
   float a[16][4];
 #pragma unroll
   for (int r = 0; r < 16; ++r)
@@ -339,18 +341,17 @@ __global__ __launch_bounds__(1024) void eig_tridiag_small_kernel(const float* __
         if (k > 0) rj -= vk * wprev[tid] + wk * vprev[tid];
         if (tid > k + 1) part = rj * rj;
       }
+      if (tid == k) piv[0] = rj;
+      if (tid == k + 1) piv[1] = rj;
     }
-    const float sigma = et_block_sum(part, red, tid);
-    if (tid < 256) vcur[tid] = rj;
-    __syncthreads();
-    const float rk = vcur[k], r1 = k + 1 < N ? vcur[k + 1] : 0.f;
+    const float sigma = et_block_sum(part, red, tid);                 // (its barriers publish piv[])
+    const float rk = piv[0], r1 = k + 1 < N ? piv[1] : 0.f;
     float tau = 0.f, beta = r1, scale = 0.f;
     if (k < N - 2 && sigma > 0.f) {
       beta = -copysignf(sqrtf(r1 * r1 + sigma), r1);
       tau = (beta - r1) / beta;
       scale = 1.f / (r1 - beta);
     }
-    __syncthreads();
     if (tid < 256) {
       const float v = tid <= k || tid >= N ? 0.f : (tid == k + 1 ? 1.f : rj * scale);
       vcur[tid] = v;
@@ -362,33 +363,43 @@ __global__ __launch_bounds__(1024) void eig_tridiag_small_kernel(const float* __
       tauv[k] = tau;
     }
     __syncthreads();
-    // fused pass over the own rows i > k (register resident)
+    // fused pass over ALL 16 row slots, branch-free (rows at or above the pivot are dead, rows beyond N are zero:
+    // updating them is harmless and keeps the 16 rows' LDS reads, FMAs and reductions in one basic block)
     float vc[4], vp[4], wp[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       const int j = lane + 64 * c;
-      vc[c] = j > k ? vcur[j] : 0.f;                                  // (entries at or beyond N are zero)
+      vc[c] = vcur[j];                                                // zero up to k and from N on
       vp[c] = vprev[j];
       wp[c] = wprev[j];
     }
+    float vi[16], wi[16], dot[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int i = wave + 16 * r;
-      if (i > k && i < N) {                                           // wave-uniform
-        const float vi = vprev[i], wi = wprev[i];
-        float dot = 0.f;
+      vi[r] = vprev[wave + 16 * r];
+      wi[r] = wprev[wave + 16 * r];
+    }
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          if (k > 0) a[r][c] -= vi * wp[c] + wi * vp[c];
-          dot += a[r][c] * vc[c];
-        }
-        if (i == k + 1) {
+    for (int r = 0; r < 16; ++r) {
+      float d = 0.f;
 #pragma unroll
-          for (int c = 0; c < 4; ++c) prow[lane + 64 * c] = a[r][c];
-        }
-        dot = et_wave_sum(dot);
-        if (lane == 0) pvec[i] = tau * dot;
+      for (int c = 0; c < 4; ++c) {
+        a[r][c] -= vi[r] * wp[c] + wi[r] * vp[c];                    // (v, w are all zero at k = 0)
+        d += a[r][c] * vc[c];
       }
+      dot[r] = d;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dot[r] = et_wave_sum(dot[r]);
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      if (wave + 16 * r == k + 1) {                                   // wave-uniform: the owner publishes the next pivot row
+#pragma unroll
+        for (int c = 0; c < 4; ++c) prow[lane + 64 * c] = a[r][c];
+      }
+    if (lane == 0) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) pvec[wave + 16 * r] = tau * dot[r];
     }
     __syncthreads();
     tau_prev = tau;
