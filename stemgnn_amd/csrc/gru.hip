@@ -956,11 +956,13 @@ extern "C" int stemgnn_gru_bwd(const float* dh_all, const float* x, const float*
     // Early weight gradients (single launch of the recurrence): when every workgroup has passed step s_mark the rows of
     // the steps >= s_mark are final; a spin kernel on side stream 1 waits for that mark and the dW_hh / dW_ih reductions
     // of those rows run there under the REST of the recurrence -- only the rows below the mark are left for afterwards.
-    // The mark sits at 30 % of the steps: in the train step the side stream is busy with block weight gradients until
-    // ~70 % of the recurrence has run (profiles/r02_step_timeline.txt).
+    // OFF by default (STEMGNN_GRU_MARK=<percent of the steps> switches it on): it needs the spin kernel to run
+    // CONCURRENTLY with the recurrence, and a hipGraph replay gives no such guarantee -- measured, the graph executor
+    // placed the spin kernel behind the recurrence, so the early rows ran last and the step got 3 % slower
+    // (profiles/r02_gru_segments.md).  Correct in eager and in graph mode (parity-tested), useful only in eager mode.
     int s_mark = -1;
     if (T == 1 && s1 && s2 && S >= 64) {
-      static const int env_m = getenv("STEMGNN_GRU_MARK") ? atoi(getenv("STEMGNN_GRU_MARK")) : 30;
+      static const int env_m = getenv("STEMGNN_GRU_MARK") ? atoi(getenv("STEMGNN_GRU_MARK")) : 0;
       if (env_m > 0 && env_m < 100) s_mark = (int)((long)S * env_m / 100);
       if (s_mark < 1) s_mark = -1;
     }

@@ -41,11 +41,12 @@ def test_gru_fwd_bwd_vs_torch_cpu(B, S, W, cluster, monkeypatch):
 def test_gru_backward_time_segments_vs_torch_cpu(B, S, W, mode):
     """Overlap mode (side streams given) of the GRU backward, both schedules against torch's CPU GRU + bitwise
     reproducibility:
-      mark      (default) one launch; when every workgroup has passed the progress mark (30 % of the steps) a spin kernel
-                releases the dW_hh / dW_ih reductions of the finished rows on the side streams, under the rest of the
-                recurrence;
-      segments  STEMGNN_GRU_SEGMENTS=4: four launches with the recurrent dh carried through global memory (measured
-                slower, kept switchable)."""
+      mark      STEMGNN_GRU_MARK=30: one launch; when every workgroup has passed the progress mark (30 % of the steps) a
+                spin kernel releases the dW_hh / dW_ih reductions of the finished rows on the side streams, under the
+                rest of the recurrence;
+      segments  STEMGNN_GRU_SEGMENTS=4: four launches with the recurrent dh carried through global memory.
+    Both are off by default (measured slower inside the hipGraph train step, profiles/r02_gru_segments.md); the library
+    reads the switches once per process, so each case re-runs itself in a child process with its switch set."""
     from stemgnn_amd import ops
     from stemgnn_amd.ops import GruFront, check_gru_status
 
@@ -57,9 +58,10 @@ def test_gru_backward_time_segments_vs_torch_cpu(B, S, W, mode):
     out.backward(dh)
     ref = (gru.weight_ih_l0, gru.weight_hh_l0, gru.bias_ih_l0, gru.bias_hh_l0)
     import subprocess, sys
-    if mode == "segments" and os.environ.get("STEMGNN_GRU_SEGMENTS") != "4":   # the library reads the switch once per
-        env = dict(os.environ, STEMGNN_GRU_SEGMENTS="4")    # process: re-run this test in a child with segmentation on
-        r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", f"{__file__}::test_gru_backward_time_segments_vs_torch_cpu[{B}-{S}-{W}-segments]"],
+    switch = {"segments": ("STEMGNN_GRU_SEGMENTS", "4"), "mark": ("STEMGNN_GRU_MARK", "30")}[mode]
+    if os.environ.get(switch[0]) != switch[1]:
+        env = dict(os.environ, **{switch[0]: switch[1]})
+        r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", f"{__file__}::test_gru_backward_time_segments_vs_torch_cpu[{B}-{S}-{W}-{mode}]"],
                            env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
         return
