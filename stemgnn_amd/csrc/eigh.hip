@@ -172,12 +172,15 @@ __device__ __forceinline__ float et_wave_sum(float v) {
   const float d = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
   return (a + b) + (c + d);
 }
-// fixed-order block sum (16 waves); every thread gets the result.  Contains two barriers.
+// LDS-only workgroup barrier: __syncthreads() would also drain vmcnt, i.e. wait for the acknowledgement of every global
+// store issued so far (the V rows / d / e / tau written inside the column loop) at each of the ~7 barriers of a step
+__device__ __forceinline__ void et_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// fixed-order block sum (16 waves); every thread gets the result.  Contains two (LDS) barriers.
 __device__ __forceinline__ float et_block_sum(float v, float* red, int tid) {
   v = et_wave_sum(v);
-  __syncthreads();
+  et_lds_barrier();
   if ((tid & 63) == 0) red[tid >> 6] = v;
-  __syncthreads();
+  et_lds_barrier();
   float s = 0.f;
 #pragma unroll
   for (int w = 0; w < 16; ++w) s += red[w];
@@ -330,7 +333,7 @@ __global__ __launch_bounds__(1024) void eig_tridiag_small_kernel(const float* __
       if (tid < 256) part = (tid >= k && tid < N) ? pvec[tid] * vprev[tid] : 0.f;
       const float alpha = 0.5f * tau_prev * et_block_sum(part, red, tid);
       if (tid < 256) wprev[tid] = (tid >= k && tid < N) ? pvec[tid] - alpha * vprev[tid] : 0.f;
-      __syncthreads();
+      et_lds_barrier();
     }
     // pivot row k (published by its owner in the previous pass, pending update still to be applied)
     float rj = 0.f, part = 0.f;
@@ -362,7 +365,7 @@ __global__ __launch_bounds__(1024) void eig_tridiag_small_kernel(const float* __
       if (k + 1 < N) evec[k] = beta;
       tauv[k] = tau;
     }
-    __syncthreads();
+    et_lds_barrier();
     // fused pass over ALL 16 row slots, branch-free (rows at or above the pivot are dead, rows beyond N are zero:
     // updating them is harmless and keeps the 16 rows' LDS reads, FMAs and reductions in one basic block)
     float vc[4], vp[4], wp[4];
@@ -401,7 +404,7 @@ __global__ __launch_bounds__(1024) void eig_tridiag_small_kernel(const float* __
 #pragma unroll
       for (int r = 0; r < 16; ++r) pvec[wave + 16 * r] = tau * dot[r];
     }
-    __syncthreads();
+    et_lds_barrier();
     tau_prev = tau;
   }
 }

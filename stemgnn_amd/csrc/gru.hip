@@ -192,6 +192,17 @@ __global__ __launch_bounds__(1024) void gru_bwd_kernel(const float* __restrict__
 // The 4 partners of a row are given block ids that are equal mod 8, i.e. the same XCD (speed only).
 // =================================================================================================
 typedef unsigned long long gru_u64;
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it makes every wave wait for
+// the acknowledgements of the global stores of the PREVIOUS step (h, the saved gates, the granules) and for the gate
+// inputs it prefetched -- none of which the barrier has to order here (the per-step barrier only publishes the partial
+// sums in LDS; consumers of global data wait through their own s_waitcnt).  -DGRU_PLAIN_BARRIER restores __syncthreads().
+__device__ __forceinline__ void gru_lds_barrier() {
+#ifdef GRU_PLAIN_BARRIER
+  __syncthreads();
+#else
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
+}
 __device__ __forceinline__ void gru_publish(gru_u64* g, unsigned tag, float v) {
   __hip_atomic_store(g, ((gru_u64)tag << 32) | (gru_u64)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -518,7 +529,7 @@ __global__ __launch_bounds__(3 * (P / OW) * 64) void gru_fwd_cluster2_kernel(con
                                          (unsigned)s, lane < kn[o], status);
       part[s & 1][g * P + q0 + o][lane] = gru_matvec<KU>(wr[o], hv);
     }
-    __syncthreads();
+    gru_lds_barrier();
     if (tid < un) {
       float g0 = bh0, g1 = bh1, g2 = bh2;
 #pragma unroll
@@ -633,7 +644,7 @@ __global__ __launch_bounds__(3 * (P / OW) * 64) void gru_bwd_cluster2_kernel(con
       else dv = gru_poll_lane(xb + (size_t)g * Hd + k0[o] + (lane < kn[o] ? lane : 0), tag, lane < kn[o], status);
       part[tag & 1][g * P + q0 + o][lane] = gru_matvec<KU>(wr[o], dv);
     }
-    __syncthreads();
+    gru_lds_barrier();
     if (s == s_mark) {
       // progress mark: every gate-gradient row of the steps >= s_mark is written.  Publish them to kernels of OTHER
       // streams while this one keeps running: drain, write the XCD's dirty L2 lines back (agent-scope release), count.
