@@ -538,9 +538,15 @@ __global__ __launch_bounds__(3 * (P / OW) * 64) void gru_fwd_cluster2_kernel(con
         g1 += part[s & 1][1 * P + qq][tid];
         g2 += part[s & 1][2 * P + qq][tid];
       }
-      const float r = gru_sigmoid(gp0 + g0);       // (the v_exp/v_rcp fast forms were measured: no gain, the step
-      const float z = gru_sigmoid(gp1 + g1);       //  is bound by the exchange latency, so the exact forms stay)
+#ifdef GRU_FAST_GATES      // v_exp / v_rcp forms (A/B builds only; measured in profiles/r02_gru_exchange.md)
+      const float r = __frcp_rn(1.f + __expf(-(gp0 + g0)));
+      const float z = __frcp_rn(1.f + __expf(-(gp1 + g1)));
+      const float n = 1.f - 2.f * __frcp_rn(1.f + __expf(2.f * (gp2 + r * g2)));
+#else
+      const float r = gru_sigmoid(gp0 + g0);
+      const float z = gru_sigmoid(gp1 + g1);
       const float n = tanhf(gp2 + r * g2);
+#endif
       const float hn = (1.f - z) * n + z * hown;
       hown = hn;
       if (s + 1 < S) gru_publish_x(xbuf + ((size_t)((s + 1) & 1) * B + b) * Hd + gu, (unsigned)(s + 1), hn, fast);
