@@ -586,6 +586,12 @@ static inline int g2_bm_mask() {
   static const int m = getenv("STEMGNN_G2_BM64") ? atoi(getenv("STEMGNN_G2_BM64")) : 3;   // measured: 1.921 -> 1.890 ms/step
   return m;
 }
+// which GLU GEMM families use 32-deep LDS stages (gemm2.h BK = 32, 64-row tiles only): bit 0 forward, 1 data gradient,
+// 2 weight gradient
+static inline int g2_bk32_mask() {
+  static const int m = getenv("STEMGNN_G2_BK32") ? atoi(getenv("STEMGNN_G2_BK32")) : 0;
+  return m;
+}
 // reductions longer than this use the two-level accumulating instantiations (large W*multi configurations)
 constexpr int SG_LONG_K = 640;
 static inline int split_chunk(int M, int S) { return ((M + S - 1) / S + 15) & ~15; }
@@ -677,6 +683,7 @@ extern "C" int stemgnn_spectral_glu_fwd(const float* packed, float* saved, int B
     }
     g.nsplit = 1; g.chunk = (sg_glu_kin(d, l) + 15) & ~15; g.b_ones_col = -1;
     if (sg_glu_kin(d, l) > SG_LONG_K) SG_TRY((g2_launch<GluFwdEpi, true, false, 64, true>(g, e, 2, st)));
+    else if (g2_bk32_mask() & 1) SG_TRY((g2_launch<GluFwdEpi, true, false, 64, false, 32>(g, e, 2, st)));
     else if (g2_bm_mask() & 1) SG_TRY((g2_launch<GluFwdEpi, true, false, 64>(g, e, 2, st)));
     else SG_TRY((g2_launch<GluFwdEpi, true, false>(g, e, 2, st)));
   }
@@ -712,7 +719,8 @@ extern "C" int stemgnn_spectral_glu_bwd(const float* packed, const float* saved,
         e.part[r] = gradpart + Gl.w[r][l];
       }
       g.nsplit = nsplit; g.chunk = chunk; g.b_ones_col = sg_glu_kin(d, l);
-      if (g2_bm_mask() & 4) SG_TRY((g2_launch<GluWgradEpi, false, false, 64>(g, e, 2, st)));
+      if (g2_bk32_mask() & 4) SG_TRY((g2_launch<GluWgradEpi, false, false, 64, false, 32>(g, e, 2, st)));
+      else if (g2_bm_mask() & 4) SG_TRY((g2_launch<GluWgradEpi, false, false, 64>(g, e, 2, st)));
       else SG_TRY((g2_launch<GluWgradEpi, false, false>(g, e, 2, st)));
     }
     if (!(parts & 1)) continue;
@@ -732,6 +740,7 @@ extern "C" int stemgnn_spectral_glu_bwd(const float* packed, const float* saved,
       e.cp = d.CP;
       g.nsplit = 1; g.chunk = (2 * d.CP + 15) & ~15; g.b_ones_col = -1;
       if (2 * d.CP > SG_LONG_K) SG_TRY((g2_launch<GluDpreEpi, true, true, 64, true>(g, e, 2, st)));
+      else if (g2_bk32_mask() & 2) SG_TRY((g2_launch<GluDpreEpi, true, true, 64, false, 32>(g, e, 2, st)));
       else if (g2_bm_mask() & 2) SG_TRY((g2_launch<GluDpreEpi, true, true, 64>(g, e, 2, st)));
       else SG_TRY((g2_launch<GluDpreEpi, true, true>(g, e, 2, st)));
     } else {      // layer 0: both branches feed the same G -> one launch with K = Re columns then Im columns

@@ -44,10 +44,11 @@ constexpr int G2_BM = 128, G2_BN = 128, G2_BK = 16, G2_LD = 132;
 // D layout of v_mfma_f32_32x32x2_f32: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
 __device__ __forceinline__ int g2_row_of(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
 
-template <bool KCONTIG, bool VEC, int ROWS = 128>
+template <bool KCONTIG, bool VEC, int ROWS = 128, int BK = 16>
 struct G2Loader {
-  static constexpr int NT = ROWS / 64;     // float4 per thread for a (ROWS x 16) operand tile
-  static constexpr int LD = ROWS + 4;      // LDS row stride (floats) of the K-major tile
+  static constexpr int NT = ROWS * BK / 1024;   // float4 per thread for a (ROWS x BK) operand tile (256 threads)
+  static constexpr int LD = ROWS + 4;           // LDS row stride (floats) of the K-major tile
+  static constexpr int KQ = BK / 4;             // float4 per row of a k-contiguous tile
   // fetch the NT float4 this thread stages for a (ROWS x 16) operand tile.  rows = i (or j) extent, kk = K limit
   static __device__ __forceinline__ void load(const float* __restrict__ P, int ld, int i0, int imax, int kb, int kmax,
                                               int ones_col, int tid, float4 (&v)[NT]) {
@@ -56,7 +57,7 @@ struct G2Loader {
       const int f = tid + 256 * t;
       float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
       if constexpr (KCONTIG) {            // element (i, k) at P[i*ld + k]; float4 = 4 k's of row i
-        const int i = i0 + (f >> 2), k = kb + ((f & 3) << 2);
+        const int i = i0 + f / KQ, k = kb + ((f % KQ) << 2);
         if constexpr (VEC) {
           const bool ok = i < imax && k < kmax;               // K % 4 == 0 is guaranteed on the VEC path
           const float4 x = *reinterpret_cast<const float4*>(P + (size_t)(ok ? i : 0) * ld + (ok ? k : 0));
@@ -100,7 +101,7 @@ struct G2Loader {
     for (int t = 0; t < NT; ++t) {
       const int f = tid + 256 * t;
       if constexpr (KCONTIG) {
-        const int i = f >> 2, k = (f & 3) << 2;
+        const int i = f / KQ, k = (f % KQ) << 2;
         T[(k + 0) * LD + i] = v[t].x;
         T[(k + 1) * LD + i] = v[t].y;
         T[(k + 2) * LD + i] = v[t].z;
@@ -117,13 +118,17 @@ struct G2Loader {
 // fp32 MFMA chain is at most G2_FLUSH * 8 instructions long -- the rounding noise of a K = 2000-4000 reduction drops to
 // that of a blocked sum (used for the long reductions of the large-N configurations only; costs 32 registers at BM = 64).
 constexpr int G2_FLUSH = 16;
-template <class Epi, bool A_KC, bool B_KC, bool VEC, int BM = 128, bool TL = false>
+// BK = K extent of one LDS stage: 16 (round 1) or 32 -- half as many barriers and twice the MFMA work per stage (2048
+// cycles per wave at BM = 64), i.e. more time for the register prefetch of the next stage to land when only a few
+// workgroups share a CU (weight gradients with few splits); costs 2x LDS (51 KB at BM = 64 -> 3 workgroups per CU).
+template <class Epi, bool A_KC, bool B_KC, bool VEC, int BM = 128, bool TL = false, int BK = 16>
 __global__ __launch_bounds__(256) void sg_gemm2(const G2Args g, const Epi epi) {
   static_assert(BM == 64 || BM == 128, "BM");
+  static_assert(BK == 16 || (BK == 32 && BM == 64), "BK = 32 is instantiated for 64-row tiles (51 KB of LDS)");
   static_assert(!TL || BM == 64, "two-level accumulation is instantiated for 64-row tiles only");
   constexpr int NI = BM / 64;                    // 32-row MFMA tiles per wave (2 x 2 waves, each (BM/2) x 64)
   constexpr int LDA = BM + 4;
-  constexpr int STAGE = G2_BK * (LDA + G2_LD);   // one double-buffer stage: A tile then B tile
+  constexpr int STAGE = BK * (LDA + G2_LD);      // one double-buffer stage: A tile then B tile
   __shared__ __attribute__((aligned(16))) float lds[2 * STAGE];
   int bx, by, z;
   {
@@ -167,29 +172,29 @@ __global__ __launch_bounds__(256) void sg_gemm2(const G2Args g, const Epi epi) {
         for (int e = 0; e < 16; ++e) acc2[i][j][e] = 0.f;
   }
   int tl_count = 0;
-  using LA = G2Loader<A_KC, VEC, BM>;
-  using LB = G2Loader<B_KC, VEC, 128>;
-  float4 ra[LA::NT], rb[2];
+  using LA = G2Loader<A_KC, VEC, BM, BK>;
+  using LB = G2Loader<B_KC, VEC, 128, BK>;
+  float4 ra[LA::NT], rb[LB::NT];
   if (K0 < K1) {
     LA::load(A, lda, m0, M, K0, K1, -1, tid, ra);
     LB::load(Bp, ldb, n0, N, K0, K1, g.b_ones_col, tid, rb);
     LA::store(lds, tid, ra);
-    LB::store(lds + G2_BK * LDA, tid, rb);
+    LB::store(lds + BK * LDA, tid, rb);
   }
   __syncthreads();
   int buf = 0;
-  for (int kb = K0; kb < K1; kb += G2_BK) {
-    const bool more = kb + G2_BK < K1;
+  for (int kb = K0; kb < K1; kb += BK) {
+    const bool more = kb + BK < K1;
     if (more && !G2_DBG(g, 4)) {
-      LA::load(A, lda, m0, M, kb + G2_BK, K1, -1, tid, ra);
-      LB::load(Bp, ldb, n0, N, kb + G2_BK, K1, g.b_ones_col, tid, rb);
+      LA::load(A, lda, m0, M, kb + BK, K1, -1, tid, ra);
+      LB::load(Bp, ldb, n0, N, kb + BK, K1, g.b_ones_col, tid, rb);
     }
     const float* As = lds + buf * STAGE;
-    const float* Bs = As + G2_BK * LDA;
+    const float* Bs = As + BK * LDA;
     const int fi = lane & 31, fk = lane >> 5;
     if (!G2_DBG(g, 2))
 #pragma unroll
-    for (int ks = 0; ks < G2_BK; ks += 2) {
+    for (int ks = 0; ks < BK; ks += 2) {
       float a[NI];
 #pragma unroll
       for (int i = 0; i < NI; ++i) a[i] = As[(ks + fk) * LDA + wm * (BM / 2) + i * 32 + fi];
@@ -203,7 +208,7 @@ __global__ __launch_bounds__(256) void sg_gemm2(const G2Args g, const Epi epi) {
     if (more) {
       float* An = lds + (buf ^ 1) * STAGE;
       LA::store(An, tid, ra);
-      LB::store(An + G2_BK * LDA, tid, rb);
+      LB::store(An + BK * LDA, tid, rb);
     }
     __syncthreads();
     buf ^= 1;
@@ -260,7 +265,7 @@ struct G2SlabEpi {
 // 16-byte alignment rules of the VEC path
 static inline bool g2_aligned(const void* p, int ld) { return (((uintptr_t)p) & 15) == 0 && (ld & 3) == 0; }
 
-template <class Epi, bool A_KC, bool B_KC, int BM = 128, bool TL = false>
+template <class Epi, bool A_KC, bool B_KC, int BM = 128, bool TL = false, int BK = 16>
 static inline hipError_t g2_launch(const G2Args& g_in, const Epi& epi, int nbranch, hipStream_t st) {
   G2Args g = g_in;
 #ifdef SG_G2_DEBUG
@@ -287,7 +292,7 @@ static inline hipError_t g2_launch(const G2Args& g_in, const Epi& epi, int nbran
   const int ngroups = g.xcd_mode ? g.nz : g.nx * g.nz;
   const int gt = g.xcd_mode ? g.nx * g.ny : g.ny;
   dim3 grid(8 * ((ngroups + 7) / 8) * gt);
-  if (vec) hipLaunchKernelGGL((sg_gemm2<Epi, A_KC, B_KC, true, BM, TL>), grid, dim3(256), 0, st, g, epi);
-  else hipLaunchKernelGGL((sg_gemm2<Epi, A_KC, B_KC, false, BM, TL>), grid, dim3(256), 0, st, g, epi);
+  if (vec) hipLaunchKernelGGL((sg_gemm2<Epi, A_KC, B_KC, true, BM, TL, BK>), grid, dim3(256), 0, st, g, epi);
+  else hipLaunchKernelGGL((sg_gemm2<Epi, A_KC, B_KC, false, BM, TL, BK>), grid, dim3(256), 0, st, g, epi);
   return hipGetLastError();
 }
