@@ -203,6 +203,13 @@ int stemgnn_fc_tail_bwd(const float* dforecast, const float* fsum, const float* 
 int stemgnn_rmsprop_step(float* params, float* grads, float* square_avg, size_t n, const float* lr_dev,
                          float alpha, float eps, int zero_grad, float grad_scale, void* stream);
 
+/* Adam step of the driver's other optimizer branch (models/handler.py:128-129; torch defaults weight_decay 0,
+ * amsgrad off) over flat buffers of n floats; lr and the step count (step_dev[0], a float, incremented by the call) are
+ * read from device memory, so the call is replayable inside a hipGraph; zero_grad / grad_scale as in rmsprop_step. */
+int stemgnn_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, size_t n, const float* lr_dev,
+                      float* step_dev, float beta1, float beta2, float eps, int zero_grad, float grad_scale,
+                      void* stream);
+
 /* ---- data path either side of the hot path ---------------------------------------------
  * normalized() (data_loader/forecast_dataloader.py:7-22): out[t,n] = (float)clip01?((raw[t,n]-sub[n])/div[n]) in IEEE
  * fp64 (z_score: sub=mean, div=std with 0->1; min_max: sub=min, div=max-min+1e-5, clip01=1).  raw [T,N] fp64. */

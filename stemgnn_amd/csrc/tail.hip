@@ -259,3 +259,44 @@ extern "C" int stemgnn_rmsprop_step(float* params, float* grads, float* square_a
   SG_TRY(hipGetLastError());
   return 0;
 }
+
+// ---- fused Adam over flat buffers (the driver's other optimizer branch, models/handler.py:128-129) -----------------
+// torch.optim.Adam(betas=(b1, b2), eps, weight_decay=0, amsgrad=False):  m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g g ;
+// p -= lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps).  The step count t lives in device memory (state[0], a
+// float that the kernel's first thread increments AFTER everybody has read it -- single pass: every thread reads t at
+// entry; the increment is done by a tail launch of one thread) so a hipGraph replay advances it without host help.
+__global__ void sg_adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                               size_t n, const float* __restrict__ lr_dev, const float* __restrict__ step_dev, float b1,
+                               float b2, float eps, int zero_grad, float gscale) {
+  const float lr = lr_dev[0];
+  const float t = step_dev[0] + 1.f;                      // this step's index (1-based)
+  const float bc1 = 1.f - powf(b1, t), bc2 = 1.f - powf(b2, t);
+  const float step_size = lr / bc1, rs2 = 1.f / sqrtf(bc2);
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    const float gv = g[i] * gscale;
+    const float mv = b1 * m[i] + (1.f - b1) * gv;
+    const float vv = b2 * v[i] + (1.f - b2) * gv * gv;
+    m[i] = mv;
+    v[i] = vv;
+    p[i] -= step_size * mv / (sqrtf(vv) * rs2 + eps);
+    if (zero_grad) g[i] = 0.f;
+  }
+}
+__global__ void sg_adam_tick_kernel(float* __restrict__ step_dev) { step_dev[0] += 1.f; }
+
+extern "C" int stemgnn_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, size_t n,
+                                 const float* lr_dev, float* step_dev, float beta1, float beta2, float eps, int zero_grad,
+                                 float grad_scale, void* stream) {
+  if (!params || !grads || !exp_avg || !exp_avg_sq || !lr_dev || !step_dev || n == 0) return SG_EINVAL;
+  unsigned blocks = (unsigned)((n + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(sg_adam_kernel, dim3(blocks), dim3(256), 0, st, params, grads, exp_avg, exp_avg_sq, n, lr_dev,
+                     step_dev, beta1, beta2, eps, zero_grad, grad_scale);
+  SG_TRY(hipGetLastError());
+  hipLaunchKernelGGL(sg_adam_tick_kernel, dim3(1), dim3(1), 0, st, step_dev);
+  SG_TRY(hipGetLastError());
+  return 0;
+}

@@ -140,6 +140,9 @@ class TrainStep:
                   loss=self.loss.clone(), loss_sum=self.loss_sum.clone())
         seed = getattr(self.model, "_seed", None)
         st["seed"] = None if seed is None else seed.clone()
+        for name in ("exp_avg", "_step_dev"):                      # FusedAdam's extra state
+            t = getattr(self.opt, name, None)
+            st[name] = None if t is None else t.clone()
         return st
 
     def _restore(self, st):
@@ -147,6 +150,9 @@ class TrainStep:
         self.loss.copy_(st["loss"]); self.loss_sum.copy_(st["loss_sum"])
         if st["seed"] is not None:
             self.model._seed.copy_(st["seed"])
+        for name in ("exp_avg", "_step_dev"):
+            if st.get(name) is not None:
+                getattr(self.opt, name).copy_(st[name])
         torch.cuda.synchronize()
 
     # -- public ----------------------------------------------------------------------------------------------

@@ -70,3 +70,36 @@ class FusedRMSprop(torch.optim.Optimizer):
             self._lr_dev.data_ptr(), float(group["alpha"]), float(group["eps"]), int(self.fuse_zero_grad),
             float(self.grad_scale), torch.cuda.current_stream().cuda_stream), "rmsprop_step")
         return loss
+
+
+class FusedAdam(FusedRMSprop):
+    """``torch.optim.Adam(params, lr, betas=(0.9, 0.999))`` of the driver's other optimizer branch (models/handler.py:128-129)
+    over the same flat buffers as FusedRMSprop: one kernel (+ a one-thread step-count tick), gradient zeroing fused in,
+    lr and the step count in device memory -- so an Adam run keeps the hipGraph train step too."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, bucket=None, fuse_zero_grad=True):
+        params = [p for p in params if p.requires_grad]
+        FusedRMSprop.__init__(self, params, lr=lr, alpha=0.0, eps=eps, bucket=bucket, fuse_zero_grad=fuse_zero_grad)
+        self.param_groups[0]["betas"] = tuple(betas)
+        self.exp_avg = torch.zeros_like(self.flat_p)
+        self.exp_avg_sq = self.square_avg                       # reuse the second flat state buffer
+        self._step_dev = torch.zeros(1, device=self.flat_p.device, dtype=torch.float32)
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = closure() if closure is not None else None
+        group = self.param_groups[0]
+        self.sync_lr()
+        from .ops import join_side_streams
+        join_side_streams(self.flat_p.device)
+        for p, view in zip(self.bucket.params, self.bucket.views):
+            if p.grad is None or p.grad.data_ptr() != view.data_ptr():
+                raise _lib.StemGNNHipError("FusedAdam: a parameter's .grad is no longer the flat-bucket view "
+                                           "(use optimizer.zero_grad() or optimizer.bucket.attach())")
+        b1, b2 = group["betas"]
+        lib = _lib.load()
+        _lib.check(lib.stemgnn_adam_step(
+            self.flat_p.data_ptr(), self.bucket.flat.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
+            self.numel, self._lr_dev.data_ptr(), self._step_dev.data_ptr(), float(b1), float(b2), float(group["eps"]),
+            int(self.fuse_zero_grad), float(self.grad_scale), torch.cuda.current_stream().cuda_stream), "adam_step")
+        return loss

@@ -29,7 +29,7 @@ from .base_model import Model
 from .engine import TrainStep
 from .forecast_dataloader import ForecastDataset, WindowLoader, denorm_coefficients
 from .math_utils import Scores
-from .optim import FusedRMSprop
+from .optim import FusedAdam, FusedRMSprop
 
 BEST = "_stemgnn.pt"
 
@@ -120,8 +120,8 @@ class DeviceTrainer:
         self.model.to(device)
         if optimizer == "RMSProp":
             self.optimizer = FusedRMSprop(self.model.parameters(), lr=lr, eps=1e-8)
-        else:                                   # Adam stays the library optimizer (then no hipGraph, see TrainStep)
-            self.optimizer = torch.optim.Adam(self.model.parameters(), lr=lr, betas=(0.9, 0.999))
+        else:                                   # the driver's other branch (models/handler.py:128-129), fused as well
+            self.optimizer = FusedAdam(self.model.parameters(), lr=lr, betas=(0.9, 0.999))
         self.schedule = torch.optim.lr_scheduler.ExponentialLR(self.optimizer, gamma=decay_rate)
         self.statistic = None
         self.stepper = None
