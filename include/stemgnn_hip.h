@@ -108,6 +108,20 @@ int stemgnn_split_weights_bf16(const float* B, int N, int K, int splits, void* p
 int stemgnn_glu_gemm_bf16(const float* A, const void* planes, float* C, int M, int N, int K, int splits, void* stream);
 int stemgnn_glu_gemm_f32(const float* A, const float* B, float* C, int M, int N, int K, void* stream);
 
+/* ---- stand-alone GLU (models/base_model.py:6-13) and the general fp32 GEMM it is composed from ---------------------
+ * stemgnn_sgemm_f32: C[M,N] (+)= A B on the exact-fp32 MFMA core; element (i,k) of A at A[i*lda+k] (a_kcontig) or
+ * A[k*lda+i]; element (k,j) of B at B[j*ldb+k] (b_kcontig) or B[k*ldb+j]; accumulate != 0 adds to C.
+ * stemgnn_glu_combine_fwd: out = (U + bl) * sigmoid(V + br), saving gate = sigmoid(.) and lin = U + bl ([M,C] each);
+ * stemgnn_glu_combine_bwd: dU = dout * gate, dV = dout * lin * gate * (1 - gate);  stemgnn_colsum: out[c] = sum_m X[m][c]
+ * in a fixed order (bias gradients). */
+int stemgnn_sgemm_f32(const float* A, int lda, int a_kcontig, const float* B, int ldb, int b_kcontig, float* C, int ldc,
+                      int M, int N, int K, int accumulate, void* stream);
+int stemgnn_glu_combine_fwd(const float* U, const float* V, const float* bl, const float* br, float* out, float* gate,
+                            float* lin, int M, int C, void* stream);
+int stemgnn_glu_combine_bwd(const float* dout, const float* lin, const float* gate, float* dU, float* dV, int M, int C,
+                            void* stream);
+int stemgnn_colsum(const float* X, int M, int C, float* out, void* stream);
+
 /* ---- GRU front (models/base_model.py:92,137: nn.GRU(time_step, units) over the node axis) ------------
  * seq_len S (= N nodes), batch B, input size W, hidden size Hd (= N).  PyTorch gate order (r,z,n).
  * x [B,W,S] is the model input read in place (x_s[b,t] = x[b,t,s]); w_ih [3Hd,W], w_hh [3Hd,Hd],

@@ -39,6 +39,10 @@ SIGNATURES = {
     "stemgnn_split_weights_bf16": (c_int, [_P, c_int, c_int, c_int, _P, _P]),
     "stemgnn_glu_gemm_bf16": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "stemgnn_glu_gemm_f32": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P]),
+    "stemgnn_sgemm_f32": (c_int, [_P, c_int, c_int, _P, c_int, c_int, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+    "stemgnn_glu_combine_fwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, _P]),
+    "stemgnn_glu_combine_bwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, _P]),
+    "stemgnn_colsum": (c_int, [_P, c_int, c_int, _P, _P]),
     "stemgnn_gru_reserve_floats": (c_size_t, [c_int, c_int, c_int]),
     "stemgnn_gru_fwd_scratch_floats": (c_size_t, [c_int, c_int, c_int]),
     "stemgnn_gru_bwd_scratch_floats": (c_size_t, [c_int, c_int, c_int, c_int]),

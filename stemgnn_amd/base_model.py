@@ -27,7 +27,9 @@ _BLOCK_FIELDS = ("forecast", "forecast_result", "backcast", "backcast_short_cut"
 
 
 class GLU(nn.Module):
-    """Parameter holder for one gated linear unit (reference :6-13); arithmetic is fused into the HIP GLU kernel."""
+    """One gated linear unit (reference :6-13).  Inside StockBlockLayer / Model the arithmetic is fused into the spectral
+    GEMM epilogues and this module only holds the parameters; called on its own, ``forward`` runs the same math through
+    the stand-alone composition ``ops.GluFn`` (general fp32 MFMA GEMM + elementwise HIP kernels)."""
 
     def __init__(self, input_channel, output_channel):
         super().__init__()
@@ -35,8 +37,13 @@ class GLU(nn.Module):
         self.linear_right = nn.Linear(input_channel, output_channel)
 
     def forward(self, x):
-        raise _lib.StemGNNHipError(
-            "stemgnn_amd.GLU is evaluated inside the fused spectral kernel; call StockBlockLayer / Model instead")
+        """x [..., input_channel] -> [..., output_channel] = linear_left(x) * sigmoid(linear_right(x))   (:12-13)."""
+        if not x.is_cuda:
+            raise _lib.StemGNNHipError(f"input is on {x.device}: stemgnn_amd.GLU runs only on a HIP device (no CPU fallback)")
+        lead = x.shape[:-1]
+        out = ops.GluFn.apply(x.reshape(-1, x.shape[-1]), self.linear_left.weight, self.linear_left.bias,
+                              self.linear_right.weight, self.linear_right.bias)
+        return out.reshape(*lead, out.shape[-1])
 
 
 class StockBlockLayer(nn.Module):

@@ -220,3 +220,105 @@ extern "C" int stemgnn_glu_gemm_f32(const float* A, const float* B, float* C, in
   SG_TRY((g2_launch<SpPlainEpi, true, true, 64>(g, e, 1, (hipStream_t)stream)));
   return 0;
 }
+
+// =================================================================================================
+// Stand-alone GLU (reference models/base_model.py:6-13: linear_left(x) * sigmoid(linear_right(x))) -- the model path
+// never calls it (there the GLU is the epilogue of the fused GEMM), but the reference exposes the module, so the drop-in
+// does too: general fp32 GEMM entry (any operand orientation, optional accumulate) on the exact-fp32 core + two
+// elementwise kernels + a fixed-order column sum for the bias gradients.  Composed by stemgnn_amd.ops.GluFn.
+// =================================================================================================
+struct SpAccEpi {
+  static constexpr bool WHOLE = false;
+  float* C;
+  int ldc, accumulate;
+  __device__ void tile(int, int, int row0, int col0, int M, int N, const sg_f32x16& acc, int lane) const {
+    const int c = col0 + (lane & 31);
+    if (c >= N) return;
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      const int row = row0 + g2_row_of(reg, lane);
+      if (row < M) {
+        float* o = C + (size_t)row * ldc + c;
+        *o = accumulate ? *o + acc[reg] : acc[reg];
+      }
+    }
+  }
+};
+
+extern "C" int stemgnn_sgemm_f32(const float* A, int lda, int a_kcontig, const float* B, int ldb, int b_kcontig, float* C,
+                                 int ldc, int M, int N, int K, int accumulate, void* stream) {
+  if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || lda <= 0 || ldb <= 0 || ldc < N) return SG_EINVAL;
+  G2Args g;
+  SpAccEpi e{C, ldc, accumulate};
+  for (int r = 0; r < 2; ++r) { g.A[r] = A; g.lda[r] = lda; g.B[r] = B; g.ldb[r] = ldb; }
+  g.M[0] = M; g.N[0] = N; g.K[0] = K; g.M[1] = 0; g.N[1] = 0; g.K[1] = 0;
+  g.nsplit = 1; g.chunk = (K + 15) & ~15; g.b_ones_col = -1;
+  hipStream_t st = (hipStream_t)stream;
+  if (a_kcontig && b_kcontig) SG_TRY((g2_launch<SpAccEpi, true, true, 64>(g, e, 1, st)));
+  else if (a_kcontig) SG_TRY((g2_launch<SpAccEpi, true, false, 64>(g, e, 1, st)));
+  else if (b_kcontig) SG_TRY((g2_launch<SpAccEpi, false, true, 64>(g, e, 1, st)));
+  else SG_TRY((g2_launch<SpAccEpi, false, false, 64>(g, e, 1, st)));
+  return 0;
+}
+
+__global__ void sp_glu_combine_fwd_kernel(const float* __restrict__ U, const float* __restrict__ V,
+                                          const float* __restrict__ bl, const float* __restrict__ br, float* __restrict__ out,
+                                          float* __restrict__ gate, float* __restrict__ lin, size_t n, int C) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    const int c = (int)(i % C);
+    const float u = U[i] + bl[c];
+    const float g = 1.f / (1.f + expf(-(V[i] + br[c])));
+    out[i] = u * g;
+    gate[i] = g;
+    lin[i] = u;
+  }
+}
+__global__ void sp_glu_combine_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ lin,
+                                          const float* __restrict__ gate, float* __restrict__ dU, float* __restrict__ dV,
+                                          size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    const float d = dout[i], g = gate[i];
+    dU[i] = d * g;
+    dV[i] = d * lin[i] * g * (1.f - g);
+  }
+}
+// out[c] = sum_m X[m][c], fixed order: 64 columns x 4 row lanes per workgroup, lanes combined through LDS
+__global__ __launch_bounds__(256) void sp_colsum_kernel(const float* __restrict__ X, int M, int C, float* __restrict__ out) {
+  __shared__ float part[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
+  float s = 0.f;
+  if (c < C)
+    for (int m = q; m < M; m += 4) s += X[(size_t)m * C + c];
+  part[q][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (q == 0 && c < C) out[c] = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
+}
+
+extern "C" int stemgnn_glu_combine_fwd(const float* U, const float* V, const float* bl, const float* br, float* out,
+                                       float* gate, float* lin, int M, int C, void* stream) {
+  if (!U || !V || !bl || !br || !out || !gate || !lin || M <= 0 || C <= 0) return SG_EINVAL;
+  const size_t n = (size_t)M * C;
+  const unsigned blocks = (unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+  hipLaunchKernelGGL(sp_glu_combine_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, U, V, bl, br, out, gate, lin, n, C);
+  SG_TRY(hipGetLastError());
+  return 0;
+}
+extern "C" int stemgnn_glu_combine_bwd(const float* dout, const float* lin, const float* gate, float* dU, float* dV, int M,
+                                       int C, void* stream) {
+  if (!dout || !lin || !gate || !dU || !dV || M <= 0 || C <= 0) return SG_EINVAL;
+  const size_t n = (size_t)M * C;
+  const unsigned blocks = (unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+  hipLaunchKernelGGL(sp_glu_combine_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dout, lin, gate, dU, dV, n);
+  SG_TRY(hipGetLastError());
+  return 0;
+}
+extern "C" int stemgnn_colsum(const float* X, int M, int C, float* out, void* stream) {
+  if (!X || !out || M <= 0 || C <= 0) return SG_EINVAL;
+  hipLaunchKernelGGL(sp_colsum_kernel, dim3((C + 63) / 64), dim3(256), 0, (hipStream_t)stream, X, M, C, out);
+  SG_TRY(hipGetLastError());
+  return 0;
+}

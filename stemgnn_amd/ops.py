@@ -273,6 +273,53 @@ class FcTail(torch.autograd.Function):
         return dfsum, dw0, db0, dw2, db2, None
 
 
+class GluFn(torch.autograd.Function):
+    """Stand-alone GLU (reference models/base_model.py:6-13): x [M,K] -> (x Wl^T + bl) * sigmoid(x Wr^T + br) [M,C].
+    Inside the model the GLU is the epilogue of the fused spectral GEMMs; this composition (general fp32 GEMM entry +
+    elementwise kernels) only backs ``stemgnn_amd.GLU.forward`` for callers that use the module on its own."""
+
+    @staticmethod
+    def forward(ctx, x, wl, bl, wr, br):
+        lib = _lib.load()
+        for name, t in (("x", x), ("linear_left.weight", wl), ("linear_right.weight", wr)):
+            _require_gpu(t, name)
+        x, wl, bl, wr, br = (t.contiguous() for t in (x, wl, bl, wr, br))
+        M, K = x.shape
+        C = wl.shape[0]
+        dev, st = x.device, _stream()
+        U = torch.empty(M, C, device=dev)
+        V = torch.empty(M, C, device=dev)
+        for w, o in ((wl, U), (wr, V)):                 # x W^T: both operands k-contiguous
+            _lib.check(lib.stemgnn_sgemm_f32(x.data_ptr(), K, 1, w.data_ptr(), K, 1, o.data_ptr(), C, M, C, K, 0, st), "sgemm")
+        out, gate, lin = (torch.empty(M, C, device=dev) for _ in range(3))
+        _lib.check(lib.stemgnn_glu_combine_fwd(U.data_ptr(), V.data_ptr(), bl.data_ptr(), br.data_ptr(), out.data_ptr(),
+                                               gate.data_ptr(), lin.data_ptr(), M, C, st), "glu_combine_fwd")
+        ctx.save_for_backward(x, wl, wr, lin, gate)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib.load()
+        x, wl, wr, lin, gate = ctx.saved_tensors
+        M, K = x.shape
+        C = wl.shape[0]
+        dev, st = x.device, _stream()
+        dout = dout.contiguous()
+        dU, dV = torch.empty(M, C, device=dev), torch.empty(M, C, device=dev)
+        _lib.check(lib.stemgnn_glu_combine_bwd(dout.data_ptr(), lin.data_ptr(), gate.data_ptr(), dU.data_ptr(),
+                                               dV.data_ptr(), M, C, st), "glu_combine_bwd")
+        dx = torch.empty(M, K, device=dev)
+        dwl, dwr = torch.empty_like(wl), torch.empty_like(wr)
+        dbl, dbr = torch.empty(C, device=dev), torch.empty(C, device=dev)
+        for i, (d, w, dw, db) in enumerate(((dU, wl, dwl, dbl), (dV, wr, dwr, dbr))):
+            # dx (+)= d W : A = d [M,C] k-contiguous, B(k=c, j) = W[c*K + j] (j-contiguous)
+            _lib.check(lib.stemgnn_sgemm_f32(d.data_ptr(), C, 1, w.data_ptr(), K, 0, dx.data_ptr(), K, M, K, C, int(i > 0), st), "sgemm")
+            # dW = d^T x : A(i=c, k=m) = d[m*C + c], B(k=m, j) = x[m*K + j]
+            _lib.check(lib.stemgnn_sgemm_f32(d.data_ptr(), C, 0, x.data_ptr(), K, 0, dw.data_ptr(), K, C, K, M, 0, st), "sgemm")
+            _lib.check(lib.stemgnn_colsum(d.data_ptr(), M, C, db.data_ptr(), st), "colsum")
+        return dx, dwl, dbl, dwr, dbr
+
+
 class StockBlockFn(torch.autograd.Function):
     """One StockBlockLayer (reference models/base_model.py:61-75) as a stand-alone autograd node:
     (X [B,N,W] contiguous, mul_L [4,N,N], multi, has_backcast, 33 block params) -> (forecast [B,N,W], backcast [B,N,W]).

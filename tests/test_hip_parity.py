@@ -413,3 +413,33 @@ def test_fused_three_layer_glu_forward_matches_layerwise(shape, monkeypatch):
     ref, got = outs
     assert float(ref[G.numel():].abs().max()) > 0
     assert relerr(got, ref) < 1e-6
+
+
+@pytest.mark.parametrize("lead,cin,cout", [((7296,), 48, 240), ((3, 20), 36, 60), ((5,), 7, 9), ((2, 3, 4), 240, 240)])
+def test_glu_module_standalone(lead, cin, cout):
+    """stemgnn_amd.GLU called on its own (reference models/base_model.py:6-13): forward and every gradient against the
+    same module evaluated by torch on the CPU."""
+    from stemgnn_amd import GLU
+
+    torch.manual_seed(cin + cout)
+    glu = GLU(cin, cout)
+    x = torch.randn(*lead, cin, requires_grad=True)
+    dy = torch.randn(*lead, cout)
+    ref = glu.linear_left(x) * torch.sigmoid(glu.linear_right(x))
+    ref.backward(dy)
+    ref_grads = {k: p.grad.clone() for k, p in glu.named_parameters()}
+    dx_ref = x.grad.clone()
+    glu.zero_grad()
+    dev_glu = GLU(cin, cout)
+    dev_glu.load_state_dict(glu.state_dict())
+    dev_glu.cuda()
+    xg = x.detach().clone().cuda().requires_grad_(True)
+    out = dev_glu(xg)
+    out.backward(dy.cuda())
+    torch.cuda.synchronize()
+    assert out.shape == ref.shape
+    assert relerr(out, ref.detach()) < 1e-5 and relerr(xg.grad, dx_ref) < 1e-5
+    for k, p in dev_glu.named_parameters():
+        assert relerr(p.grad, ref_grads[k]) < 1e-5, k
+    with pytest.raises(Exception):
+        dev_glu(x.detach())                      # CPU tensor: no fallback
