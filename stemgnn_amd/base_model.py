@@ -17,7 +17,6 @@ import os
 
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from . import _lib, ops
 from .ops import FcTail, GruFront, SpectralHotPath, StockBlockFn
