@@ -16,12 +16,16 @@
     if (_e != hipSuccess) return -(int)_e;       \
   } while (0)
 
-constexpr int TAIL_MAXW = 64;    // window sizes up to 64 / horizons up to 32 keep a row in registers
-constexpr int TAIL_MAXH = 32;    // (fully unrolled, predicated loops: two instantiations, <16,4> and <64,32>)
-constexpr int TAIL_RB = 256;     // rows per backward workgroup: the fixed-order weight-gradient walk is TAIL_RB steps long
+constexpr int TAIL_MAXW = 64;    // window sizes up to 64 / horizons up to 32
+constexpr int TAIL_MAXH = 32;
+constexpr int TAIL_RB = 64;      // series rows per workgroup: 256 threads = 64 rows x 4 threads per row
 
-// forward: one thread per series row m = (b, n).  LDS: w0[W*W] | b0[W] | w2[H*W] | b2[H]
-template <int WM, int HM>
+// Both kernels: thread (r = tid & 63, q = tid >> 6) works on row r of the block and on every 4th output index
+// (t, u or h = q, q + 4, ...), rows are staged in LDS with an odd stride (W + 1: conflict-free column walks).
+// Round 1 used one thread per row with fully unrolled 16 x 16 loops and 256-row blocks (29 workgroups at PEMS07,
+// 28.6 + 7.5 us for the backward); four threads per row and 64-row blocks spread the same work over 114 workgroups.
+
+// forward.  LDS: w0[W*W] | b0[W] | w2[H*W] | b2[H] | x[64][W+1] | a[64][W+1]
 __global__ __launch_bounds__(256) void sg_fc_tail_fwd_kernel(const float* __restrict__ fsum, const float* __restrict__ w0,
                                                              const float* __restrict__ b0, const float* __restrict__ w2,
                                                              const float* __restrict__ b2, int B, int N, int W, int H,
@@ -31,38 +35,37 @@ __global__ __launch_bounds__(256) void sg_fc_tail_fwd_kernel(const float* __rest
   float* sb0 = sw0 + W * W;
   float* sw2 = sb0 + W;
   float* sb2 = sw2 + H * W;
-  for (int i = threadIdx.x; i < W * W; i += 256) sw0[i] = w0[i];
-  for (int i = threadIdx.x; i < W; i += 256) sb0[i] = b0[i];
-  for (int i = threadIdx.x; i < H * W; i += 256) sw2[i] = w2[i];
-  for (int i = threadIdx.x; i < H; i += 256) sb2[i] = b2[i];
-  __syncthreads();
-  const int m = blockIdx.x * 256 + threadIdx.x;
-  if (m >= B * N) return;
-  const int b = m / N, n = m - b * N;
-  float x[WM], a[WM];
-#pragma unroll
-  for (int t = 0; t < WM; ++t) x[t] = t < W ? fsum[(size_t)m * W + t] : 0.f;
-#pragma unroll
-  for (int t = 0; t < WM; ++t) {
-    float z = t < W ? sb0[t] : 0.f;
-#pragma unroll
-    for (int u = 0; u < WM; ++u) z = fmaf(x[u], (t < W && u < W) ? sw0[t * W + u] : 0.f, z);
-    a[t] = z > 0.f ? z : 0.01f * z;
+  float* sx = sb2 + H;
+  float* sa = sx + TAIL_RB * (W + 1);
+  const int tid = threadIdx.x, r = tid & 63, q = tid >> 6;
+  const int M = B * N, m0 = blockIdx.x * TAIL_RB, m = m0 + r;
+  for (int i = tid; i < W * W; i += 256) sw0[i] = w0[i];
+  for (int i = tid; i < W; i += 256) sb0[i] = b0[i];
+  for (int i = tid; i < H * W; i += 256) sw2[i] = w2[i];
+  for (int i = tid; i < H; i += 256) sb2[i] = b2[i];
+  for (int i = tid; i < TAIL_RB * W; i += 256) {           // coalesced: the block's rows are contiguous in fsum
+    const int rr = i / W, t = i - rr * W;
+    sx[rr * (W + 1) + t] = m0 + rr < M ? fsum[(size_t)m0 * W + i] : 0.f;
   }
-#pragma unroll
-  for (int h = 0; h < HM; ++h) {
-    if (h < H) {
+  __syncthreads();
+  for (int t = q; t < W; t += 4) {
+    float z = sb0[t];
+    for (int u = 0; u < W; ++u) z = fmaf(sx[r * (W + 1) + u], sw0[t * W + u], z);
+    sa[r * (W + 1) + t] = z > 0.f ? z : 0.01f * z;
+  }
+  __syncthreads();
+  if (m < M) {
+    const int b = m / N, n = m - b * N;
+    for (int h = q; h < H; h += 4) {
       float y = sb2[h];
-#pragma unroll
-      for (int t = 0; t < WM; ++t) y = fmaf(a[t], t < W ? sw2[h * W + t] : 0.f, y);
-      forecast[((size_t)b * H + h) * N + n] = y;      // [B,H,N]: coalesced over n
+      for (int t = 0; t < W; ++t) y = fmaf(sa[r * (W + 1) + t], sw2[h * W + t], y);
+      forecast[((size_t)b * H + h) * N + n] = y;           // [B,H,N]: coalesced over n
     }
   }
 }
 
-// backward: recomputes z (cheap) from fsum; writes dfsum and per-block partial sums of the weight gradients.
-// partial layout per block: dw0[W*W] | db0[W] | dw2[H*W] | db2[H]
-template <int WM, int HM>
+// backward: recomputes z from fsum; writes dfsum and per-block partial sums of the weight gradients.
+// partial layout per block: dw0[W*W] | db0[W] | dw2[H*W] | db2[H].   LDS: w0 | b0 | w2 | x | dz | a | dy
 __global__ __launch_bounds__(256) void sg_fc_tail_bwd_kernel(const float* __restrict__ dforecast, const float* __restrict__ fsum,
                                                              const float* __restrict__ w0, const float* __restrict__ b0,
                                                              const float* __restrict__ w2, int B, int N, int W, int H,
@@ -72,62 +75,41 @@ __global__ __launch_bounds__(256) void sg_fc_tail_bwd_kernel(const float* __rest
   float* sw0 = sm;
   float* sb0 = sw0 + W * W;
   float* sw2 = sb0 + W;
-  float* acc = sw2 + H * W;        // [nacc] block accumulators
-  for (int i = threadIdx.x; i < W * W; i += 256) sw0[i] = w0[i];
-  for (int i = threadIdx.x; i < W; i += 256) sb0[i] = b0[i];
-  for (int i = threadIdx.x; i < H * W; i += 256) sw2[i] = w2[i];
-  for (int i = threadIdx.x; i < nacc; i += 256) acc[i] = 0.f;
+  float* sx = sw2 + H * W;                 // [RB][W+1]
+  float* sdz = sx + TAIL_RB * (W + 1);     // [RB][W+1]
+  float* sa = sdz + TAIL_RB * (W + 1);     // [RB][W+1]
+  float* sdy = sa + TAIL_RB * (W + 1);     // [RB][H+1]
+  const int tid = threadIdx.x, r = tid & 63, q = tid >> 6;
+  const int M = B * N, m0 = blockIdx.x * TAIL_RB, m = m0 + r;
+  for (int i = tid; i < W * W; i += 256) sw0[i] = w0[i];
+  for (int i = tid; i < W; i += 256) sb0[i] = b0[i];
+  for (int i = tid; i < H * W; i += 256) sw2[i] = w2[i];
+  for (int i = tid; i < TAIL_RB * W; i += 256) {
+    const int rr = i / W, t = i - rr * W;
+    sx[rr * (W + 1) + t] = m0 + rr < M ? fsum[(size_t)m0 * W + i] : 0.f;
+  }
+  {
+    const int mc = m < M ? m : 0, b = mc / N, n = mc - b * N;
+    for (int h = q; h < H; h += 4) sdy[r * (H + 1) + h] = m < M ? dforecast[((size_t)b * H + h) * N + n] : 0.f;
+  }
   __syncthreads();
-  const int m = blockIdx.x * TAIL_RB + threadIdx.x;
-  const bool live = threadIdx.x < TAIL_RB && m < B * N;
-  float x[WM], a[WM], dz[WM], dy[HM];
-  if (threadIdx.x < TAIL_RB) {            // one wave: a thread per series row
-    const int mc = live ? m : 0;
-    const int b = mc / N, n = mc - b * N;
-#pragma unroll
-    for (int t = 0; t < WM; ++t) x[t] = (live && t < W) ? fsum[(size_t)mc * W + t] : 0.f;
-#pragma unroll
-    for (int h = 0; h < HM; ++h) dy[h] = (live && h < H) ? dforecast[((size_t)b * H + h) * N + n] : 0.f;
-#pragma unroll
-    for (int t = 0; t < WM; ++t) {
-      float z = t < W ? sb0[t] : 0.f;
-#pragma unroll
-      for (int u = 0; u < WM; ++u) z = fmaf(x[u], (t < W && u < W) ? sw0[t * W + u] : 0.f, z);
-      a[t] = z > 0.f ? z : 0.01f * z;
-      float da = 0.f;
-#pragma unroll
-      for (int h = 0; h < HM; ++h) da = fmaf(dy[h], (h < H && t < W) ? sw2[h * W + t] : 0.f, da);
-      dz[t] = z > 0.f ? da : 0.01f * da;
-    }
-#pragma unroll
-    for (int u = 0; u < WM; ++u) {
+  for (int t = q; t < W; t += 4) {
+    float z = sb0[t];
+    for (int u = 0; u < W; ++u) z = fmaf(sx[r * (W + 1) + u], sw0[t * W + u], z);
+    float da = 0.f;
+    for (int h = 0; h < H; ++h) da = fmaf(sdy[r * (H + 1) + h], sw2[h * W + t], da);
+    sa[r * (W + 1) + t] = m < M ? (z > 0.f ? z : 0.01f * z) : 0.f;
+    sdz[r * (W + 1) + t] = m < M ? (z > 0.f ? da : 0.01f * da) : 0.f;
+  }
+  __syncthreads();
+  if (m < M)
+    for (int u = q; u < W; u += 4) {
       float d = 0.f;
-#pragma unroll
-      for (int t = 0; t < WM; ++t) d = fmaf(dz[t], (t < W && u < W) ? sw0[t * W + u] : 0.f, d);
-      if (live && u < W) dfsum[(size_t)m * W + u] = d;
+      for (int t = 0; t < W; ++t) d = fmaf(sdz[r * (W + 1) + t], sw0[t * W + u], d);
+      dfsum[(size_t)m * W + u] = d;
     }
-  }
-  // weight-gradient partials of this block's TAIL_RB rows: stage dz / x / a / dy rows in LDS (row stride odd -> no bank
-  // conflicts), then one thread per weight element walks the rows in a fixed order (deterministic, no atomics)
-  float* sx = acc + nacc;                 // [RB][W+1]
-  float* sdz = sx + TAIL_RB * (W + 1);    // [RB][W+1]
-  float* sa = sdz + TAIL_RB * (W + 1);    // [RB][W+1]
-  float* sdy = sa + TAIL_RB * (W + 1);    // [RB][H+1]
-  if (threadIdx.x < TAIL_RB) {
-    const int rr = threadIdx.x;
-#pragma unroll
-    for (int t = 0; t < WM; ++t)
-      if (t < W) {
-        sx[rr * (W + 1) + t] = x[t];
-        sdz[rr * (W + 1) + t] = live ? dz[t] : 0.f;
-        sa[rr * (W + 1) + t] = live ? a[t] : 0.f;
-      }
-#pragma unroll
-    for (int h = 0; h < HM; ++h)
-      if (h < H) sdy[rr * (H + 1) + h] = dy[h];
-  }
-  __syncthreads();
-  for (int e = threadIdx.x; e < nacc; e += 256) {
+  // weight-gradient partials of this block's rows: one thread per weight element walks the rows in a fixed order
+  for (int e = tid; e < nacc; e += 256) {
     float sum = 0.f;
     if (e < W * W) {
       const int t = e / W, u = e - t * W;
@@ -136,7 +118,7 @@ __global__ __launch_bounds__(256) void sg_fc_tail_bwd_kernel(const float* __rest
       const int t = e - W * W;
       for (int rr = 0; rr < TAIL_RB; ++rr) sum += sdz[rr * (W + 1) + t];
     } else if (e < W * W + W + H * W) {
-      const int q = e - W * W - W, h = q / W, t = q - h * W;
+      const int qq = e - W * W - W, h = qq / W, t = qq - h * W;
       for (int rr = 0; rr < TAIL_RB; ++rr) sum = fmaf(sdy[rr * (H + 1) + h], sa[rr * (W + 1) + t], sum);
     } else {
       const int h = e - W * W - W - H * W;
@@ -146,22 +128,29 @@ __global__ __launch_bounds__(256) void sg_fc_tail_bwd_kernel(const float* __rest
   }
 }
 
-__global__ void sg_fc_tail_reduce_kernel(const float* __restrict__ partial, int nblocks, int W, int H, float* __restrict__ dw0,
-                                         float* __restrict__ db0, float* __restrict__ dw2, float* __restrict__ db2) {
+// fixed-order sum of the per-block partials; 4 lanes per element walk interleaved blocks, combined in a fixed order
+__global__ __launch_bounds__(256) void sg_fc_tail_reduce_kernel(const float* __restrict__ partial, int nblocks, int W, int H,
+                                                                float* __restrict__ dw0, float* __restrict__ db0,
+                                                                float* __restrict__ dw2, float* __restrict__ db2) {
+  __shared__ float red[4][64];
   const int nacc = W * W + W + H * W + H;
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= nacc) return;
+  const int i = blockIdx.x * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
   float s = 0.f;
-  for (int b = 0; b < nblocks; ++b) s += partial[(size_t)b * nacc + i];
+  if (i < nacc)
+    for (int b = q; b < nblocks; b += 4) s += partial[(size_t)b * nacc + i];
+  red[q][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (q != 0 || i >= nacc) return;
+  s = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
   if (i < W * W) dw0[i] = s;
   else if (i < W * W + W) db0[i - W * W] = s;
   else if (i < W * W + W + H * W) dw2[i - W * W - W] = s;
   else db2[i - W * W - W - H * W] = s;
 }
 
+static size_t fc_tail_fwd_lds(int W, int H) { return (size_t)(W * W + W + H * W + H + 2 * TAIL_RB * (W + 1)) * sizeof(float); }
 static size_t fc_tail_bwd_lds(int W, int H) {
-  const int nacc = W * W + W + H * W + H;
-  return (size_t)(W * W + W + H * W + nacc + TAIL_RB * (3 * (W + 1) + H + 1)) * sizeof(float);
+  return (size_t)(W * W + W + H * W + TAIL_RB * (3 * (W + 1) + H + 1)) * sizeof(float);
 }
 extern "C" int stemgnn_fc_tail_supported(int W, int H) {
   return W > 0 && H > 0 && W <= TAIL_MAXW && H <= TAIL_MAXH && fc_tail_bwd_lds(W, H) <= 150 * 1024;
@@ -174,13 +163,14 @@ extern "C" int stemgnn_fc_tail_fwd(const float* fsum, const float* w0, const flo
                                    int B, int N, int W, int H, float* forecast, void* stream) {
   if (!fsum || !w0 || !b0 || !w2 || !b2 || !forecast || B <= 0 || N <= 0 || !stemgnn_fc_tail_supported(W, H))
     return SG_EINVAL;
-  const size_t lds = (size_t)(W * W + W + H * W + H) * sizeof(float);
-  if (W <= 16 && H <= 4)
-    hipLaunchKernelGGL((sg_fc_tail_fwd_kernel<16, 4>), dim3((B * N + 255) / 256), dim3(256), lds, (hipStream_t)stream, fsum,
-                       w0, b0, w2, b2, B, N, W, H, forecast);
-  else
-    hipLaunchKernelGGL((sg_fc_tail_fwd_kernel<64, 32>), dim3((B * N + 255) / 256), dim3(256), lds, (hipStream_t)stream, fsum,
-                       w0, b0, w2, b2, B, N, W, H, forecast);
+  const size_t lds = fc_tail_fwd_lds(W, H);
+  static bool attr_done = false;
+  if (!attr_done && lds > 64 * 1024) {
+    SG_TRY(hipFuncSetAttribute((const void*)sg_fc_tail_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(sg_fc_tail_fwd_kernel, dim3((B * N + TAIL_RB - 1) / TAIL_RB), dim3(256), lds, (hipStream_t)stream, fsum,
+                     w0, b0, w2, b2, B, N, W, H, forecast);
   SG_TRY(hipGetLastError());
   return 0;
 }
@@ -198,18 +188,13 @@ extern "C" int stemgnn_fc_tail_bwd(const float* dforecast, const float* fsum, co
   if (!stemgnn_fc_tail_supported(W, H)) return SG_EINVAL;
   static bool attr_done = false;
   if (!attr_done && lds > 64 * 1024) {
-    SG_TRY(hipFuncSetAttribute((const void*)sg_fc_tail_bwd_kernel<64, 32>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                               150 * 1024));
+    SG_TRY(hipFuncSetAttribute((const void*)sg_fc_tail_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     attr_done = true;
   }
-  if (W <= 16 && H <= 4)
-    hipLaunchKernelGGL((sg_fc_tail_bwd_kernel<16, 4>), dim3(nblocks), dim3(256), lds, st, dforecast, fsum, w0, b0, w2, B, N,
-                       W, H, dfsum, scratch);
-  else
-    hipLaunchKernelGGL((sg_fc_tail_bwd_kernel<64, 32>), dim3(nblocks), dim3(256), lds, st, dforecast, fsum, w0, b0, w2, B, N,
-                       W, H, dfsum, scratch);
+  hipLaunchKernelGGL(sg_fc_tail_bwd_kernel, dim3(nblocks), dim3(256), lds, st, dforecast, fsum, w0, b0, w2, B, N, W, H, dfsum,
+                     scratch);
   SG_TRY(hipGetLastError());
-  hipLaunchKernelGGL(sg_fc_tail_reduce_kernel, dim3((nacc + 255) / 256), dim3(256), 0, st, scratch, nblocks, W, H, dw0,
+  hipLaunchKernelGGL(sg_fc_tail_reduce_kernel, dim3((nacc + 63) / 64), dim3(256), 0, st, scratch, nblocks, W, H, dw0,
                      db0, dw2, db2);
   SG_TRY(hipGetLastError());
   return 0;
