@@ -118,6 +118,24 @@ __global__ void sg_mse_final_kernel(const float* __restrict__ part, int nparts, 
   }
 }
 
+// small inputs (one training batch: B*H*N = 21,888 values at PEMS07): ONE workgroup, one launch -- the two-stage
+// reduction above costs a second kernel boundary on the critical path for nothing
+__global__ __launch_bounds__(1024) void sg_mse_small_kernel(const float* __restrict__ f, const float* __restrict__ y, size_t n,
+                                                            float* __restrict__ loss, double* __restrict__ accum) {
+  __shared__ float sm[16];
+  float acc = 0.f;
+  for (size_t i = threadIdx.x; i < n; i += 1024) {
+    const float d = f[i] - y[i];
+    acc = fmaf(d, d, acc);
+  }
+  const float t = sg_block_sum(acc, sm);
+  if (threadIdx.x == 0) {
+    const float l = t / (float)n;
+    loss[0] = l;
+    if (accum) accum[0] += (double)l;
+  }
+}
+
 __global__ void sg_mse_bwd_kernel(const float* __restrict__ f, const float* __restrict__ y, size_t n,
                                   const float* __restrict__ gout, float* __restrict__ df) {
   const float s = 2.f * gout[0] / (float)n;
@@ -130,6 +148,11 @@ extern "C" size_t stemgnn_mse_scratch_floats(void) { return MSE_BLOCKS; }
 extern "C" int stemgnn_mse_fwd(const float* forecast, const float* target, size_t n, float* scratch, float* loss,
                                double* loss_accum, void* stream) {
   if (!forecast || !target || !scratch || !loss || n == 0) return SG_EINVAL;
+  if (n <= (size_t)1 << 16) {
+    hipLaunchKernelGGL(sg_mse_small_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, forecast, target, n, loss, loss_accum);
+    SG_TRY(hipGetLastError());
+    return 0;
+  }
   hipLaunchKernelGGL(sg_mse_partial_kernel, dim3(MSE_BLOCKS), dim3(MSE_THREADS), 0, (hipStream_t)stream, forecast,
                      target, n, scratch);
   SG_TRY(hipGetLastError());

@@ -7,6 +7,7 @@
 // These stages are HBM/LDS-bound (O(B N^2) exp + O(N^2) elementwise); only the two N^3 Chebyshev
 // products run on MFMA.
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include <stdint.h>
 
 #include "../../include/stemgnn_hip.h"
@@ -484,6 +485,15 @@ extern "C" int stemgnn_cheb_fwd(float* mul_L, int N, void* stream) {
   const size_t nn = (size_t)N * N;
   float* L = mul_L + nn;
   ChebFwdOp op2{L, L, mul_L + 2 * nn, N, 0};
+  // small N: the products are a chain of dependent load -> LDS -> MFMA rounds; BK = 128 halves the number of rounds
+  // (STEMGNN_CHEB_BK=64 restores the round-1 tiles)
+  static const bool bk128 = !(getenv("STEMGNN_CHEB_BK") && atoi(getenv("STEMGNN_CHEB_BK")) == 64);
+  if (bk128 && N <= 512) {
+    SG_TRY((sg_launch_gemm<ChebFwdOp, 32, 32, true, false, false, 128, true>(op2, N, N, 1, st)));
+    ChebFwdOp op3b{L, mul_L + 2 * nn, mul_L + 3 * nn, N, 1};
+    SG_TRY((sg_launch_gemm<ChebFwdOp, 32, 32, true, false, false, 128, true>(op3b, N, N, 1, st)));
+    return 0;
+  }
   SG_TRY((sg_launch_gemm<ChebFwdOp, 32, 32, true, false, false, 64, true>(op2, N, N, 1, st)));
   ChebFwdOp op3{L, mul_L + 2 * nn, mul_L + 3 * nn, N, 1};
   SG_TRY((sg_launch_gemm<ChebFwdOp, 32, 32, true, false, false, 64, true>(op3, N, N, 1, st)));
@@ -498,6 +508,13 @@ extern "C" int stemgnn_cheb_bwd(const float* mul_L, const float* dmul_L, float* 
   float* dLp = scratch;
   float* dT2p = scratch + nn;
   ChebBwd1Op op1{mul_L + nn, mul_L + 2 * nn, dmul_L + nn, dmul_L + 2 * nn, dmul_L + 3 * nn, dLp, dT2p, N};
+  static const bool bk128 = !(getenv("STEMGNN_CHEB_BK") && atoi(getenv("STEMGNN_CHEB_BK")) == 64);
+  if (bk128 && N <= 512) {
+    SG_TRY((sg_launch_gemm<ChebBwd1Op, 32, 32, true, true, false, 128, true>(op1, N, N, 2, st)));
+    ChebBwd2Op op2b{mul_L + nn, dT2p, dLp, dL, N};
+    SG_TRY((sg_launch_gemm<ChebBwd2Op, 32, 32, true, true, false, 128, true>(op2b, N, N, 1, st)));
+    return 0;
+  }
   SG_TRY((sg_launch_gemm<ChebBwd1Op, 32, 32, true, true, false, 64, true>(op1, N, N, 2, st)));
   ChebBwd2Op op2{mul_L + nn, dT2p, dLp, dL, N};
   SG_TRY((sg_launch_gemm<ChebBwd2Op, 32, 32, true, true, false, 64, true>(op2, N, N, 1, st)));
