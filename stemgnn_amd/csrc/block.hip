@@ -586,6 +586,11 @@ static inline int g2_bm_mask() {
   static const int m = getenv("STEMGNN_G2_BM64") ? atoi(getenv("STEMGNN_G2_BM64")) : 3;   // measured: 1.921 -> 1.890 ms/step
   return m;
 }
+// small graph products (N <= 512) with 128-deep K tiles; STEMGNN_CHEB_BK=64 restores the round-1 tiles
+static inline bool sg_small_bk128() {
+  static const bool on = !(getenv("STEMGNN_CHEB_BK") && atoi(getenv("STEMGNN_CHEB_BK")) == 64);
+  return on;
+}
 // which GLU GEMM families use 32-deep LDS stages (gemm2.h BK = 32, 64-row tiles only): bit 0 forward, 1 data gradient,
 // 2 weight gradient
 static inline int g2_bk32_mask() {
@@ -601,6 +606,11 @@ extern "C" int stemgnn_gft_fwd(const float* mul_L, const float* X, long xs_b, lo
   if (!mul_L || !X || !G || B <= 0 || N <= 0 || W <= 0) return SG_EINVAL;
   GftFwdOp op{mul_L + (size_t)N * N, XView{X, xs_b, xs_n, xs_t, N}, G, B, N, W};
   hipStream_t st = (hipStream_t)stream;
+  if (sg_small_bk128() && N <= 512) {       // latency-bound at small N: half as many load -> LDS -> MFMA rounds
+    if (xs_n == 1) SG_TRY((sg_launch_gemm<GftFwdOp, 32, 32, true, true, false, 128, true>(op, 3 * N, B * W, 1, st)));
+    else SG_TRY((sg_launch_gemm<GftFwdOp, 32, 32, true, false, false, 128, true>(op, 3 * N, B * W, 1, st)));
+    return 0;
+  }
   if (xs_n == 1) SG_TRY((sg_launch_gemm<GftFwdOp, 32, 64, true, true, false, 64, true>(op, 3 * N, B * W, 1, st)));
   else SG_TRY((sg_launch_gemm<GftFwdOp, 32, 64, true, false, false, 64, true>(op, 3 * N, B * W, 1, st)));
   return 0;
@@ -611,11 +621,18 @@ extern "C" int stemgnn_gft_bwd(const float* mul_L, const float* X, long xs_b, lo
                                int B, int N, int W, void* stream) {
   if (!mul_L || !X || !dG || !dmul_L || B <= 0 || N <= 0 || W <= 0) return SG_EINVAL;
   hipStream_t st = (hipStream_t)stream;
+  const bool bk128 = sg_small_bk128() && N <= 512;
   if (dX) {
     GftBwdDxOp op{mul_L + (size_t)N * N, dG, dX, B, N, W, (size_t)B * N * 3 * W};
-    SG_TRY((sg_launch_gemm<GftBwdDxOp, 32, 32, false, false, false, 64, true>(op, N, B * W, 1, st)));
+    if (bk128) SG_TRY((sg_launch_gemm<GftBwdDxOp, 32, 32, false, false, false, 128, true>(op, N, B * W, 1, st)));
+    else SG_TRY((sg_launch_gemm<GftBwdDxOp, 32, 32, false, false, false, 64, true>(op, N, B * W, 1, st)));
   }
   GftBwdDtOp op{dG, XView{X, xs_b, xs_n, xs_t, N}, dmul_L + (size_t)N * N, B, N, W, accumulate, (size_t)B * N * 3 * W};
+  if (bk128) {
+    if (xs_t == 1) SG_TRY((sg_launch_gemm<GftBwdDtOp, 32, 32, true, true, false, 128, true>(op, 3 * N, N, 1, st)));
+    else SG_TRY((sg_launch_gemm<GftBwdDtOp, 32, 32, true, false, false, 128, true>(op, 3 * N, N, 1, st)));
+    return 0;
+  }
   if (xs_t == 1) SG_TRY((sg_launch_gemm<GftBwdDtOp, 32, 32, true, true, false, 64, true>(op, 3 * N, N, 1, st)));
   else SG_TRY((sg_launch_gemm<GftBwdDtOp, 32, 32, true, false, false, 64, true>(op, 3 * N, N, 1, st)));
   return 0;
