@@ -452,20 +452,52 @@ __device__ __forceinline__ float gru_bcast(float v, int src_lane) {     // wave 
 // v_pk_fma_f32 (weights in a VGPR pair, the two broadcast h values in an SGPR pair): 1.5 instructions per k instead
 // of 2, and the loop stops at KU instead of 64 -- the recurrence step is VALU- and exchange-latency bound.
 typedef float gru_f2 __attribute__((ext_vector_type(2)));
-template <int KU>
-__device__ __forceinline__ float gru_matvec(const gru_f2 (&wr)[32], float hv) {
+// Where the broadcast values come from.  A v_readlane per k makes the mat-vec VALU-issue bound (3 waves per SIMD, 1.5
+// instructions per k), so only the first NR k's of a slice are broadcast that way; the wave drops its 64 polled values
+// into a private LDS row and every lane reads the others back with ds_read_b128 (identical address = broadcast, 4 k's
+// per instruction, LDS pipe instead of VALU).  The k order of the two accumulation chains is unchanged, so the sums
+// are bit-identical for every NR; the reads are issued first and land while the readlane part runs.
+#ifndef GRU_NR_FWD
+#define GRU_NR_FWD 8
+#endif
+#ifndef GRU_NR_BWD
+#define GRU_NR_BWD 16
+#endif
+// the LDS rows cost up to 4 * ceil((KU - NR) / 4) VGPRs: only where the register budget of the launch shape has room
+// (<= 12 waves per workgroup for the per-(gate, owner) kernels; the three-gate forward holds 3 * KU weights already)
+#define GRU_NR2(P, OW) (((OW) == 1 && (P) <= 4) ? GRU_NR_BWD : 64)
+#define GRU_NR3(KU) ((KU) <= 58 ? GRU_NR_FWD : 32)
+template <int KU, int NR>
+struct GruBcast {
+  static constexpr int NRK = NR < KU ? (NR & ~3) : ((KU + 3) & ~3);     // k < NRK: readlane
+  static constexpr int NL = NRK < KU ? (KU - NRK + 3) / 4 : 0;          // float4 broadcast reads for k >= NRK
+  float4 v[NL > 0 ? NL : 1];
+  float hv;
+  __device__ __forceinline__ GruBcast(float hv_, float* lrow, int lane) : hv(hv_) {
+    if constexpr (NL > 0) {
+      lrow[lane] = hv_;
+      asm volatile("" ::: "memory");                 // program order is enough: one wave's LDS operations complete in order
+#pragma unroll
+      for (int i = 0; i < NL; ++i) v[i] = *reinterpret_cast<const float4*>(lrow + NRK + 4 * i);
+      __builtin_amdgcn_sched_barrier(0);             // all reads in flight before the readlane part starts
+    }
+  }
+  __device__ __forceinline__ gru_f2 pair(int kk) const {      // {h[kk], h[kk+1]}, kk even and compile-time constant
+    if (kk < NRK) return gru_f2{gru_bcast(hv, kk), gru_bcast(hv, kk + 1)};
+    const float4 t = v[NL > 0 ? (kk - NRK) >> 2 : 0];
+    return ((kk - NRK) & 2) ? gru_f2{t.z, t.w} : gru_f2{t.x, t.y};
+  }
+};
+template <int KU, int NR>
+__device__ __forceinline__ float gru_matvec(const gru_f2 (&wr)[32], float hv, float* lrow, int lane) {
+  const GruBcast<KU, NR> bc(hv, lrow, lane);
   gru_f2 a0 = {0.f, 0.f}, a1 = {0.f, 0.f};
 #pragma unroll
   for (int kk = 0; kk + 3 < KU; kk += 4) {
-    const gru_f2 h0 = {gru_bcast(hv, kk), gru_bcast(hv, kk + 1)};
-    const gru_f2 h1 = {gru_bcast(hv, kk + 2), gru_bcast(hv, kk + 3)};
-    a0 = __builtin_elementwise_fma(wr[kk >> 1], h0, a0);
-    a1 = __builtin_elementwise_fma(wr[(kk >> 1) + 1], h1, a1);
+    a0 = __builtin_elementwise_fma(wr[kk >> 1], bc.pair(kk), a0);
+    a1 = __builtin_elementwise_fma(wr[(kk >> 1) + 1], bc.pair(kk + 2), a1);
   }
-  if constexpr ((KU & 3) != 0) {
-    const gru_f2 h0 = {gru_bcast(hv, KU - 2), gru_bcast(hv, KU - 1)};
-    a0 = __builtin_elementwise_fma(wr[(KU - 2) >> 1], h0, a0);
-  }
+  if constexpr ((KU & 3) != 0) a0 = __builtin_elementwise_fma(wr[(KU - 2) >> 1], bc.pair(KU - 2), a0);
   return (a0.x + a1.x) + (a0.y + a1.y);
 }
 __device__ __forceinline__ float gru_poll_lane(const gru_u64* g, unsigned tag, bool active, int* status) {
@@ -485,6 +517,7 @@ __global__ __launch_bounds__(3 * (P / OW) * 64) void gru_fwd_cluster2_kernel(con
                                                                       gru_u64* __restrict__ xid, int allow_fast) {
   static_assert(P % OW == 0, "owners per wave");
   __shared__ float part[2][3 * P][64];
+  __shared__ __attribute__((aligned(16))) float lrow[3 * P][64];   // per-wave broadcast rows (GruBcast)
   __shared__ int s_fast;
   int b, p;
   gru_cluster_ids(B, P, b, p);
@@ -527,7 +560,7 @@ __global__ __launch_bounds__(3 * (P / OW) * 64) void gru_fwd_cluster2_kernel(con
       if (wave == 0 && o == 0) hv = hown;                 // own slice: h_{s-1} of unit `lane` is this lane's register
       else if (s > 0) hv = gru_poll_lane(xbuf + ((size_t)(s & 1) * B + b) * Hd + k0[o] + (lane < kn[o] ? lane : 0),
                                          (unsigned)s, lane < kn[o], status);
-      part[s & 1][g * P + q0 + o][lane] = gru_matvec<KU>(wr[o], hv);
+      part[s & 1][g * P + q0 + o][lane] = gru_matvec<KU, GRU_NR2(P, OW)>(wr[o], hv, lrow[wave * OW + o], lane);
     }
     gru_lds_barrier();
     if (tid < un) {
@@ -557,6 +590,137 @@ __global__ __launch_bounds__(3 * (P / OW) * 64) void gru_fwd_cluster2_kernel(con
   }
 }
 
+// -DGRU_PROF builds (tools/gpu_job_r2m.sh): cycle counters of the phases of one recurrence step, summed over the steps
+// and printed by workgroup 0 (lane 0 of wave 0 = the gate-phase wave, lane 0 of wave 1 = a polling wave)
+#ifdef GRU_PROF
+#define GRU_T(var) const long long var = (long long)__builtin_readcyclecounter()
+#define GRU_ACC(acc, t1, t0) acc += (t1) - (t0)
+#else
+#define GRU_T(var)
+#define GRU_ACC(acc, t1, t0)
+#endif
+// Forward, one wave per OWNER slice (P <= 5): wave q holds the rows of all three gates for the k-slice of owner q
+// (3 * KU weights per lane) and broadcasts each polled h value ONCE for the three gates -- 1 v_readlane + 1.5 v_pk_fma
+// per k instead of 3 + 1.5 on three waves.  The mat-vec of a step is VALU-issue bound (12 waves on 4 SIMDs before, P
+// waves now); each gate's sum is formed in exactly the order gru_matvec uses, so the results are bit-identical.
+template <int KU, int NR>
+__device__ __forceinline__ void gru_matvec3(const gru_f2 (&w0)[32], const gru_f2 (&w1)[32], const gru_f2 (&w2)[32],
+                                            float hv, float* lrow, int lane, float& o0, float& o1, float& o2) {
+  const GruBcast<KU, NR> bc(hv, lrow, lane);
+  gru_f2 a0 = {0.f, 0.f}, b0 = {0.f, 0.f}, a1 = {0.f, 0.f}, b1 = {0.f, 0.f}, a2 = {0.f, 0.f}, b2 = {0.f, 0.f};
+#pragma unroll
+  for (int kk = 0; kk + 3 < KU; kk += 4) {
+    const gru_f2 h0 = bc.pair(kk), h1 = bc.pair(kk + 2);
+    a0 = __builtin_elementwise_fma(w0[kk >> 1], h0, a0);
+    a1 = __builtin_elementwise_fma(w1[kk >> 1], h0, a1);
+    a2 = __builtin_elementwise_fma(w2[kk >> 1], h0, a2);
+    b0 = __builtin_elementwise_fma(w0[(kk >> 1) + 1], h1, b0);
+    b1 = __builtin_elementwise_fma(w1[(kk >> 1) + 1], h1, b1);
+    b2 = __builtin_elementwise_fma(w2[(kk >> 1) + 1], h1, b2);
+  }
+  if constexpr ((KU & 3) != 0) {
+    const gru_f2 h0 = bc.pair(KU - 2);
+    a0 = __builtin_elementwise_fma(w0[(KU - 2) >> 1], h0, a0);
+    a1 = __builtin_elementwise_fma(w1[(KU - 2) >> 1], h0, a1);
+    a2 = __builtin_elementwise_fma(w2[(KU - 2) >> 1], h0, a2);
+  }
+  o0 = (a0.x + b0.x) + (a0.y + b0.y);
+  o1 = (a1.x + b1.x) + (a1.y + b1.y);
+  o2 = (a2.x + b2.x) + (a2.y + b2.y);
+}
+template <int P, int KU>
+__global__ __launch_bounds__(P * 64) void gru_fwd_cluster3_kernel(const float* __restrict__ gi, const float* __restrict__ w_hh,
+                                                                  const float* __restrict__ b_hh, int B, int S, int Hd,
+                                                                  gru_u64* __restrict__ xbuf, int* __restrict__ status,
+                                                                  float* __restrict__ h_all, float* __restrict__ reserve,
+                                                                  gru_u64* __restrict__ xid, int allow_fast) {
+  __shared__ float part[2][3 * P][64];
+  __shared__ __attribute__((aligned(16))) float lrow[P][64];       // per-wave broadcast rows (GruBcast)
+  __shared__ int s_fast;
+  int b, p;
+  gru_cluster_ids(B, P, b, p);
+  if (b >= B) return;
+  const bool fast = P > 1 && gru_same_xcd(xid + (size_t)b * P, p, P, allow_fast, status, &s_fast, threadIdx.x);
+  const int U = (Hd + P - 1) / P;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int q = gru_uniform(tid >> 6);                  // wave = owner slot, rotated by p: wave 0 multiplies the OWN units
+  const int u0 = p * U, un = max(0, min(Hd, u0 + U) - u0);
+  const int H3 = 3 * Hd;
+  const int k0 = ((q + p) % P) * U, kn = max(0, min(Hd, k0 + U) - k0);
+  gru_f2 wr[3][32];
+  {
+    const bool lane_ok = lane < un;
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+      const float* wrow = w_hh + ((size_t)g * Hd + (lane_ok ? u0 + lane : 0)) * Hd + (kn > 0 ? k0 : 0);
+#pragma unroll
+      for (int kk = 0; kk < KU; ++kk) {
+        const float v = wrow[kk < kn ? kk : 0];
+        wr[g][kk >> 1][kk & 1] = (lane_ok && kk < kn) ? v : 0.f;
+      }
+    }
+  }
+  const int gu = u0 + (tid < un ? tid : 0);
+  const float bh0 = b_hh[gu], bh1 = b_hh[Hd + gu], bh2 = b_hh[2 * Hd + gu];
+  float hown = 0.f;
+
+#ifdef GRU_PROF
+  long long c_poll = 0, c_mv = 0, c_bar = 0, c_gate = 0;
+#endif
+  for (int s = 0; s < S; ++s) {
+    const size_t row = (size_t)s * B + b;
+    const float* gip = gi + row * H3;
+    const float gp0 = gip[gu], gp1 = gip[Hd + gu], gp2 = gip[2 * Hd + gu];     // prefetch for the gate phase
+    GRU_T(t0);
+    {
+      float hv = 0.f;
+      if (q == 0) hv = hown;
+      else if (s > 0) hv = gru_poll_lane(xbuf + ((size_t)(s & 1) * B + b) * Hd + k0 + (lane < kn ? lane : 0), (unsigned)s,
+                                         lane < kn, status);
+      GRU_T(t1);                                          // (the poll has returned: its value was compared)
+      GRU_ACC(c_poll, t1, t0);
+      float o0, o1, o2;
+      gru_matvec3<KU, GRU_NR3(KU)>(wr[0], wr[1], wr[2], hv, lrow[q], lane, o0, o1, o2);
+      part[s & 1][0 * P + q][lane] = o0;
+      part[s & 1][1 * P + q][lane] = o1;
+      part[s & 1][2 * P + q][lane] = o2;
+#ifdef GRU_PROF
+      GRU_T(t2);
+      GRU_ACC(c_mv, t2, t1);
+#endif
+    }
+    GRU_T(t3);
+    gru_lds_barrier();
+    GRU_T(t4);
+    GRU_ACC(c_bar, t4, t3);
+    if (tid < un) {
+      float g0 = bh0, g1 = bh1, g2 = bh2;
+#pragma unroll
+      for (int qq = 0; qq < P; ++qq) {
+        g0 += part[s & 1][0 * P + qq][tid];
+        g1 += part[s & 1][1 * P + qq][tid];
+        g2 += part[s & 1][2 * P + qq][tid];
+      }
+      const float r = gru_sigmoid(gp0 + g0);
+      const float z = gru_sigmoid(gp1 + g1);
+      const float n = tanhf(gp2 + r * g2);
+      const float hn = (1.f - z) * n + z * hown;
+      hown = hn;
+      if (s + 1 < S) gru_publish_x(xbuf + ((size_t)((s + 1) & 1) * B + b) * Hd + gu, (unsigned)(s + 1), hn, fast);
+      GRU_T(t5);
+      GRU_ACC(c_gate, t5, t4);
+      float* rs = reserve + row * 4 * Hd;
+      rs[gu] = r; rs[Hd + gu] = z; rs[2 * Hd + gu] = n; rs[3 * Hd + gu] = g2;
+      h_all[row * Hd + gu] = hn;
+    }
+  }
+#ifdef GRU_PROF
+  if (blockIdx.x == 0 && lane == 0)
+    printf("gru fwd3 wave %d: per step cycles: poll/own %lld  matvec %lld  barrier wait %lld  gate phase %lld  (S=%d)\n", q,
+           c_poll / S, c_mv / S, c_bar / S, c_gate / S, S);
+#endif
+}
+
 // backward.  LDS: part[2][3*P][64].  Wave (g, q): reduction slice j = g*Hd + units of owner q.
 template <int P, int KU, int OW>
 __global__ __launch_bounds__(3 * (P / OW) * 64) void gru_bwd_cluster2_kernel(const float* __restrict__ dout, const float* __restrict__ w_hh,
@@ -574,6 +738,7 @@ __global__ __launch_bounds__(3 * (P / OW) * 64) void gru_bwd_cluster2_kernel(con
   static_assert(P % OW == 0, "owners per wave");
   constexpr int NTH = 3 * (P / OW) * 64;
   __shared__ float part[2][3 * P][64];
+  __shared__ __attribute__((aligned(16))) float lrow[3 * P][64];   // per-wave broadcast rows (GruBcast)
   __shared__ int s_fast;
   int b, p;
   gru_cluster_ids(B, P, b, p);
@@ -611,11 +776,15 @@ __global__ __launch_bounds__(3 * (P / OW) * 64) void gru_bwd_cluster2_kernel(con
   float p_h = h_all[(s_hi > 0 ? prow - B : prow) * Hd + gu];
   __syncthreads();
 
+#ifdef GRU_PROF
+  long long c_poll = 0, c_mv = 0, c_bar = 0, c_gate = 0;
+#endif
   for (int s = s_hi; s >= s_lo; --s) {
     const size_t row = (size_t)s * B + b;
     const unsigned tag = (unsigned)(S - s);
     gru_u64* xb = xbuf + ((size_t)(tag & 1) * B + b) * H3;
     float own_dr = 0.f;
+    GRU_T(t0);
     if (tid < un) {
       float dh = p_do + dhz;
 #pragma unroll
@@ -643,14 +812,27 @@ __global__ __launch_bounds__(3 * (P / OW) * 64) void gru_bwd_cluster2_kernel(con
       dghn[row * Hd + gu] = dnr;
     }
     if (s == 0) break;
+    GRU_T(t1);
+    GRU_ACC(c_gate, t1, t0);
 #pragma unroll
     for (int o = 0; o < OW; ++o) {
       float dv;
       if (wave == 0 && o == 0) dv = own_dr;               // gate r, own units: computed by this lane a moment ago
       else dv = gru_poll_lane(xb + (size_t)g * Hd + k0[o] + (lane < kn[o] ? lane : 0), tag, lane < kn[o], status);
-      part[tag & 1][g * P + q0 + o][lane] = gru_matvec<KU>(wr[o], dv);
+#ifdef GRU_PROF
+      GRU_T(t2);
+      GRU_ACC(c_poll, t2, t1);
+#endif
+      part[tag & 1][g * P + q0 + o][lane] = gru_matvec<KU, GRU_NR2(P, OW)>(wr[o], dv, lrow[wave * OW + o], lane);
+#ifdef GRU_PROF
+      GRU_T(t3);
+      GRU_ACC(c_mv, t3, t2);
+#endif
     }
+    GRU_T(t4);
     gru_lds_barrier();
+    GRU_T(t5);
+    GRU_ACC(c_bar, t5, t4);
     if (s == s_mark) {
       // progress mark: every gate-gradient row of the steps >= s_mark is written.  Publish them to kernels of OTHER
       // streams while this one keeps running: drain, write the XCD's dirty L2 lines back (agent-scope release), count.
@@ -665,6 +847,11 @@ __global__ __launch_bounds__(3 * (P / OW) * 64) void gru_bwd_cluster2_kernel(con
       }
     }
   }
+#ifdef GRU_PROF
+  if (blockIdx.x == 0 && lane == 0)
+    printf("gru bwd2 wave %d: per step cycles: gate phase %lld  poll/own %lld  matvec %lld  barrier wait %lld  (S=%d)\n", wave,
+           c_gate / S, c_poll / S, c_mv / S, c_bar / S, S);
+#endif
   if (s_lo > 0 && tid < un) {                             // hand the recurrent part of dh_{s_lo - 1} to the next segment
     const unsigned tag = (unsigned)(S - s_lo);
     float c = dhz;
@@ -736,10 +923,19 @@ __global__ void gru_reduce_grad_kernel(const GruReduceJobs J, int nsplit) {
 }
 
 // =================================================================================================
-static const int GRU_NSPLIT = 32;
+#include <stdlib.h>
+// split-K slabs of the weight-gradient GEMMs (fixed-order reduce afterwards); STEMGNN_GRU_NSPLIT in [8, 64] for A/B runs
+static int gru_nsplit() {
+  static const int v = [] {
+    const char* e = getenv("STEMGNN_GRU_NSPLIT");
+    const int n = e ? atoi(e) : 32;
+    return n < 8 ? 8 : (n > 64 ? 64 : n);
+  }();
+  return v;
+}
+#define GRU_NSPLIT gru_nsplit()
 
 extern "C" size_t stemgnn_gru_reserve_floats(int B, int S, int Hd) { return (size_t)4 * S * B * Hd; }
-#include <stdlib.h>
 // cluster size: smallest P in {1,2,4,8} whose per-lane weight slice fits the register budget; 0 = use the
 // single-workgroup streaming kernels (very wide hidden states, or STEMGNN_GRU_CLUSTER=0)
 #define GRU_KC 48       // resident weights per lane (registers); the per-step loops are fully unrolled over it
@@ -788,7 +984,7 @@ template <int P>
 static size_t gru_lds_hog(const void* fn) {
   static const bool on = !(getenv("STEMGNN_GRU_LDS_HOG") && atoi(getenv("STEMGNN_GRU_LDS_HOG")) == 0);
   if (!on) return 0;
-  const size_t bytes = (size_t)156 * 1024 - sizeof(float) * 2 * 3 * P * 64;
+  const size_t bytes = (size_t)156 * 1024 - sizeof(float) * 3 * 3 * P * 64;      // static: part[2][3P][64] + lrow[3P][64]
   (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
   return bytes;
 }
@@ -851,8 +1047,20 @@ extern "C" int stemgnn_gru_fwd(const float* x, const float* w_ih, const float* w
 #define GRU_F2(PP, OO) do { if (KU2 == 32) GRU_F2K(PP, 32, OO); else if (KU2 == 48) GRU_F2K(PP, 48, OO); \
                             else if (KU2 == 58) GRU_F2K(PP, 58, OO); else GRU_F2K(PP, 64, OO); } while (0)
     const int KU2 = gru_pick_KU(Hd, P2);
-    if (P2 == 1) GRU_F2(1, 1); else if (P2 == 2) GRU_F2(2, 1); else if (P2 == 4) GRU_F2(4, 1);
+    // one wave per owner slice with the three gates sharing every broadcast (P <= 5); STEMGNN_GRU_FWD3=0: one wave per
+    // (gate, owner) as in round 1
+    const char* e3 = getenv("STEMGNN_GRU_FWD3");        // read per launch (a hipGraph capture freezes the choice)
+    const int fwd3 = !(e3 && atoi(e3) == 0);
+#define GRU_F3K(PP, KK) hipLaunchKernelGGL((gru_fwd_cluster3_kernel<PP, KK>), grid, dim3(PP * 64), 0, st, gi, w_hh, b_hh, B, S, \
+                                           Hd, xbuf, status, h_all, reserve, xid, allow_fast)
+#define GRU_F3(PP) do { if (KU2 == 32) GRU_F3K(PP, 32); else if (KU2 == 48) GRU_F3K(PP, 48); \
+                        else if (KU2 == 58) GRU_F3K(PP, 58); else GRU_F3K(PP, 64); } while (0)
+    if (fwd3 && P2 <= 5) {
+      if (P2 == 1) GRU_F3(1); else if (P2 == 2) GRU_F3(2); else if (P2 == 4) GRU_F3(4); else GRU_F3(5);
+    } else if (P2 == 1) GRU_F2(1, 1); else if (P2 == 2) GRU_F2(2, 1); else if (P2 == 4) GRU_F2(4, 1);
     else if (P2 == 5) GRU_F2(5, 1); else if (P2 == 6) GRU_F2(6, 2); else GRU_F2(8, 2);
+#undef GRU_F3
+#undef GRU_F3K
 #undef GRU_F2
 #undef GRU_F2K
     SG_TRY(hipGetLastError());

@@ -36,6 +36,25 @@ def test_gru_fwd_bwd_vs_torch_cpu(B, S, W, cluster, monkeypatch):
         assert relerr(mine.grad, ref.grad) < TOL
 
 
+@pytest.mark.parametrize("B,S,W", [(32, 228, 12), (5, 33, 7), (3, 140, 12), (2, 300, 4), (4, 307, 12)])
+def test_gru_forward_wave_per_owner_is_bit_identical(B, S, W, monkeypatch):
+    """The round-2 forward (one wave per owner slice, three gates per broadcast) sums every gate in the order of the
+    round-1 kernel (one wave per gate and owner, STEMGNN_GRU_FWD3=0): same bits."""
+    from stemgnn_amd.ops import GruFront, check_gru_status
+
+    torch.manual_seed(S + 3 * B)
+    gru = torch.nn.GRU(W, S)
+    x = torch.randn(B, W, S).cuda()
+    params = [p.detach().clone().cuda() for p in (gru.weight_ih_l0, gru.weight_hh_l0, gru.bias_ih_l0, gru.bias_hh_l0)]
+    outs = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("STEMGNN_GRU_FWD3", flag)
+        outs.append(GruFront.apply(x, *params).clone())
+    torch.cuda.synchronize()
+    check_gru_status(torch.device("cuda:0"))
+    assert torch.equal(outs[0], outs[1])
+
+
 @pytest.mark.parametrize("mode", ["mark", "segments"])
 @pytest.mark.parametrize("B,S,W", [(32, 228, 12), (9, 358, 12), (3, 140, 12), (2, 64, 5)])
 def test_gru_backward_time_segments_vs_torch_cpu(B, S, W, mode):
