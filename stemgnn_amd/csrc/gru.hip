@@ -229,7 +229,11 @@ __device__ __forceinline__ float gru_consume(const gru_u64* g, unsigned tag, int
 __device__ __forceinline__ void gru_publish_x(gru_u64* g, unsigned tag, float v, bool same_xcd) {
   const gru_u64 x = ((gru_u64)tag << 32) | (gru_u64)__float_as_uint(v);
   // one PLAIN global_store_dwordx2 (a `volatile` C++ store is emitted `sc0 sc1`, an atomic one `sc1`: both leave the L2)
+#if defined(GRU_PUB_PUSH) && GRU_PUB_PUSH == 3
+  if (same_xcd) asm volatile("global_store_dwordx2 %0, %1, off sc0" : : "v"(g), "v"(x) : "memory");
+#else
   if (same_xcd) asm volatile("global_store_dwordx2 %0, %1, off" : : "v"(g), "v"(x) : "memory");
+#endif
   else __hip_atomic_store(g, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // returns true when all P workgroups of batch row b run on one XCD.  xid: P granules of this row, zeroed before launch.
@@ -462,6 +466,9 @@ typedef float gru_f2 __attribute__((ext_vector_type(2)));
 #endif
 #ifndef GRU_NR_BWD
 #define GRU_NR_BWD 16
+#endif
+#ifndef GRU_NR4
+#define GRU_NR4 16                    // gru_cluster4.h (14 waves: 128 registers per lane; fewer LDS rows at KU = 64)
 #endif
 // the LDS rows cost up to 4 * ceil((KU - NR) / 4) VGPRs: only where the register budget of the launch shape has room
 // (<= 12 waves per workgroup for the per-(gate, owner) kernels; the three-gate forward holds 3 * KU weights already)
@@ -861,6 +868,8 @@ __global__ __launch_bounds__(3 * (P / OW) * 64) void gru_bwd_cluster2_kernel(con
   }
 }
 
+#include "gru_cluster4.h"
+
 // ---- weight gradients: reductions over all (s,b) rows as split-K GEMMs ----------------------------------------
 // z = split: part[z][j][k | bias] = sum_{rows in split} dgh[row][j] * hprev[row][k]
 struct GruWhhGradOp {
@@ -988,6 +997,14 @@ static size_t gru_lds_hog(const void* fn) {
   (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
   return bytes;
 }
+template <int P>
+static size_t gru_lds_hog4(const void* fn) {             // the same for the wave-specialised backward (its static LDS is larger)
+  static const bool on = !(getenv("STEMGNN_GRU_LDS_HOG") && atoi(getenv("STEMGNN_GRU_LDS_HOG")) == 0);
+  if (!on) return 0;
+  const size_t bytes = (size_t)156 * 1024 - sizeof(float) * gru4_static_lds_floats(P, 6, 4);
+  (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  return bytes;
+}
 static int gru_pick_KU(int Hd, int P) {              // unrolled mat-vec length: smallest instantiation >= the slice
   const int U = (Hd + P - 1) / P;
   return U <= 32 ? 32 : (U <= 48 ? 48 : (U <= 58 ? 58 : 64));
@@ -1055,10 +1072,20 @@ extern "C" int stemgnn_gru_fwd(const float* x, const float* w_ih, const float* w
                                            Hd, xbuf, status, h_all, reserve, xid, allow_fast)
 #define GRU_F3(PP) do { if (KU2 == 32) GRU_F3K(PP, 32); else if (KU2 == 48) GRU_F3K(PP, 48); \
                         else if (KU2 == 58) GRU_F3K(PP, 58); else GRU_F3K(PP, 64); } while (0)
-    if (fwd3 && P2 <= 5) {
+    const char* e4 = getenv("STEMGNN_GRU_V4");           // wave-specialised kernels (gru_cluster4.h); 0: v2 / v3
+    const int v4 = !(e4 && atoi(e4) == 0) && P2 <= 4;
+#define GRU_F4K(PP, KK) hipLaunchKernelGGL((gru_fwd_cluster4_kernel<PP, KK>), grid, dim3((PP + 2) * 64), 0, st, gi, w_hh, \
+                                           b_hh, B, S, Hd, xbuf, status, h_all, reserve, xid, allow_fast)
+#define GRU_F4(PP) do { if (KU2 == 32) GRU_F4K(PP, 32); else if (KU2 == 48) GRU_F4K(PP, 48); \
+                        else if (KU2 == 58) GRU_F4K(PP, 58); else GRU_F4K(PP, 64); } while (0)
+    if (v4) {
+      if (P2 == 1) GRU_F4(1); else if (P2 == 2) GRU_F4(2); else GRU_F4(4);
+    } else if (fwd3 && P2 <= 5) {
       if (P2 == 1) GRU_F3(1); else if (P2 == 2) GRU_F3(2); else if (P2 == 4) GRU_F3(4); else GRU_F3(5);
     } else if (P2 == 1) GRU_F2(1, 1); else if (P2 == 2) GRU_F2(2, 1); else if (P2 == 4) GRU_F2(4, 1);
     else if (P2 == 5) GRU_F2(5, 1); else if (P2 == 6) GRU_F2(6, 2); else GRU_F2(8, 2);
+#undef GRU_F4
+#undef GRU_F4K
 #undef GRU_F3
 #undef GRU_F3K
 #undef GRU_F2
@@ -1210,8 +1237,19 @@ extern "C" int stemgnn_gru_bwd(const float* dh_all, const float* x, const float*
                        xid0 + (size_t)seg * 8 * B, allow_fast); } while (0)
 #define GRU_B2(PP, OO) do { if (KU2 == 32) GRU_B2K(PP, 32, OO); else if (KU2 == 48) GRU_B2K(PP, 48, OO); \
                             else if (KU2 == 58) GRU_B2K(PP, 58, OO); else GRU_B2K(PP, 64, OO); } while (0)
-      if (P2 == 1) GRU_B2(1, 1); else if (P2 == 2) GRU_B2(2, 1); else if (P2 == 4) GRU_B2(4, 1);
+      const char* e4 = getenv("STEMGNN_GRU_V4");
+      const bool v4 = !(e4 && atoi(e4) == 0) && P2 <= 4 && T == 1 && s_mark < 0;
+#define GRU_B4K(PP, KK) do { const size_t hog = gru_lds_hog4<PP>((const void*)gru_bwd_cluster4_kernel<PP, KK>); \
+    hipLaunchKernelGGL((gru_bwd_cluster4_kernel<PP, KK>), grid, dim3((3 * PP + 2) * 64), hog, st, dh_all, w_hh, h_all, reserve, B, S, \
+                       Hd, xbuf, status, dgi, dghn, xid0, allow_fast); } while (0)
+#define GRU_B4(PP) do { if (KU2 == 32) GRU_B4K(PP, 32); else if (KU2 == 48) GRU_B4K(PP, 48); \
+                        else if (KU2 == 58) GRU_B4K(PP, 58); else GRU_B4K(PP, 64); } while (0)
+      if (v4) {
+        if (P2 == 1) GRU_B4(1); else if (P2 == 2) GRU_B4(2); else GRU_B4(4);
+      } else if (P2 == 1) GRU_B2(1, 1); else if (P2 == 2) GRU_B2(2, 1); else if (P2 == 4) GRU_B2(4, 1);
       else if (P2 == 5) GRU_B2(5, 1); else if (P2 == 6) GRU_B2(6, 2); else GRU_B2(8, 2);
+#undef GRU_B4
+#undef GRU_B4K
 #undef GRU_B2
 #undef GRU_B2K
       SG_TRY(hipGetLastError());

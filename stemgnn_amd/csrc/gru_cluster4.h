@@ -1,0 +1,413 @@
+// Cluster recurrence v4 (P <= 4 workgroups per batch row, U = ceil(Hd/P) <= 64): WAVE SPECIALISATION.
+//
+// What bounds a recurrence step is not FLOPs or bytes but the number of instructions the busiest wave has to ISSUE (a wave
+// issues one instruction every ~4-5 cycles whatever its kind; measured with -DGRU_PROF, profiles/r02_gru_phase_cycles.txt):
+// in the v2 / v3 kernels wave 0 ran the gate phase (LDS partial sums, gate math, granule stores), the global loads of the
+// next step's inputs with their 64-bit address arithmetic, the global stores of the saved gates AND its own mat-vec slice
+// -- 800-930 cycles of gate phase plus a 1100-cycle mat-vec, the whole critical path of the step, while the other waves
+// sat in their poll loops.  Here
+//   * wave 3P is the GATE wave: barrier -> partial sums and inputs from LDS -> gate math -> granule stores -> results
+//     into an LDS stash.  No global loads, no global data stores, no mat-vec.
+//   * waves 0 .. 3P-1 are the MAT-VEC waves (gate g, owner slice q) as in v2; every slice -- the workgroup's own units
+//     included -- arrives through the granule exchange.  Poll -> mat-vec -> partial sum into LDS, nothing else: a global
+//     store or load issued ahead of a poll would hold the poll back (vmcnt retires in order).
+//   * wave 3P+1 is the CHORE wave: it fetches the next step's gate inputs from global memory into LDS and moves the
+//     previous step's stash to global memory.  It never polls, so it may wait for its memory operations at leisure.
+// The arithmetic (mat-vec chains, order of the partial sums, gate formulas) is that of the v2 kernels: the hidden states
+// are bit-identical, the gradients agree to rounding (the compiler contracts the gate-gradient products differently in
+// the two kernels) (tests/test_hip_gru_eigh.py).  LDS buffers are double buffered by step parity; the hand-offs
+// (who writes / reads which parity between which two barriers) are spelled out at each buffer below.
+#pragma once
+
+// A/B hook (-DGRU_PUB_PUSH=n): what the gate wave does right after its granule stores.  0: nothing; 1: wait for their
+// acknowledgement; 2: a dummy L2 load behind them; 3: the stores carry sc0 (gru_publish_x)
+#ifndef GRU_PUB_PUSH
+#define GRU_PUB_PUSH 0
+#endif
+__device__ __forceinline__ void gru4_after_publish(const gru_u64* g) {
+#if GRU_PUB_PUSH == 1
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#elif GRU_PUB_PUSH == 2
+  gru_u64 x;
+  asm volatile("global_load_dwordx2 %0, %1, off sc1" : "=v"(x) : "v"(g) : "memory");
+  asm volatile("" :: "v"(x));
+#else
+  (void)g;
+#endif
+}
+// Poll of one granule per lane in the mat-vec waves.  GRU_POLL_MODE bit 0: two loads in flight, half a round trip apart
+// (the expected wait for the NEXT look at the granule after it lands is a quarter of a round trip instead of a half);
+// PRE (x 64 cycles): sleep first -- nothing can arrive before the gate phase of the producers is over, and an idle
+// memory pipeline lets their granule stores through sooner.
+#ifndef GRU_POLL_MODE
+#define GRU_POLL_MODE 0
+#endif
+#ifndef GRU_POLL_PRE_F
+#define GRU_POLL_PRE_F 14
+#endif
+#ifndef GRU_POLL_PRE_B
+#define GRU_POLL_PRE_B 9
+#endif
+#ifndef GRU_POLL_LOOP_SLEEP
+#define GRU_POLL_LOOP_SLEEP 1
+#endif
+template <int PRE>
+__device__ __forceinline__ float gru4_poll(const gru_u64* g, unsigned tag, bool active, int* status) {
+  if (PRE > 0) __builtin_amdgcn_s_sleep(PRE);
+#if (GRU_POLL_MODE & 1)
+  float v = 0.f;
+  if (active) {
+    gru_u64 a = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_s_sleep(2);
+    gru_u64 b = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned spins = 0;
+    for (;;) {
+      if ((unsigned)(a >> 32) == tag) { v = __uint_as_float((unsigned)a); break; }
+      a = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if ((unsigned)(b >> 32) == tag) { v = __uint_as_float((unsigned)b); break; }
+      b = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (++spins > (1u << 22)) { atomicExch(status, 1); break; }
+    }
+  }
+  return v;
+#else
+  float v = 0.f;
+  if (active) {
+    gru_u64 x = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned spins = 0;
+    while ((unsigned)(x >> 32) != tag) {
+      if (GRU_POLL_LOOP_SLEEP > 0) __builtin_amdgcn_s_sleep(GRU_POLL_LOOP_SLEEP);
+      x = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (++spins > (1u << 22)) { atomicExch(status, 1); break; }   // partner not resident / lost: give up, flag it
+    }
+    v = __uint_as_float((unsigned)x);
+  }
+  return v;
+#endif
+}
+constexpr int gru4_static_lds_floats(int P, int nin, int nout) { return 2 * 3 * P * 64 + 3 * P * 64 + 2 * nin * 64 + 2 * nout * 64; }
+
+// ---- forward ------------------------------------------------------------------------------------------------------
+// Waves 0 .. P-1: mat-vec of owner slice q for all three gates (one broadcast per k serves three v_pk_fma, as in the v3
+// kernel: 4 polling waves instead of 12), wave P: gates, wave P+1: chores.
+// barrier #s closes the mat-vec of step s.  part[s&1]: written by the mat-vec waves before barrier #s, read by the gate
+// wave between #s and #s+1, rewritten before #s+2.  gin[s&1] (the gi values of step s): written by the chore wave right
+// after #s-1 from registers it loaded a step earlier, read by the gate wave after #s.  stash[s&1]: written by the gate
+// wave between #s and #s+1, moved to global memory by the chore wave between #s+1 and #s+2, rewritten after #s+2.
+// The chore wave issues its global loads / stores only after a pause that lets the gate wave's granule stores go first:
+// the CU's memory pipeline is in order, and a granule store queued behind HBM loads costs the whole cluster a step time.
+#ifndef GRU_CHORE_SLEEP_F
+#define GRU_CHORE_SLEEP_F 16            // x 64 cycles after the barrier (the forward gate phase takes ~700)
+#endif
+#ifndef GRU_CHORE_SLEEP_B
+#define GRU_CHORE_SLEEP_B 12
+#endif
+template <int P, int KU>
+__global__ __launch_bounds__((P + 2) * 64) void gru_fwd_cluster4_kernel(const float* __restrict__ gi, const float* __restrict__ w_hh,
+                                                                        const float* __restrict__ b_hh, int B, int S, int Hd,
+                                                                        gru_u64* __restrict__ xbuf, int* __restrict__ status,
+                                                                        float* __restrict__ h_all, float* __restrict__ reserve,
+                                                                        gru_u64* __restrict__ xid, int allow_fast) {
+  __shared__ float part[2][3 * P][64];
+  __shared__ __attribute__((aligned(16))) float lrow[P][64];
+  __shared__ float gin[2][3][64];
+  __shared__ float stash[2][5][64];                      // r, z, n, W_hn h + b_hn, h
+  __shared__ int s_fast;
+  int b, p;
+  gru_cluster_ids(B, P, b, p);
+  if (b >= B) return;
+  const bool fast = P > 1 && gru_same_xcd(xid + (size_t)b * P, p, P, allow_fast, status, &s_fast, threadIdx.x);
+  const int U = (Hd + P - 1) / P;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = gru_uniform(tid >> 6);
+  const int u0 = p * U, un = max(0, min(Hd, u0 + U) - u0);
+  const int H3 = 3 * Hd;
+  const bool lane_ok = lane < un;
+  const int gu = u0 + (lane_ok ? lane : 0);
+
+  if (wave < P) {
+    // ---------------- mat-vec wave: owner slot q (rotated by p), gates r, z, n ----------------
+    const int q = wave;
+    const int k0 = ((q + p) % P) * U, kn = max(0, min(Hd, k0 + U) - k0);
+    gru_f2 wr[3][32];
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+      const float* wrow = w_hh + ((size_t)g * Hd + gu) * Hd + (kn > 0 ? k0 : 0);
+#pragma unroll
+      for (int kk = 0; kk < KU; ++kk) {
+        const float v = wrow[kk < kn ? kk : 0];
+        wr[g][kk >> 1][kk & 1] = (lane_ok && kk < kn) ? v : 0.f;
+      }
+    }
+    const gru_u64* pollp = xbuf + (size_t)b * Hd + k0 + (lane < kn ? lane : 0);      // parity 0; parity 1 is B*Hd further
+    const size_t par = (size_t)B * Hd;
+#ifdef GRU_PROF
+    long long c_a = 0, c_b = 0, c_c = 0;
+#endif
+    for (int s = 0; s < S; ++s) {
+      GRU_T(t0);
+      float hv = 0.f;
+      if (s > 0) hv = gru4_poll<GRU_POLL_PRE_F>(pollp + (s & 1) * par, (unsigned)s, lane < kn, status);
+      GRU_T(t1);
+      GRU_ACC(c_a, t1, t0);
+      float o0, o1, o2;
+      gru_matvec3<KU, GRU_NR3(KU)>(wr[0], wr[1], wr[2], hv, lrow[q], lane, o0, o1, o2);
+      part[s & 1][0 * P + q][lane] = o0;
+      part[s & 1][1 * P + q][lane] = o1;
+      part[s & 1][2 * P + q][lane] = o2;
+      GRU_T(t2);
+      GRU_ACC(c_b, t2, t1);
+      gru_lds_barrier();                                 // #s
+      GRU_T(t3);
+      GRU_ACC(c_c, t3, t2);
+    }
+    gru_lds_barrier();                                   // the gate wave has finished step S - 1
+#ifdef GRU_PROF
+    if (blockIdx.x == 0 && lane == 0)
+      printf("gru fwd4 mat-vec wave %d: per step cycles: poll %lld  matvec %lld  barrier wait %lld\n", wave, c_a / S, c_b / S, c_c / S);
+#endif
+  } else if (wave == P + 1) {
+    // ---------------- chore wave ----------------
+    const float* gip = gi + (size_t)b * H3 + gu;         // row (s, b) is s * B * H3 further
+    const size_t grow = (size_t)B * H3;
+    float v0 = gip[0], v1 = gip[Hd], v2 = gip[2 * Hd];  // gi values of step 0
+    for (int s = 0; s < S; ++s) {
+      gin[s & 1][0][lane] = v0;                          // (gate(s-2), the last reader of this parity, finished before #s-1)
+      gin[s & 1][1][lane] = v1;
+      gin[s & 1][2][lane] = v2;
+      float r = 0.f, z = 0.f, n = 0.f, g2 = 0.f, hn = 0.f;
+      if (s >= 2) {
+        r = stash[s & 1][0][lane]; z = stash[s & 1][1][lane]; n = stash[s & 1][2][lane];
+        g2 = stash[s & 1][3][lane]; hn = stash[s & 1][4][lane];
+      }
+      if (s > 0) __builtin_amdgcn_s_sleep(GRU_CHORE_SLEEP_F);   // let the granule stores of gate(s-1) go first
+      if (s + 1 < S) {
+        const float* gn = gip + (size_t)(s + 1) * grow;
+        v0 = gn[0]; v1 = gn[Hd]; v2 = gn[2 * Hd];
+      }
+      if (s >= 2 && lane_ok) {
+        const size_t rw = (size_t)(s - 2) * B + b;
+        float* rs = reserve + rw * 4 * Hd + gu;
+        rs[0] = r; rs[Hd] = z; rs[2 * Hd] = n; rs[3 * Hd] = g2;
+        h_all[rw * Hd + gu] = hn;
+      }
+      gru_lds_barrier();                                 // #s
+    }
+    gru_lds_barrier();                                   // the gate wave has finished step S - 1 (stash[(S-1)&1] is complete)
+    for (int t = (S >= 2 ? S - 2 : S - 1); t < S; ++t) {
+      const size_t rw = (size_t)t * B + b;
+      if (lane_ok) {
+        float* rs = reserve + rw * 4 * Hd + gu;
+        rs[0] = stash[t & 1][0][lane]; rs[Hd] = stash[t & 1][1][lane]; rs[2 * Hd] = stash[t & 1][2][lane];
+        rs[3 * Hd] = stash[t & 1][3][lane];
+        h_all[rw * Hd + gu] = stash[t & 1][4][lane];
+      }
+    }
+  } else {
+    // ---------------- gate wave ----------------
+    const float bh0 = b_hh[gu], bh1 = b_hh[Hd + gu], bh2 = b_hh[2 * Hd + gu];
+    float hown = 0.f;
+    gru_u64* pub = xbuf + (size_t)b * Hd + gu;           // parity 0
+    const size_t par = (size_t)B * Hd;
+#ifdef GRU_PROF
+    long long c_a = 0, c_b = 0, c_c = 0;
+#endif
+    for (int s = 0; s < S; ++s) {
+      GRU_T(t0);
+      gru_lds_barrier();                                 // #s
+      GRU_T(t1);
+      GRU_ACC(c_a, t1, t0);
+      float g0 = bh0, g1 = bh1, g2 = bh2;
+#pragma unroll
+      for (int qq = 0; qq < P; ++qq) {
+        g0 += part[s & 1][0 * P + qq][lane];
+        g1 += part[s & 1][1 * P + qq][lane];
+        g2 += part[s & 1][2 * P + qq][lane];
+      }
+      const float gp0 = gin[s & 1][0][lane], gp1 = gin[s & 1][1][lane], gp2 = gin[s & 1][2][lane];
+      const float r = gru_sigmoid(gp0 + g0);
+      const float z = gru_sigmoid(gp1 + g1);
+      const float n = tanhf(gp2 + r * g2);
+      const float hn = (1.f - z) * n + z * hown;
+      hown = hn;
+      if (s + 1 < S && lane_ok) gru_publish_x(pub + ((s + 1) & 1) * par, (unsigned)(s + 1), hn, fast);
+      gru4_after_publish(pub);
+      GRU_T(t2);
+      GRU_ACC(c_b, t2, t1);
+      stash[s & 1][0][lane] = r;
+      stash[s & 1][1][lane] = z;
+      stash[s & 1][2][lane] = n;
+      stash[s & 1][3][lane] = g2;
+      stash[s & 1][4][lane] = hn;
+      GRU_T(t3);
+      GRU_ACC(c_c, t3, t2);
+    }
+    gru_lds_barrier();
+#ifdef GRU_PROF
+    if (blockIdx.x == 0 && lane == 0)
+      printf("gru fwd4 gate wave: per step cycles: barrier wait %lld  gate phase to publish %lld  stash %lld\n", c_a / S, c_b / S, c_c / S);
+#endif
+  }
+}
+
+// ---- backward -----------------------------------------------------------------------------------------------------
+// Barriers: B_init, then B_s (s = S-1 .. 1) closing the mat-vec of step s, then B_fin.  gate(s) runs between B_{s+1}
+// and B_s.  part[tag&1] (tag = S-s): written by mat-vec(s) before B_s, read by gate(s-1).  bin[(s-1)&1]: inputs of
+// gate(s-1), fetched by the chore wave during step s+1 and written at the top of step s (before B_s).  bout[s&1]: written by gate(s) before
+// B_s, moved to global memory by the chore wave during step s-1 (before B_{s-1}), rewritten by gate(s-2) after that.
+template <int P, int KU>
+__global__ __launch_bounds__((3 * P + 2) * 64) void gru_bwd_cluster4_kernel(const float* __restrict__ dout, const float* __restrict__ w_hh,
+                                                                            const float* __restrict__ h_all,
+                                                                            const float* __restrict__ reserve, int B, int S, int Hd,
+                                                                            gru_u64* __restrict__ xbuf, int* __restrict__ status,
+                                                                            float* __restrict__ dgi, float* __restrict__ dghn,
+                                                                            gru_u64* __restrict__ xid, int allow_fast) {
+  constexpr int NMV = 3 * P;
+  __shared__ float part[2][NMV][64];
+  __shared__ __attribute__((aligned(16))) float lrow[NMV][64];
+  __shared__ float bin[2][6][64];                        // dh_out, r, z, n, W_hn h + b_hn, h_prev
+  __shared__ float bout[2][4][64];                       // dr, dz, dn, dn * r
+  __shared__ int s_fast;
+  int b, p;
+  gru_cluster_ids(B, P, b, p);
+  if (b >= B) return;
+  const bool fast = P > 1 && gru_same_xcd(xid + (size_t)b * P, p, P, allow_fast, status, &s_fast, threadIdx.x);
+  const int U = (Hd + P - 1) / P;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = gru_uniform(tid >> 6);
+  const int u0 = p * U, un = max(0, min(Hd, u0 + U) - u0);
+  const int H3 = 3 * Hd;
+  const bool lane_ok = lane < un;
+  const int gu = u0 + (lane_ok ? lane : 0);
+  for (int i = tid; i < 2 * NMV * 64; i += (NMV + 2) * 64) (&part[0][0][0])[i] = 0.f;
+
+  if (wave < NMV) {
+    // ---------------- mat-vec wave (gate g, owner slot q rotated by p): reduction slice j = g*Hd + units of that owner
+    const int g = wave / P, q = wave - g * P;
+    const int k0 = ((q + p) % P) * U, kn = max(0, min(Hd, k0 + U) - k0);
+    gru_f2 wr[32];
+    {
+      const float* wcol = w_hh + ((size_t)g * Hd + (kn > 0 ? k0 : 0)) * Hd + gu;
+#pragma unroll
+      for (int kk = 0; kk < KU; ++kk) {
+        const float v = wcol[(size_t)(kk < kn ? kk : 0) * Hd];
+        wr[kk >> 1][kk & 1] = (lane_ok && kk < kn) ? v : 0.f;
+      }
+    }
+    const gru_u64* pollp = xbuf + (size_t)b * H3 + (size_t)g * Hd + k0 + (lane < kn ? lane : 0);   // parity 0
+    const size_t par = (size_t)B * H3;
+#ifdef GRU_PROF
+    long long c_a = 0, c_b = 0, c_c = 0;
+#endif
+    gru_lds_barrier();                                   // B_init (also publishes the zeroed partial sums)
+    for (int s = S - 1; s >= 1; --s) {
+      const unsigned tag = (unsigned)(S - s);
+      GRU_T(t0);
+      const float dv = gru4_poll<GRU_POLL_PRE_B>(pollp + (tag & 1) * par, tag, lane < kn, status);
+      GRU_T(t1);
+      GRU_ACC(c_a, t1, t0);
+      part[tag & 1][wave][lane] = gru_matvec<KU, (KU <= 58 ? GRU_NR4 : (GRU_NR4 > 24 ? GRU_NR4 : 24))>(wr, dv, lrow[wave], lane);
+      GRU_T(t2);
+      GRU_ACC(c_b, t2, t1);
+      gru_lds_barrier();                                 // B_s
+      GRU_T(t3);
+      GRU_ACC(c_c, t3, t2);
+    }
+    gru_lds_barrier();                                   // B_fin: gate(0) is done
+#ifdef GRU_PROF
+    if (blockIdx.x == 0 && lane == 0)
+      printf("gru bwd4 mat-vec wave %d: per step cycles: poll %lld  matvec %lld  barrier wait %lld\n", wave, c_a / S, c_b / S, c_c / S);
+#endif
+  } else if (wave == NMV + 1) {
+    // ---------------- chore wave: inputs of gate(s-1) into bin[(s-1)&1] before B_s; outputs of gate(s+1) to global ----
+    auto fetch = [&](int t, float (&val)[6]) {
+      const size_t rw = (size_t)t * B + b;
+      const float* rs = reserve + rw * 4 * Hd + gu;
+      val[0] = dout[rw * Hd + gu];
+      val[1] = rs[0]; val[2] = rs[Hd]; val[3] = rs[2 * Hd]; val[4] = rs[3 * Hd];
+      val[5] = t > 0 ? h_all[(rw - B) * Hd + gu] : 0.f;
+    };
+    auto stage = [&](int t, const float (&val)[6]) {
+#pragma unroll
+      for (int v = 0; v < 6; ++v) bin[t & 1][v][lane] = val[v];
+    };
+    auto flush = [&](int t) {
+      const size_t rw = (size_t)t * B + b;
+      const float dr = bout[t & 1][0][lane], dz = bout[t & 1][1][lane], dn = bout[t & 1][2][lane], dnr = bout[t & 1][3][lane];
+      if (lane_ok) {
+        float* go = dgi + rw * H3 + gu;
+        go[0] = dr; go[Hd] = dz; go[2 * Hd] = dn;
+        dghn[rw * Hd + gu] = dnr;
+      }
+    };
+    float val[6];
+    fetch(S - 1, val);
+    stage(S - 1, val);
+    if (S >= 2) fetch(S - 2, val);                       // inputs of gate(S-2): staged at the top of step S-1
+    gru_lds_barrier();                                   // B_init
+    for (int s = S - 1; s >= 1; --s) {
+      stage(s - 1, val);                                 // (gate(s+1), the last reader of this parity, finished before B_{s+1})
+      float dr = 0.f, dz = 0.f, dn = 0.f, dnr = 0.f;
+      const bool have = s + 1 <= S - 1;
+      if (have) { dr = bout[(s + 1) & 1][0][lane]; dz = bout[(s + 1) & 1][1][lane]; dn = bout[(s + 1) & 1][2][lane]; dnr = bout[(s + 1) & 1][3][lane]; }
+      __builtin_amdgcn_s_sleep(GRU_CHORE_SLEEP_B);       // let the granule stores of gate(s) go first
+      if (s >= 2) fetch(s - 2, val);
+      if (have && lane_ok) {
+        const size_t rw = (size_t)(s + 1) * B + b;
+        float* go = dgi + rw * H3 + gu;
+        go[0] = dr; go[Hd] = dz; go[2 * Hd] = dn;
+        dghn[rw * Hd + gu] = dnr;
+      }
+      gru_lds_barrier();                                 // B_s
+    }
+    gru_lds_barrier();                                   // B_fin: gate(0) is done
+    if (S >= 2) flush(1);
+    flush(0);
+  } else {
+    // ---------------- gate wave ----------------
+    float dhz = 0.f;
+    gru_u64* pub = xbuf + (size_t)b * H3 + gu;           // parity 0, gate r; gates z / n are Hd / 2 Hd granules further
+    const size_t par = (size_t)B * H3;
+#ifdef GRU_PROF
+    long long c_a = 0, c_b = 0, c_c = 0;
+#endif
+    gru_lds_barrier();                                   // B_init
+    for (int s = S - 1; s >= 0; --s) {
+      const unsigned tag = (unsigned)(S - s);
+      GRU_T(t1);
+      float dh = bin[s & 1][0][lane] + dhz;
+#pragma unroll
+      for (int w = 0; w < NMV; ++w) dh += part[(tag + 1) & 1][w][lane];      // partials of the step after this one
+      const float r = bin[s & 1][1][lane], z = bin[s & 1][2][lane], n = bin[s & 1][3][lane], ghn = bin[s & 1][4][lane];
+      const float hprev = s > 0 ? bin[s & 1][5][lane] : 0.f;
+      const float dn = dh * (1.f - z) * (1.f - n * n);
+      const float dz = dh * (hprev - n) * z * (1.f - z);
+      const float dr = dn * ghn * r * (1.f - r);
+      const float dnr = dn * r;
+      dhz = dh * z;
+      if (s > 0 && lane_ok) {
+        gru_u64* xb = pub + (tag & 1) * par;
+        gru_publish_x(xb, tag, dr, fast);
+        gru_publish_x(xb + Hd, tag, dz, fast);
+        gru_publish_x(xb + 2 * Hd, tag, dnr, fast);
+      }
+      gru4_after_publish(pub);
+      GRU_T(t2);
+      GRU_ACC(c_b, t2, t1);
+      bout[s & 1][0][lane] = dr;
+      bout[s & 1][1][lane] = dz;
+      bout[s & 1][2][lane] = dn;
+      bout[s & 1][3][lane] = dnr;
+      GRU_T(t3);
+      GRU_ACC(c_c, t3, t2);
+      if (s > 0) gru_lds_barrier();                      // B_s
+      GRU_T(t4);
+      GRU_ACC(c_a, t4, t3);
+    }
+    gru_lds_barrier();                                   // B_fin
+#ifdef GRU_PROF
+    if (blockIdx.x == 0 && lane == 0)
+      printf("gru bwd4 gate wave: per step cycles: barrier wait %lld  gate phase to publish %lld  stash %lld\n", c_a / S, c_b / S, c_c / S);
+#endif
+  }
+}

@@ -55,6 +55,33 @@ def test_gru_forward_wave_per_owner_is_bit_identical(B, S, W, monkeypatch):
     assert torch.equal(outs[0], outs[1])
 
 
+@pytest.mark.parametrize("B,S,W", [(32, 228, 12), (5, 33, 7), (3, 140, 12), (2, 64, 5), (1, 100, 3), (7, 250, 12), (2, 1, 4), (2, 2, 4)])
+def test_gru_wave_specialised_kernels_are_bit_identical(B, S, W, monkeypatch):
+    """gru_cluster4.h (a dedicated gate wave, the chores done by the polling waves) against the round-1 layout
+    (STEMGNN_GRU_V4=0, STEMGNN_GRU_FWD3=0): same mat-vec chains, same order of the partial sums -> the same bits in
+    the hidden states; the gradients agree to rounding."""
+    from stemgnn_amd.ops import GruFront, check_gru_status
+
+    torch.manual_seed(S + 5 * B)
+    gru = torch.nn.GRU(W, S)
+    x = torch.randn(B, W, S).cuda()
+    dh = torch.randn(S, B, S).cuda()
+    ref = (gru.weight_ih_l0, gru.weight_hh_l0, gru.bias_ih_l0, gru.bias_hh_l0)
+    runs = []
+    for v4 in ("1", "0"):
+        monkeypatch.setenv("STEMGNN_GRU_V4", v4)
+        monkeypatch.setenv("STEMGNN_GRU_FWD3", v4)
+        params = [p.detach().clone().cuda().requires_grad_(True) for p in ref]
+        h = GruFront.apply(x, *params)
+        h.backward(dh)
+        torch.cuda.synchronize()
+        runs.append([h.detach().clone()] + [p.grad.clone() for p in params])
+    check_gru_status(torch.device("cuda:0"))
+    assert torch.equal(runs[0][0], runs[1][0])                    # hidden states: the same bits
+    for a, c in zip(runs[0][1:], runs[1][1:]):                    # gradients: rounding only (fma contraction differs)
+        assert relerr(a, c) < 2e-6
+
+
 @pytest.mark.parametrize("mode", ["mark", "segments"])
 @pytest.mark.parametrize("B,S,W", [(32, 228, 12), (9, 358, 12), (3, 140, 12), (2, 64, 5)])
 def test_gru_backward_time_segments_vs_torch_cpu(B, S, W, mode):
