@@ -1073,13 +1073,28 @@ extern "C" int stemgnn_gru_fwd(const float* x, const float* w_ih, const float* w
 #define GRU_F3(PP) do { if (KU2 == 32) GRU_F3K(PP, 32); else if (KU2 == 48) GRU_F3K(PP, 48); \
                         else if (KU2 == 58) GRU_F3K(PP, 58); else GRU_F3K(PP, 64); } while (0)
     const char* e4 = getenv("STEMGNN_GRU_V4");           // wave-specialised kernels (gru_cluster4.h); 0: v2 / v3
-    const int v4 = !(e4 && atoi(e4) == 0) && P2 <= 4;
-#define GRU_F4K(PP, KK) hipLaunchKernelGGL((gru_fwd_cluster4_kernel<PP, KK>), grid, dim3((PP + 2) * 64), 0, st, gi, w_hh, \
+    const int v4 = !(e4 && atoi(e4) == 0);
+    // The v4 forward runs P + 2 waves per workgroup, so every P <= 8 fits; its cluster size may differ from the backward's
+    // (the backward shares the chip with the side-stream weight-gradient GEMMs, the forward has it to itself).
+    // Default: 7 workgroups per batch row when B * 7 of them are resident (224 of the 256 CUs at batch 32: the mat-vec
+    // slices shrink to 33 columns; measured 1.4985 -> 1.4850 ms per step at PEMS07, P = 5 / 6: 1.509 / 1.491), else the
+    // backward's P.  STEMGNN_GRU_FWD_P=n forces n (1, 2, 4 .. 8; needs ceil(Hd / n) <= 64), =0 means "as the backward".
+    int PF = P2;
+    {
+      const char* ep = getenv("STEMGNN_GRU_FWD_P");
+      const int want = ep ? atoi(ep) : 7;
+      if (want >= 1 && want <= 8 && want != 3 && (Hd + want - 1) / want <= 64 && B * want <= gru_resident_limit()) PF = want;
+    }
+    const int UF = (Hd + PF - 1) / PF;
+    const int KF = UF <= 32 ? 32 : (UF <= 34 ? 34 : (UF <= 40 ? 40 : (UF <= 48 ? 48 : (UF <= 58 ? 58 : 64))));
+    const dim3 grid4(8 * ((B + 7) / 8) * PF);
+#define GRU_F4K(PP, KK) hipLaunchKernelGGL((gru_fwd_cluster4_kernel<PP, KK>), grid4, dim3((PP + 2) * 64), 0, st, gi, w_hh, \
                                            b_hh, B, S, Hd, xbuf, status, h_all, reserve, xid, allow_fast)
-#define GRU_F4(PP) do { if (KU2 == 32) GRU_F4K(PP, 32); else if (KU2 == 48) GRU_F4K(PP, 48); \
-                        else if (KU2 == 58) GRU_F4K(PP, 58); else GRU_F4K(PP, 64); } while (0)
+#define GRU_F4(PP) do { if (KF == 32) GRU_F4K(PP, 32); else if (KF == 34) GRU_F4K(PP, 34); else if (KF == 40) GRU_F4K(PP, 40); \
+                        else if (KF == 48) GRU_F4K(PP, 48); else if (KF == 58) GRU_F4K(PP, 58); else GRU_F4K(PP, 64); } while (0)
     if (v4) {
-      if (P2 == 1) GRU_F4(1); else if (P2 == 2) GRU_F4(2); else GRU_F4(4);
+      if (PF == 1) GRU_F4(1); else if (PF == 2) GRU_F4(2); else if (PF == 4) GRU_F4(4); else if (PF == 5) GRU_F4(5);
+      else if (PF == 6) GRU_F4(6); else if (PF == 7) GRU_F4(7); else GRU_F4(8);
     } else if (fwd3 && P2 <= 5) {
       if (P2 == 1) GRU_F3(1); else if (P2 == 2) GRU_F3(2); else if (P2 == 4) GRU_F3(4); else GRU_F3(5);
     } else if (P2 == 1) GRU_F2(1, 1); else if (P2 == 2) GRU_F2(2, 1); else if (P2 == 4) GRU_F2(4, 1);

@@ -71,6 +71,7 @@ def test_gru_wave_specialised_kernels_are_bit_identical(B, S, W, monkeypatch):
     for v4 in ("1", "0"):
         monkeypatch.setenv("STEMGNN_GRU_V4", v4)
         monkeypatch.setenv("STEMGNN_GRU_FWD3", v4)
+        monkeypatch.setenv("STEMGNN_GRU_FWD_P", "0")          # the backward's cluster size (the default forward is wider)
         params = [p.detach().clone().cuda().requires_grad_(True) for p in ref]
         h = GruFront.apply(x, *params)
         h.backward(dh)
