@@ -1078,12 +1078,16 @@ extern "C" int stemgnn_gru_fwd(const float* x, const float* w_ih, const float* w
     // (the backward shares the chip with the side-stream weight-gradient GEMMs, the forward has it to itself).
     // Default: 7 workgroups per batch row when B * 7 of them are resident (224 of the 256 CUs at batch 32: the mat-vec
     // slices shrink to 33 columns; measured 1.4985 -> 1.4850 ms per step at PEMS07, P = 5 / 6: 1.509 / 1.491), else the
-    // backward's P.  STEMGNN_GRU_FWD_P=n forces n (1, 2, 4 .. 8; needs ceil(Hd / n) <= 64), =0 means "as the backward".
+    // backward's P.  STEMGNN_GRU_FWD_P=n forces n (1, 2, 4 .. 8; needs ceil(Hd / n) <= 64, and <= 40 for n >= 7), =0 means
+    // "as the backward".
     int PF = P2;
     {
       const char* ep = getenv("STEMGNN_GRU_FWD_P");
       const int want = ep ? atoi(ep) : 7;
-      if (want >= 1 && want <= 8 && want != 3 && (Hd + want - 1) / want <= 64 && B * want <= gru_resident_limit()) PF = want;
+      const int uw = want >= 1 ? (Hd + want - 1) / want : 0;
+      // 7 or 8 workgroups per row = 9 or 10 waves = three on one SIMD = 168 registers per lane: slices of <= 40 columns only
+      const bool regs_ok = want <= 6 || uw <= 40;
+      if (want >= 1 && want <= 8 && want != 3 && uw <= 64 && regs_ok && B * want <= gru_resident_limit()) PF = want;
     }
     const int UF = (Hd + PF - 1) / PF;
     const int KF = UF <= 32 ? 32 : (UF <= 34 ? 34 : (UF <= 40 ? 40 : (UF <= 48 ? 48 : (UF <= 58 ? 58 : 64))));
