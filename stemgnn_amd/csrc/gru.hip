@@ -915,10 +915,11 @@ struct GruReduceJobs {
   const float* part[3];
   float* out_w[3];
   float* out_b[3];
-  int rows[3], cols[3];
+  int rows[3], cols[3], nsplit[3];
 };
-__global__ void gru_reduce_grad_kernel(const GruReduceJobs J, int nsplit) {
+__global__ void gru_reduce_grad_kernel(const GruReduceJobs J) {
   const int job = blockIdx.y;
+  const int nsplit = J.nsplit[job];
   const int rows = J.rows[job], cols = J.cols[job];
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t slab = (size_t)rows * (cols + 1);
@@ -943,6 +944,9 @@ static int gru_nsplit() {
   return v;
 }
 #define GRU_NSPLIT gru_nsplit()
+// slabs of the dW_ih | db_ih reduction: one per split of the GEMM, or one per batch row when the wave-specialised
+// backward accumulates them itself (gru_cluster4.h)
+static int gru_ih_slabs(int B) { return B > gru_nsplit() ? B : gru_nsplit(); }
 
 extern "C" size_t stemgnn_gru_reserve_floats(int B, int S, int Hd) { return (size_t)4 * S * B * Hd; }
 // cluster size: smallest P in {1,2,4,8} whose per-lane weight slice fits the register budget; 0 = use the
@@ -1029,7 +1033,7 @@ extern "C" size_t stemgnn_gru_fwd_scratch_floats(int B, int S, int Hd) {
   return (size_t)3 * Hd * Hd + (size_t)3 * S * B * Hd + gru_xbuf_floats(B, Hd) + 4;   // W_hh^T | gi | exchange
 }
 extern "C" size_t stemgnn_gru_bwd_scratch_floats(int B, int S, int Hd, int W) {
-  return (size_t)4 * S * B * Hd + (size_t)GRU_NSPLIT * 3 * Hd * (Hd + 1) + (size_t)GRU_NSPLIT * 3 * Hd * (W + 1) +
+  return (size_t)4 * S * B * Hd + (size_t)GRU_NSPLIT * 3 * Hd * (Hd + 1) + (size_t)gru_ih_slabs(B) * 3 * Hd * (W + 1) +
          gru_xbuf_floats(B, Hd) + 4 + (size_t)B * Hd + 8;     // ... | exchange | carry (time segments) | progress
 }
 
@@ -1140,7 +1144,7 @@ extern "C" int stemgnn_gru_fwd(const float* x, const float* w_ih, const float* w
 // `slab0` .. `slab0 + nsplit - 1` of the GRU_NSPLIT slabs the final fixed-order reduce sums
 static int gru_wgrad_rows(const float* dgi, const float* dghn, const float* h_ext, const float* x, float* p_hh, float* p_ih,
                           int B, int S, int Hd, int W, int row0, int rows, int slab0, int nsplit, hipStream_t st_hh,
-                          hipStream_t st_ih) {
+                          hipStream_t st_ih, bool do_ih = true) {
   const int chunk = ((rows + nsplit - 1) / nsplit + 15) & ~15;
   {  // dW_hh | db_hh = dgh^T [3Hd x rows] * [h_prev | 1]: rows 0..2Hd-1 of dgh are dgi's r,z gates, rows 2Hd..3Hd-1 = dghn
      // (two "branches" of one 128x128 MFMA GEMM launch); h_prev of row (s,b) is row (s,b) of h_ext (slab 0 = zeros)
@@ -1156,6 +1160,7 @@ static int gru_wgrad_rows(const float* dgi, const float* dghn, const float* h_ex
     if (bm64) SG_TRY((g2_launch<G2SlabEpi, false, false, 64>(g, e, 2, st_hh)));
     else SG_TRY((g2_launch<G2SlabEpi, false, false>(g, e, 2, st_hh)));
   }
+  if (!do_ih) return 0;                                  // accumulated inside the recurrence (gru_cluster4.h)
   GruWihGradOp o2{dgi, x, p_ih + (size_t)slab0 * 3 * Hd * (W + 1), B, S, Hd, W, nsplit, chunk, row0, rows};
   SG_TRY((sg_launch_gemm<GruWihGradOp, 64, 32, false, false, false, 64>(o2, 3 * Hd, W + 1, nsplit, st_ih)));
   return 0;
@@ -1197,10 +1202,10 @@ extern "C" int stemgnn_gru_bwd(const float* dh_all, const float* x, const float*
   float* p_ih = p_hh + (size_t)GRU_NSPLIT * 3 * Hd * (Hd + 1);
   const int P2 = gru_pick_P2(B, Hd);
   const int P = P2 > 0 ? 0 : gru_pick_P(B, Hd);
-  bool segmented = false;
+  bool segmented = false, fold_ih = false;
   GruWide wide;
   if (gru_pick_wide(B, Hd, P2, &wide) > 0) {
-    float* xb = scratch + ((((size_t)(p_ih - scratch) + (size_t)GRU_NSPLIT * 3 * Hd * (W + 1)) + 3) & ~(size_t)3);
+    float* xb = scratch + ((((size_t)(p_ih - scratch) + (size_t)gru_ih_slabs(B) * 3 * Hd * (W + 1)) + 3) & ~(size_t)3);
     SG_TRY(gru_wide_bwd(dh_all, w_hh, h_all, reserve, B, S, Hd, wide, xb, status, dgi, dghn, st));
   } else if (P2 > 0) {
     // Time segmentation (side streams given): the S steps run as T launches; as soon as a segment's gate gradients are
@@ -1217,7 +1222,7 @@ extern "C" int stemgnn_gru_bwd(const float* dh_all, const float* x, const float*
     }
     hipEvent_t* ev = T > 1 ? gru_events() : nullptr;
     if (T > 1 && !ev) T = 1;
-    float* xtail = scratch + ((((size_t)(p_ih - scratch) + (size_t)GRU_NSPLIT * 3 * Hd * (W + 1)) + 1) & ~(size_t)1);
+    float* xtail = scratch + ((((size_t)(p_ih - scratch) + (size_t)gru_ih_slabs(B) * 3 * Hd * (W + 1)) + 1) & ~(size_t)1);
     gru_u64* xbuf = (gru_u64*)xtail;
     float* carry = xtail + gru_xbuf_floats(B, Hd);
     unsigned* progress = (unsigned*)(carry + (size_t)B * Hd);
@@ -1258,9 +1263,14 @@ extern "C" int stemgnn_gru_bwd(const float* dh_all, const float* x, const float*
                             else if (KU2 == 58) GRU_B2K(PP, 58, OO); else GRU_B2K(PP, 64, OO); } while (0)
       const char* e4 = getenv("STEMGNN_GRU_V4");
       const bool v4 = !(e4 && atoi(e4) == 0) && P2 <= 4 && T == 1 && s_mark < 0;
+      // dW_ih | db_ih accumulated by the chore wave while the gate gradients pass through it: one slab per batch row
+      // instead of the split-K GEMM behind the recurrence (STEMGNN_GRU_FOLD_IH=0: keep the GEMM)
+      const char* ef = getenv("STEMGNN_GRU_FOLD_IH");
+      fold_ih = v4 && W <= GRU4_WMAX && !(ef && atoi(ef) == 0);
+      float* ih_slab = fold_ih ? p_ih : nullptr;
 #define GRU_B4K(PP, KK) do { const size_t hog = gru_lds_hog4<PP>((const void*)gru_bwd_cluster4_kernel<PP, KK>); \
     hipLaunchKernelGGL((gru_bwd_cluster4_kernel<PP, KK>), grid, dim3((3 * PP + 2) * 64), hog, st, dh_all, w_hh, h_all, reserve, B, S, \
-                       Hd, xbuf, status, dgi, dghn, xid0, allow_fast); } while (0)
+                       Hd, xbuf, status, dgi, dghn, xid0, allow_fast, x, ih_slab, W); } while (0)
 #define GRU_B4(PP) do { if (KU2 == 32) GRU_B4K(PP, 32); else if (KU2 == 48) GRU_B4K(PP, 48); \
                         else if (KU2 == 58) GRU_B4K(PP, 58); else GRU_B4K(PP, 64); } while (0)
       if (v4) {
@@ -1303,7 +1313,7 @@ extern "C" int stemgnn_gru_bwd(const float* dh_all, const float* x, const float*
     segmented = T > 1 || s_mark > 0;
   } else if (P > 0) {
     const GruCluster c = gru_cluster_geom(Hd, P);
-    gru_u64* xbuf = (gru_u64*)(scratch + ((((size_t)(p_ih - scratch) + (size_t)GRU_NSPLIT * 3 * Hd * (W + 1)) + 1) & ~(size_t)1));
+    gru_u64* xbuf = (gru_u64*)(scratch + ((((size_t)(p_ih - scratch) + (size_t)gru_ih_slabs(B) * 3 * Hd * (W + 1)) + 1) & ~(size_t)1));
     if (P > 1) SG_TRY(hipMemsetAsync(xbuf, 0, (size_t)2 * B * 3 * Hd * sizeof(gru_u64), st));
     const size_t lds = (size_t)(3 * Hd + GRU_KC + c.U + c.ksb * c.U) * sizeof(float);
     const dim3 grid(8 * ((B + 7) / 8) * P);
@@ -1328,7 +1338,7 @@ extern "C" int stemgnn_gru_bwd(const float* dh_all, const float* x, const float*
       SG_TRY(hipStreamWaitEvent(s2, ev[10], 0));
     }
     const int rc = gru_wgrad_rows(dgi, dghn, h_ext, x, p_hh, p_ih, B, S, Hd, W, 0, S * B, 0, GRU_NSPLIT, st,
-                                  ev && tail_par ? s2 : st);
+                                  ev && tail_par ? s2 : st, !fold_ih);
     if (rc) return rc;
     if (ev && tail_par) {
       SG_TRY(hipEventRecord(ev[11], s2));
@@ -1342,10 +1352,11 @@ extern "C" int stemgnn_gru_bwd(const float* dh_all, const float* x, const float*
     J.part[1] = p_hh + (size_t)GRU_NSPLIT * n0; J.out_w[1] = dw_hh + (size_t)2 * Hd * Hd; J.out_b[1] = db_hh + 2 * Hd;
     J.rows[1] = Hd; J.cols[1] = Hd;
     J.part[2] = p_ih; J.out_w[2] = dw_ih; J.out_b[2] = db_ih; J.rows[2] = 3 * Hd; J.cols[2] = W;
+    J.nsplit[0] = J.nsplit[1] = GRU_NSPLIT; J.nsplit[2] = fold_ih ? B : GRU_NSPLIT;
     size_t nmax = n0;
     const size_t n2 = (size_t)3 * Hd * (W + 1);
     if (n2 > nmax) nmax = n2;
-    hipLaunchKernelGGL(gru_reduce_grad_kernel, dim3((unsigned)((nmax + 255) / 256), 3), dim3(256), 0, st, J, GRU_NSPLIT);
+    hipLaunchKernelGGL(gru_reduce_grad_kernel, dim3((unsigned)((nmax + 255) / 256), 3), dim3(256), 0, st, J);
     SG_TRY(hipGetLastError());
   }
   return 0;

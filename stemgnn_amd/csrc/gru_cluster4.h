@@ -96,6 +96,7 @@ constexpr int gru4_static_lds_floats(int P, int nin, int nout) { return 2 * 3 * 
 // wave between #s and #s+1, moved to global memory by the chore wave between #s+1 and #s+2, rewritten after #s+2.
 // The chore wave issues its global loads / stores only after a pause that lets the gate wave's granule stores go first:
 // the CU's memory pipeline is in order, and a granule store queued behind HBM loads costs the whole cluster a step time.
+constexpr int GRU4_WMAX = 16;            // window lengths up to this have dW_ih accumulated inside the backward recurrence
 #ifndef GRU_CHORE_SLEEP_F
 #define GRU_CHORE_SLEEP_F 16            // x 64 cycles after the barrier (the forward gate phase takes ~700)
 #endif
@@ -261,7 +262,9 @@ __global__ __launch_bounds__((3 * P + 2) * 64) void gru_bwd_cluster4_kernel(cons
                                                                             const float* __restrict__ reserve, int B, int S, int Hd,
                                                                             gru_u64* __restrict__ xbuf, int* __restrict__ status,
                                                                             float* __restrict__ dgi, float* __restrict__ dghn,
-                                                                            gru_u64* __restrict__ xid, int allow_fast) {
+                                                                            gru_u64* __restrict__ xid, int allow_fast,
+                                                                            const float* __restrict__ x, float* __restrict__ ih_slab,
+                                                                            int W) {
   constexpr int NMV = 3 * P;
   __shared__ float part[2][NMV][64];
   __shared__ __attribute__((aligned(16))) float lrow[NMV][64];
@@ -340,6 +343,30 @@ __global__ __launch_bounds__((3 * P + 2) * 64) void gru_bwd_cluster4_kernel(cons
         dghn[rw * Hd + gu] = dnr;
       }
     };
+    // dW_ih | db_ih of this workgroup's units and batch row, accumulated over the steps as the gate gradients pass through
+    // on their way to global memory (ih_slab != nullptr, W <= GRU4_WMAX): acc[g][w] += d_g(t) * x[b][w][t].  x is read
+    // with wave-uniform (scalar) loads.  The slab row (b, gate row) is reduced over b by gru_reduce_grad_kernel.
+    float acc[3][GRU4_WMAX], accb[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+      for (int w = 0; w < GRU4_WMAX; ++w) acc[g][w] = 0.f;
+    const float* xrow = x + (size_t)b * W * S;           // x[b][w][t] = xrow[w * S + t]
+    auto wih_x = [&](int t, float (&xv)[GRU4_WMAX]) {     // the W window values of step t: independent scalar loads, no branches
+      if (!ih_slab) return;
+#pragma unroll
+      for (int w = 0; w < GRU4_WMAX; ++w) xv[w] = xrow[(size_t)(w < W ? w : 0) * S + t];
+    };
+    auto wih = [&](const float (&xv)[GRU4_WMAX], float dr, float dz, float dn) {
+      if (!ih_slab) return;
+      accb[0] += dr; accb[1] += dz; accb[2] += dn;
+#pragma unroll
+      for (int w = 0; w < GRU4_WMAX; ++w) {              // (columns w >= W accumulate a copy of column 0 and are never stored)
+        acc[0][w] = fmaf(dr, xv[w], acc[0][w]);
+        acc[1][w] = fmaf(dz, xv[w], acc[1][w]);
+        acc[2][w] = fmaf(dn, xv[w], acc[2][w]);
+      }
+    };
     float val[6];
     fetch(S - 1, val);
     stage(S - 1, val);
@@ -350,6 +377,8 @@ __global__ __launch_bounds__((3 * P + 2) * 64) void gru_bwd_cluster4_kernel(cons
       float dr = 0.f, dz = 0.f, dn = 0.f, dnr = 0.f;
       const bool have = s + 1 <= S - 1;
       if (have) { dr = bout[(s + 1) & 1][0][lane]; dz = bout[(s + 1) & 1][1][lane]; dn = bout[(s + 1) & 1][2][lane]; dnr = bout[(s + 1) & 1][3][lane]; }
+      float xv[GRU4_WMAX];
+      if (have) wih_x(s + 1, xv);                        // scalar-cache loads: not in the vector memory pipeline's way
       __builtin_amdgcn_s_sleep(GRU_CHORE_SLEEP_B);       // let the granule stores of gate(s) go first
       if (s >= 2) fetch(s - 2, val);
       if (have && lane_ok) {
@@ -358,11 +387,25 @@ __global__ __launch_bounds__((3 * P + 2) * 64) void gru_bwd_cluster4_kernel(cons
         go[0] = dr; go[Hd] = dz; go[2 * Hd] = dn;
         dghn[rw * Hd + gu] = dnr;
       }
+      if (have) wih(xv, dr, dz, dn);
       gru_lds_barrier();                                 // B_s
     }
     gru_lds_barrier();                                   // B_fin: gate(0) is done
-    if (S >= 2) flush(1);
+    float xv[GRU4_WMAX];
+    if (S >= 2) { flush(1); wih_x(1, xv); wih(xv, bout[1][0][lane], bout[1][1][lane], bout[1][2][lane]); }
     flush(0);
+    wih_x(0, xv);
+    wih(xv, bout[0][0][lane], bout[0][1][lane], bout[0][2][lane]);
+    if (ih_slab && lane_ok) {
+#pragma unroll
+      for (int g = 0; g < 3; ++g) {
+        float* o = ih_slab + ((size_t)b * H3 + (size_t)g * Hd + gu) * (W + 1);
+#pragma unroll
+        for (int w = 0; w < GRU4_WMAX; ++w)
+          if (w < W) o[w] = acc[g][w];
+        o[W] = accb[g];
+      }
+    }
   } else {
     // ---------------- gate wave ----------------
     float dhz = 0.f;
