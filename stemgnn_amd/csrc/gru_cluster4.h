@@ -98,10 +98,10 @@ constexpr int gru4_static_lds_floats(int P, int nin, int nout) { return 2 * 3 * 
 // the CU's memory pipeline is in order, and a granule store queued behind HBM loads costs the whole cluster a step time.
 constexpr int GRU4_WMAX = 16;            // window lengths up to this have dW_ih accumulated inside the backward recurrence
 #ifndef GRU_CHORE_SLEEP_F
-#define GRU_CHORE_SLEEP_F 16            // x 64 cycles after the barrier (the forward gate phase takes ~700)
+#define GRU_CHORE_SLEEP_F 20            // x 64 cycles after the barrier (the forward gate phase takes ~700)
 #endif
 #ifndef GRU_CHORE_SLEEP_B
-#define GRU_CHORE_SLEEP_B 12
+#define GRU_CHORE_SLEEP_B 10
 #endif
 template <int P, int KU>
 __global__ __launch_bounds__((P + 2) * 64) void gru_fwd_cluster4_kernel(const float* __restrict__ gi, const float* __restrict__ w_hh,
