@@ -43,7 +43,7 @@ __device__ __forceinline__ void gru4_after_publish(const gru_u64* g) {
 #define GRU_POLL_MODE 0
 #endif
 #ifndef GRU_POLL_PRE_F
-#define GRU_POLL_PRE_F 14
+#define GRU_POLL_PRE_F 12
 #endif
 #ifndef GRU_POLL_PRE_B
 #define GRU_POLL_PRE_B 9
