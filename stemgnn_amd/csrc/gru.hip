@@ -12,6 +12,15 @@
 // (x W_ih^T + b_ih, no recurrence) and the weight gradients (reductions over all S*B rows) are
 // ordinary GEMMs on the exact-fp32 MFMA core.
 //
+// Kernel generations in this file (the host entry points pick the newest one that fits the shape; the older ones stay
+// selectable by environment switches for A/B runs and as fallbacks, all parity-tested):
+//   streaming        gru_fwd_kernel / gru_bwd_kernel             one workgroup per batch row, W_hh re-streamed from L2
+//   cluster v1       gru_*_cluster_kernel                        P workgroups per row, weights resident, LDS staging
+//   cluster v2       gru_*_cluster2_kernel<P, KU, OW>            wave-level exchange: wave (gate, owner) polls + multiplies
+//   cluster v3       gru_fwd_cluster3_kernel<P, KU>              forward: one wave per owner, three gates per broadcast
+//   cluster v4       gru_cluster4.h                              wave specialisation (gate / chore / mat-vec waves) -- default
+//   wide cluster     gru_wide.h                                  hidden > 512: one cluster per GPU, MFMA mat-vec
+//
 // PyTorch GRU semantics:  r = s(gi_r + gh_r), z = s(gi_z + gh_z), n = tanh(gi_n + r * gh_n),
 //                         h' = (1 - z) * n + z * h,   gi = x W_ih^T + b_ih, gh = h W_hh^T + b_hh.
 #include <hip/hip_runtime.h>

@@ -1,22 +1,28 @@
-// Cluster recurrence v4 (P <= 4 workgroups per batch row, U = ceil(Hd/P) <= 64): WAVE SPECIALISATION.
+// Cluster recurrence v4 (U = ceil(Hd/P) <= 64; forward: any P <= 8, backward: P <= 4): WAVE SPECIALISATION.
 //
 // What bounds a recurrence step is not FLOPs or bytes but the number of instructions the busiest wave has to ISSUE (a wave
-// issues one instruction every ~4-5 cycles whatever its kind; measured with -DGRU_PROF, profiles/r02_gru_phase_cycles.txt):
-// in the v2 / v3 kernels wave 0 ran the gate phase (LDS partial sums, gate math, granule stores), the global loads of the
-// next step's inputs with their 64-bit address arithmetic, the global stores of the saved gates AND its own mat-vec slice
-// -- 800-930 cycles of gate phase plus a 1100-cycle mat-vec, the whole critical path of the step, while the other waves
-// sat in their poll loops.  Here
-//   * wave 3P is the GATE wave: barrier -> partial sums and inputs from LDS -> gate math -> granule stores -> results
-//     into an LDS stash.  No global loads, no global data stores, no mat-vec.
-//   * waves 0 .. 3P-1 are the MAT-VEC waves (gate g, owner slice q) as in v2; every slice -- the workgroup's own units
-//     included -- arrives through the granule exchange.  Poll -> mat-vec -> partial sum into LDS, nothing else: a global
-//     store or load issued ahead of a poll would hold the poll back (vmcnt retires in order).
-//   * wave 3P+1 is the CHORE wave: it fetches the next step's gate inputs from global memory into LDS and moves the
-//     previous step's stash to global memory.  It never polls, so it may wait for its memory operations at leisure.
-// The arithmetic (mat-vec chains, order of the partial sums, gate formulas) is that of the v2 kernels: the hidden states
-// are bit-identical, the gradients agree to rounding (the compiler contracts the gate-gradient products differently in
-// the two kernels) (tests/test_hip_gru_eigh.py).  LDS buffers are double buffered by step parity; the hand-offs
-// (who writes / reads which parity between which two barriers) are spelled out at each buffer below.
+// issues one instruction every ~4-5 cycles whatever its kind; measured with -DGRU_PROF, profiles/r02_gru_phase_cycles.txt,
+// profiles/r02_gru_wave_specialisation.md): in the v2 / v3 kernels wave 0 ran the gate phase (LDS partial sums, gate math,
+// granule stores), the global loads of the next step's inputs with their 64-bit address arithmetic, the global stores of
+// the saved gates AND its own mat-vec slice -- 800-930 cycles of gate phase plus a 1100-cycle mat-vec, the whole critical
+// path of the step, while the other waves sat in their poll loops.  Here the waves of a workgroup have roles:
+//   * the MAT-VEC waves -- forward: P of them, owner slice q for all three gates (one broadcast of h_k serves three
+//     v_pk_fma); backward: 3P, (gate g, owner slice q) -- poll their slice's granules (the workgroup's own units included:
+//     every slice arrives through the exchange), multiply, leave a partial sum in LDS.  Nothing else: a global store or
+//     load issued ahead of a poll would hold the poll back (vmcnt retires in order).
+//   * ONE GATE wave: barrier -> partial sums and inputs from LDS -> gate math -> granule stores -> results into an LDS
+//     stash.  No global loads, no global data stores, no mat-vec.
+//   * ONE CHORE wave: it fetches the next step's gate inputs from global memory into LDS (one step ahead), moves the
+//     previous step's stash to global memory and, in the backward, accumulates dW_ih | db_ih from the gate gradients
+//     passing through it.  It never polls, so it may wait for its memory operations at leisure.
+//   * Timing: the chore wave and the pollers SLEEP through the gate phase.  The CU's vector-memory pipeline is in order; a
+//     granule store queued behind HBM loads or behind a dozen waves' poll loads reaches the L2 late and every partner of
+//     the cluster waits for it.  The sleep lengths (GRU_CHORE_SLEEP_*, GRU_POLL_PRE_*) are tuned on MI355X and only
+//     affect speed, never the result.
+// The arithmetic (mat-vec chains, order of the partial sums, gate formulas) is that of the v2 kernels: with the same P the
+// hidden states are bit-identical, the gradients agree to rounding (the compiler contracts the gate-gradient products
+// differently in the two kernels) (tests/test_hip_gru_eigh.py).  LDS buffers are double buffered by step parity; the
+// hand-offs (who writes / reads which parity between which two barriers) are spelled out at each kernel below.
 #pragma once
 
 // A/B hook (-DGRU_PUB_PUSH=n): what the gate wave does right after its granule stores.  0: nothing; 1: wait for their
