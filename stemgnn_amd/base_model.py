@@ -90,9 +90,9 @@ class Model(nn.Module):
     def __init__(self, units, stack_cnt, time_step, multi_layer, horizon=1, dropout_rate=0.5, leaky_rate=0.2,
                  device='cpu'):
         super().__init__()
-        if stack_cnt != 2:
-            # the reference hard-codes result[0] + result[1] (:174) and the driver passes 2 (handler.py:105)
-            raise ValueError("StemGNN's forward sums exactly two StockBlocks; stack_cnt must be 2")
+        # Like the reference, the constructor builds `stack_cnt` blocks for ANY count (:93-95) -- same state_dict -- and it is
+        # forward that only works for 2: it sums result[0] + result[1] (:174) and block >= 1 hands None on as the next
+        # block's input (:73-75), so 3+ fails on None.unsqueeze and < 2 on result[1]; hot_path reproduces both failures.
         self.unit, self.stack_cnt, self.alpha = units, stack_cnt, leaky_rate
         self.time_step, self.horizon, self.multi_layer = time_step, horizon, multi_layer
         self.dropout_rate = float(dropout_rate)
@@ -142,12 +142,30 @@ class Model(nn.Module):
         self._instance = next(_instance_counter)
         self.hot_state = ops.HotPathState()
 
+    def train(self, mode=True):
+        """nn.Module.train plus the device-side health check of the persistent GRU cluster kernels: the reference driver
+        toggles train()/eval() once per epoch / validation pass (models/handler.py:154, :44), so a lost partner workgroup
+        (status word set by csrc/gru.hip) raises here instead of training on silently wrong hidden states.  One host
+        sync per toggle; skipped while a hipGraph capture is running and before any GRU kernel has run."""
+        out = super().train(mode)
+        dev = self.weight_key.device if hasattr(self, "weight_key") else None
+        if dev is not None and dev.type == "cuda" and ops.gru_status_exists(dev) \
+                and not torch.cuda.is_current_stream_capturing():
+            ops.check_gru_status(dev)
+            if os.environ.get("STEMGNN_SPECTRAL", "cheb") == "eig":
+                ops.check_eigh_status()
+        return out
+
     # -- forward --------------------------------------------------------------------------------------
     def hot_path(self, x):
         """GRU (library) then the HIP hot path; returns (block forecast sum [B,N,W], attention, mul_L)."""
         if not x.is_cuda:
             raise _lib.StemGNNHipError(
                 f"input is on {x.device}: stemgnn_amd.Model runs only on a HIP device (no CPU fallback)")
+        if self.stack_cnt > 2:        # reference: block 1 returns backcast None (:73-75) -> block 2's x.unsqueeze(1) (:63)
+            raise AttributeError("'NoneType' object has no attribute 'unsqueeze'")
+        if self.stack_cnt < 2:        # reference: result[0] + result[1] (:174)
+            raise IndexError("list index out of range")
         x = x.contiguous()
         blocks = (self.stock_block[0].hip_params(), self.stock_block[1].hip_params())
         use_drop = self.training and self.dropout_rate > 0.0

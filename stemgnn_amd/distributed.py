@@ -39,13 +39,14 @@ class FlatGradBucket:
     def zero(self):
         self.flat.zero_()
 
-    def all_reduce_sum(self, group=None):
+    def all_reduce_sum(self, group=None, force=False):
         """SUM over the ranks; the consumer scales by 1 / world (FusedRMSprop.grad_scale: inside the optimizer kernel,
-        no separate averaging pass over the bucket)."""
+        no separate averaging pass over the bucket).  `force`: issue the collective even in a one-rank group (RCCL
+        readiness tests on a 1-GPU box: same call, same stream semantics, result unchanged)."""
         if self.flat.is_cuda:
             from .ops import join_side_streams
             join_side_streams(self.flat.device)      # weight gradients may still be in flight on the side stream
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        if dist.is_available() and dist.is_initialized() and (force or dist.get_world_size(group) > 1):
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
             return dist.get_world_size(group)
         return 1

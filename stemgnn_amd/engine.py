@@ -5,9 +5,10 @@
 
 With ``FusedRMSprop`` the whole step is captured once into a hipGraph (two graphs around the all-reduce when
 world > 1) and replayed per batch: the host only copies B int64 indices into a static buffer.  A ragged last batch
-(``drop_last=False``) or another optimizer runs the same code eagerly.  Used by ``stemgnn_amd.handler.train`` and
+(``drop_last=False``) or another optimizer runs the same code eagerly.  Used by ``stemgnn_amd.trainer.DeviceTrainer`` and
 ``bench.py`` -- the benchmark measures exactly what the driver runs.
 """
+import os
 import sys
 
 import torch
@@ -46,14 +47,21 @@ def capture(fn, warmups=3, on_fail=None):
 
 class TrainStep:
     def __init__(self, model, optimizer, batch_size, window_size, horizon, units, series=None, world=1, graph=True,
-                 exact=False, group=None):
+                 exact=False, group=None, collective=None, one_graph=None):
+        """collective: run the data-parallel step structure (gradient all-reduce between backward and optimizer); default
+        world > 1, True forces it for a one-rank group (RCCL readiness on a 1-GPU box).  one_graph: capture the
+        all-reduce INSIDE the step's hipGraph (one replay per step) instead of graph / eager collective / graph; default
+        from STEMGNN_DDP_ONE_GRAPH (off: RCCL capture has only ever run with one rank here); a failed
+        capture falls back to the two-graph form."""
         self.model, self.opt = model, optimizer
+        self.collective = (world > 1) if collective is None else bool(collective)
+        self.one_graph = (os.environ.get("STEMGNN_DDP_ONE_GRAPH", "0") == "1") if one_graph is None else bool(one_graph)
         self.B, self.W, self.H, self.N = int(batch_size), int(window_size), int(horizon), int(units)
         self.world = world
         dev = next(model.parameters()).device
         self.device = dev
         self.fused = hasattr(optimizer, "bucket")                       # FusedRMSprop: flat params + flat grads
-        self.bucket = optimizer.bucket if self.fused else (FlatGradBucket(model.parameters()) if world > 1 else None)
+        self.bucket = optimizer.bucket if self.fused else (FlatGradBucket(model.parameters()) if self.collective else None)
         self.state = ops.set_direct_grad(model, self.fused, overlap=self.fused)   # scoped to THIS model
         self.fuse_zero = self.fused and getattr(optimizer, "fuse_zero_grad", False)
         self.series = series                                            # [T,N] fp32 resident, or None: x/y given
@@ -67,8 +75,10 @@ class TrainStep:
         self._one = torch.ones((), device=dev)
         self.want_graph = bool(graph) and self.fused
         self.group = group
-        if world > 1 and self.fused:
-            optimizer.grad_scale = 1.0 / world          # the all-reduce SUMs; the optimizer kernel applies 1 / world
+        if self.fused:
+            # the all-reduce SUMs; the optimizer kernel applies 1 / world.  Passed per step (see _finish): the optimizer
+            # object itself is left as it was, so using it elsewhere with all_reduce_mean does not double-scale
+            self._grad_scale = 1.0 / world if self.collective else 1.0
         if exact and world > 1:
             # exact data-parallel mode: A and dA are averaged over the ranks inside forward / backward
             # (two host-launched [N,N] collectives), so the step cannot be one captured graph: it runs eagerly
@@ -95,12 +105,19 @@ class TrainStep:
         return self.loss
 
     def _finish(self, loss):
-        self.opt.step()                                                 # :165
+        if not self.fused:
+            self.opt.step()                                             # :165
+            return
+        prev, self.opt.grad_scale = self.opt.grad_scale, self._grad_scale
+        try:
+            self.opt.step()
+        finally:
+            self.opt.grad_scale = prev
 
     def _sync(self):
-        if self.world > 1:
+        if self.collective:
             if self.fused:
-                self.bucket.all_reduce_sum(self.group)
+                self.bucket.all_reduce_sum(self.group, force=True)
             else:
                 self.bucket.all_reduce_mean(self.group)
 
@@ -109,22 +126,25 @@ class TrainStep:
         self._armed = True
         if not self.want_graph:
             return
-        if self.world == 1:
+        if not self.collective or self.one_graph:
             def whole():
-                self._finish(self._fwd_bwd(self.hi, self.x, self.y))
+                loss = self._fwd_bwd(self.hi, self.x, self.y)
+                self._sync()                                        # no-op unless the collective is captured too
+                self._finish(loss)
             snap = self._snapshot()
             rep = capture(whole, on_fail=self.state.reset)
             self._restore(snap)
             if rep is not None:
-                self._replay, self.mode = rep, "hipgraph(whole step)"
-        else:
+                self._replay = rep
+                self.mode = "hipgraph(whole step incl. rccl all-reduce)" if self.collective else "hipgraph(whole step)"
+        if self._replay is None and self.collective:
             box = {}
 
             def part_a():
                 box["loss"] = self._fwd_bwd(self.hi, self.x, self.y)
 
             def part_b():
-                self.opt.step()
+                self._finish(box.get("loss"))
             snap = self._snapshot()
             ra = capture(part_a, on_fail=self.state.reset)
             rb = capture(part_b, on_fail=self.state.reset) if ra is not None else None

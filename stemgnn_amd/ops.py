@@ -64,7 +64,10 @@ class HotPathState:
         """Drop queued side-stream work after a failed capture / aborted step (engine.capture)."""
         for item in (self.prepacked, self.pending):
             if item is not None:
-                (item[1] if item is self.prepacked else item[0]).synchronize()
+                try:        # the stream may have been forked into the capture that just failed (invalidated capture)
+                    (item[1] if item is self.prepacked else item[0]).synchronize()
+                except RuntimeError:
+                    pass    # engine.capture synchronizes the device afterwards anyway
         self.prepacked = None
         self.pending = None
 
@@ -157,6 +160,11 @@ def gru_status(device):
     return t
 
 
+def gru_status_exists(device):
+    """True once a GRU kernel has been launched on `device` (the status word is created by the first launch)."""
+    return str(device) in _gru_status
+
+
 def check_eigh_status():
     """Host sync + raise if a grid-barrier wait of the direct eigensolver timed out (STEMGNN_SPECTRAL=eig only)."""
     rc = _lib.load().stemgnn_eigh_status()
@@ -166,7 +174,9 @@ def check_eigh_status():
 
 def check_gru_status(device):
     """Host sync + raise if a GRU exchange timed out (call outside timed regions / in tests)."""
-    if int(gru_status(device).item()) != 0:
+    st = gru_status(device)
+    if int(st.item()) != 0:
+        st.zero_()                               # report once; the next check sees only new time-outs
         raise _lib.StemGNNHipError("GRU cluster exchange timed out (partner workgroup not resident?); "
                                    "set STEMGNN_GRU_CLUSTER=0 to use the single-workgroup kernels")
 
@@ -217,8 +227,8 @@ class GruFront(torch.autograd.Function):
             dw_ih, dw_hh = torch.empty_like(w_ih), torch.empty_like(w_hh)
             db_ih = torch.empty(3 * Hd, device=dev, dtype=f32)
             db_hh = torch.empty(3 * Hd, device=dev, dtype=f32)
-        # overlap mode: the recurrence runs as time segments whose weight-gradient GEMMs go to two side streams (forked
-        # from and joined back to the current stream inside the call)
+        # the two side-stream handles are only used by the opt-in schedules (STEMGNN_GRU_SEGMENTS / _MARK / _TAIL_PAR, all
+        # off by default: measured slower inside the hipGraph step); the default path runs on the current stream alone
         sides = (_side_stream(dev).cuda_stream, _side_stream(dev, 1).cuda_stream) if ctx.state.overlap else (None, None)
         _lib.check(lib.stemgnn_gru_bwd(dh_all.data_ptr(), x.data_ptr(), w_hh.data_ptr(), h_ext.data_ptr(),
                                        reserve.data_ptr(), B, S, Hd, W, scratch.data_ptr(), dw_ih.data_ptr(),

@@ -41,6 +41,21 @@ class FusedRMSprop(torch.optim.Optimizer):
     def zero_grad(self, set_to_none=False):   # gradients live in the flat bucket; never drop the views
         self.bucket.zero()
 
+    def _check_grad_views(self):
+        """The step reads the FLAT gradient buffer: every p.grad must still be its view (torch's default
+        model.zero_grad(set_to_none=True) drops them -> backward would fill fresh tensors and the step would see zeros).
+        Object identity first (what attach() stored; a handful of ns per parameter on the launch-bound eager path), the
+        device-pointer comparison only for a .grad someone replaced."""
+        for p, view in zip(self.bucket.params, self.bucket.views):
+            g = p.grad
+            if g is view:
+                continue
+            if g is None or g.data_ptr() != view.data_ptr():
+                raise _lib.StemGNNHipError(
+                    f"{type(self).__name__}: a parameter's .grad is no longer the flat-bucket view (model.zero_grad() with "
+                    "set_to_none=True?).  Use optimizer.zero_grad() / model.zero_grad(set_to_none=False), or call "
+                    "optimizer.bucket.attach() before backward.")
+
     def sync_lr(self):
         """Push a learning rate an LR scheduler changed (host side) to the device word the kernel reads.  step() calls
         it; a hipGraph replay does not run step()'s Python, so engine.TrainStep calls it before every replay."""
@@ -56,14 +71,7 @@ class FusedRMSprop(torch.optim.Optimizer):
         self.sync_lr()
         from .ops import join_side_streams
         join_side_streams(self.flat_p.device)
-        # the step reads the FLAT gradient buffer: every p.grad must still be its view (torch's default
-        # model.zero_grad(set_to_none=True) drops them -> backward would fill fresh tensors and this step would see zeros)
-        for p, view in zip(self.bucket.params, self.bucket.views):
-            if p.grad is None or p.grad.data_ptr() != view.data_ptr():
-                raise _lib.StemGNNHipError(
-                    "FusedRMSprop: a parameter's .grad is no longer the flat-bucket view (model.zero_grad() with "
-                    "set_to_none=True?).  Use optimizer.zero_grad() / model.zero_grad(set_to_none=False), or call "
-                    "optimizer.bucket.attach() before backward.")
+        self._check_grad_views()
         lib = _lib.load()
         _lib.check(lib.stemgnn_rmsprop_step(
             self.flat_p.data_ptr(), self.bucket.flat.data_ptr(), self.square_avg.data_ptr(), self.numel,
@@ -92,10 +100,7 @@ class FusedAdam(FusedRMSprop):
         self.sync_lr()
         from .ops import join_side_streams
         join_side_streams(self.flat_p.device)
-        for p, view in zip(self.bucket.params, self.bucket.views):
-            if p.grad is None or p.grad.data_ptr() != view.data_ptr():
-                raise _lib.StemGNNHipError("FusedAdam: a parameter's .grad is no longer the flat-bucket view "
-                                           "(use optimizer.zero_grad() or optimizer.bucket.attach())")
+        self._check_grad_views()
         b1, b2 = group["betas"]
         lib = _lib.load()
         _lib.check(lib.stemgnn_adam_step(

@@ -1,0 +1,95 @@
+"""Run under `python -m torch.distributed.run --nproc-per-node 1 ...` on a GPU box: RCCL readiness with ONE rank.
+
+  1. init_process_group("nccl") (= RCCL) on the visible GPU;
+  2. FlatGradBucket.all_reduce_sum forced through dist.all_reduce: values unchanged, ordering against the side stream kept;
+  3. PROBE: can dist.all_reduce be captured inside torch.cuda.graph on this stack (and replayed)?  Recorded, not asserted;
+  4. TrainStep in collective form (hipGraph fwd+bwd -> RCCL all-reduce -> hipGraph optimizer) equals the plain one-graph
+     step bit for bit; with one_graph=True (collective captured inside the graph) as well, when 3. says yes.
+Prints one JSON line (last line of stdout).
+"""
+import json
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+
+
+def train_losses(collective, one_graph, steps=6):
+    from stemgnn_amd import Model
+    from stemgnn_amd.engine import TrainStep
+    from stemgnn_amd.optim import FusedRMSprop
+    N, W, H, multi, B = 20, 12, 3, 5, 8
+    torch.manual_seed(0)
+    model = Model(N, 2, W, multi, horizon=H, dropout_rate=0.0).to("cuda").train()
+    opt = FusedRMSprop(model.parameters(), lr=1e-3, eps=1e-8)
+    g = torch.Generator().manual_seed(3)
+    series = torch.randn(400, N, generator=g).cuda()
+    hi = (torch.randperm(380, generator=g)[: steps * B] + W).cuda().view(steps, B)
+    st = TrainStep(model, opt, B, W, H, N, series=series, world=1, collective=collective, one_graph=one_graph)
+    out = []
+    for i in range(steps):
+        st.run_indices(hi[i])
+        out.append(float(st.loss.item()))
+    return out, st.mode, opt.flat_p.clone()
+
+
+def main():
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+    dev = torch.device("cuda", torch.cuda.current_device())
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    res = {"world": world, "backend": dist.get_backend()}
+
+    from stemgnn_amd.distributed import FlatGradBucket
+    ps = [torch.nn.Parameter(torch.randn(257, 3, device=dev)), torch.nn.Parameter(torch.randn(1000, device=dev))]
+    bucket = FlatGradBucket(ps)
+    bucket.flat.copy_(torch.randn_like(bucket.flat))
+    before = bucket.flat.clone()
+    w = bucket.all_reduce_sum(force=True)
+    torch.cuda.synchronize()
+    res["allreduce_world"] = w
+    res["allreduce_unchanged"] = bool(torch.equal(before, bucket.flat))
+
+    try:                                           # the probe: a collective inside a captured graph
+        buf = torch.arange(1024, device=dev, dtype=torch.float32)
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            dist.all_reduce(buf)                   # warm-up outside capture (communicator set-up)
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
+            buf.mul_(2.0)
+            dist.all_reduce(buf)
+            buf.add_(1.0)
+        torch.cuda.synchronize()
+        ref = torch.arange(1024, device=dev, dtype=torch.float32)
+        for _ in range(3):
+            g.replay()
+            ref = ref * 2.0 * world + 1.0
+        torch.cuda.synchronize()
+        res["graph_capture_allreduce"] = bool(torch.equal(buf, ref))
+        res["graph_capture_error"] = None
+    except Exception as e:  # noqa: BLE001
+        res["graph_capture_allreduce"] = False
+        res["graph_capture_error"] = f"{type(e).__name__}: {e}"[:300]
+        torch.cuda.synchronize()
+
+    base, mode0, p0 = train_losses(False, False)
+    two, mode1, p1 = train_losses(True, False)
+    res.update(mode_plain=mode0, mode_collective=mode1, collective_equals_plain=bool(base == two and torch.equal(p0, p1)))
+    if res["graph_capture_allreduce"]:
+        one, mode2, p2 = train_losses(True, True)
+        res.update(mode_one_graph=mode2, one_graph_equals_plain=bool(base == one and torch.equal(p0, p2)))
+    dist.barrier()
+    dist.destroy_process_group()
+    print(json.dumps(res), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -132,3 +132,36 @@ def test_exact_mode_math_equals_single_process():
     _, _, _, grads = O.loss_and_grads(x, y, sd)
     ref = torch.cat([(g if g is not None else torch.zeros_like(sd[k])).reshape(-1) for k, g in grads.items()])
     assert float((out[0] - ref).abs().max()) <= 1e-12 * float(ref.abs().max()) + 1e-15
+
+ROOT_DIR = __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__)))
+
+
+def test_bench_self_launch_argv():
+    """`python bench.py --gpus N` without a launcher re-executes itself through torch.distributed.run with N ranks on
+    127.0.0.1; checked here by intercepting the command (no second GPU needed)."""
+    import importlib
+    import pytest
+    import sys
+    sys.path.insert(0, ROOT_DIR)
+    bench = importlib.import_module("bench")
+    seen = {}
+
+    def fake_run(cmd, env=None, **kw):
+        seen["cmd"], seen["env"] = cmd, env
+
+        class R:
+            returncode = 0
+        return R()
+    real, bench.subprocess.run = bench.subprocess.run, fake_run
+    argv = sys.argv
+    sys.argv = ["bench.py", "--gpus", "8", "--steps", "3"]
+    try:
+        with pytest.raises(SystemExit) as e:
+            bench._self_launch(type("A", (), {"gpus": 8})())
+        assert e.value.code == 0
+    finally:
+        bench.subprocess.run, sys.argv = real, argv
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=8" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-4:] == ["--gpus", "8", "--steps", "3"]
+    assert seen["env"].get("HSA_ENABLE_IPC_MODE_LEGACY") == "0"

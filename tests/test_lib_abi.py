@@ -102,3 +102,22 @@ def test_state_dict_contract_matches_reference_order():
     got = [(k, tuple(v.shape)) for k, v in m.state_dict().items()]
     assert got == list(shapes.items())
     assert [k for k, _ in m.named_parameters()] == list(shapes.keys())
+
+
+@pytest.mark.parametrize("stack_cnt", [1, 3])
+def test_constructor_accepts_any_stack_count_like_the_reference(stack_cnt):
+    """reference :93-95 builds `stack_cnt` blocks; only block 0 owns `backcast` (:29-30); train()/eval() on a CPU model
+    (never ran a kernel) must not touch the device."""
+    from stemgnn_amd import Model
+
+    m = Model(6, stack_cnt, 4, 2, horizon=2)
+    assert len(m.stock_block) == stack_cnt and hasattr(m.stock_block[0], "backcast")
+    assert all(not hasattr(b, "backcast") for b in m.stock_block[1:])
+    keys = list(m.state_dict().keys())
+    assert sum(k.startswith(f"stock_block.{stack_cnt - 1}.") for k in keys) > 0
+    m.eval(); m.train()
+    from oracle import ref_shim
+    if ref_shim.reference_available():
+        ref = ref_shim.load_reference_model_module().Model(6, stack_cnt, 4, 2, horizon=2)
+        assert [(k, tuple(v.shape)) for k, v in ref.state_dict().items()] == \
+               [(k, tuple(v.shape)) for k, v in m.state_dict().items()]
