@@ -12,6 +12,8 @@
 #include "gemm2.h"
 #include "gemm_core.h"
 #include "layout.h"
+#include "reduce.h"
+#include "wgrad.h"
 
 #define SG_TRY(e)                                \
   do {                                           \
@@ -599,6 +601,10 @@ static inline int g2_bk32_mask() {
 }
 // reductions longer than this use the two-level accumulating instantiations (large W*multi configurations)
 constexpr int SG_LONG_K = 640;
+static inline bool wg_fused_on() {
+  static const int v = getenv("STEMGNN_WG_FUSED") ? atoi(getenv("STEMGNN_WG_FUSED")) : 1;
+  return v != 0;
+}
 static inline int split_chunk(int M, int S) { return ((M + S - 1) / S + 15) & ~15; }
 
 extern "C" int stemgnn_gft_fwd(const float* mul_L, const float* X, long xs_b, long xs_n, long xs_t,
@@ -720,11 +726,29 @@ extern "C" int stemgnn_spectral_glu_bwd(const float* packed, const float* saved,
   const SgGradLayout Gl = sg_grad_layout(d, nsplit);
   hipStream_t st = (hipStream_t)stream;
   const int chunk = split_chunk(d.M, nsplit);
+  // weight gradients: part[q][kin | bias] = sum_m dpre[m][q] * x[m][kin].  Default: ONE launch of the fused kernel
+  // (csrc/wgrad.h: direct-to-LDS ring, few long splits, in-kernel fixed-order reduction) for all six products, queued
+  // after the data-gradient chain below.  Shapes that break its 16-byte rules (odd W*multi ...) and STEMGNN_WG_FUSED=0
+  // take the round-1 path: per layer a split-M slab GEMM, then one reduce over the GLU slabs.  Either way slab 0 of
+  // every GLU region holds the complete gradient when this function returns.
+  WgGemm wq[6];
+  bool fused = (parts & 2) && wg_fused_on();
+  if (parts & 2) {
+    for (int l = 0; l < 3; ++l)
+      for (int r = 0; r < 2; ++r) {
+        WgGemm& q = wq[l * 2 + r];
+        q.A = scratch + C.dact[r][l]; q.lda = sg_glu_np(d, l, r);
+        q.B = l == 0 ? saved + S.G : saved + S.out[r][l - 1]; q.ldb = l == 0 ? d.KG : d.CP;
+        q.out = gradpart + Gl.w[r][l];
+        q.Mi = sg_glu_np(d, l, r); q.Nj = sg_glu_kin(d, l) + 1; q.ones_col = sg_glu_kin(d, l);
+        fused = fused && wg_gemm_ok(q);
+      }
+  }
   for (int l = 2; l >= 0; --l) {
     // d(pre-activation) of layer l lives in dact[r][l] as [M x NP(l,r)] (pair order); it was written by
     // igft_heads_bwd (l = 2) or by the data-gradient epilogue of layer l+1
     const int slot = l;
-    if (parts & 2) {  // weight gradient: part[q][kin | bias] = sum_m dpre[m][q] * x[m][kin]   (split over the M rows)
+    if ((parts & 2) && !fused) {
       G2Args g;
       GluWgradEpi e;
       for (int r = 0; r < 2; ++r) {
@@ -766,6 +790,21 @@ extern "C" int stemgnn_spectral_glu_bwd(const float* packed, const float* saved,
       op.dG = scratch + C.dG; op.np0 = sg_glu_np(d, 0, 0); op.KG = d.KG; op.M = d.M;
       if (op.np0 > SG_LONG_K) SG_TRY((sg_launch_gemm<GluDgrad0Op, 32, 64, true, true, false, 64, true>(op, d.M, d.KG, 2, st)));
       else SG_TRY((sg_launch_gemm<GluDgrad0Op, 32, 64, true, true, false, 64>(op, d.M, d.KG, 2, st)));
+    }
+  }
+  if (parts & 2) {
+    if (fused) {
+      SG_TRY(wg_launch(wq, 6, d.M, gradpart + Gl.wg_ws, reinterpret_cast<unsigned*>(gradpart + Gl.wg_cnt), Gl.wg_smax, st));
+    } else if (nsplit > 1) {
+      SgSlabRegions R;
+      R.n = 0;
+      for (int r = 0; r < 2; ++r)
+        for (int l = 0; l < 3; ++l) {
+          R.off[R.n] = Gl.w[r][l];
+          R.slab[R.n] = (size_t)sg_glu_np(d, l, r) * (sg_glu_kin(d, l) + 1);
+          ++R.n;
+        }
+      SG_TRY(sg_reduce_slabs(gradpart, R, nsplit, st));
     }
   }
   return 0;

@@ -87,9 +87,24 @@ SG_HD SgPackedLayout sg_packed_layout(const SgDims& d) {
 struct SgGradLayout {
   size_t w[2][3];
   size_t wfold, fr, fc, bc, bs;
+  size_t wg_ws;          // fused weight-gradient kernel (csrc/wgrad.h): partial tiles [tile][split][128*128]
+  size_t wg_cnt;         // its arrival counters (one 32-bit word per tile), zeroed by a memset node per launch
   size_t total;
   int nsplit;
+  int wg_tiles, wg_smax;
 };
+// output tiles (128 x 128) of the six GLU weight gradients of one block, and the most splits the fused kernel will use
+// (pure functions of W / multi, so the caller-owned buffer can be sized without knowing the batch)
+SG_HD int sg_wg_tiles(const SgDims& d) {
+  int t = 0;
+  for (int r = 0; r < 2; ++r)
+    for (int l = 0; l < 3; ++l) t += sg_ceil_div(sg_glu_np(d, l, r), 128) * sg_ceil_div(sg_glu_kin(d, l) + 1, 128);
+  return t;
+}
+SG_HD int sg_wg_smax(int tiles) {
+  int s = sg_ceil_div(1024, tiles > 0 ? tiles : 1);     // up to 4 workgroups per CU worth of splits
+  return s > 32 ? 32 : (s < 1 ? 1 : s);
+}
 SG_HD SgGradLayout sg_grad_layout(const SgDims& d, int nsplit) {
   SgGradLayout L;
   L.nsplit = nsplit;
@@ -103,6 +118,11 @@ SG_HD SgGradLayout sg_grad_layout(const SgDims& d, int nsplit) {
   L.fc = off; off += S * d.Wm * (d.Wm + 1);
   L.bc = off; off += S * d.W * (d.Wm + 1);
   L.bs = off; off += S * d.W * (d.W + 1);
+  L.wg_tiles = sg_wg_tiles(d);
+  L.wg_smax = sg_wg_smax(L.wg_tiles);
+  off = (off + 3) & ~(size_t)3;
+  L.wg_ws = off; off += L.wg_smax > 1 ? (size_t)L.wg_tiles * L.wg_smax * 128 * 128 : 0;
+  L.wg_cnt = off; off += ((size_t)L.wg_tiles + 63) & ~(size_t)63;
   L.total = off;
   return L;
 }

@@ -12,6 +12,7 @@
 
 #include "../../include/stemgnn_hip.h"
 #include "layout.h"
+#include "reduce.h"
 
 #define SG_TRY(e)                                \
   do {                                           \
@@ -165,26 +166,6 @@ extern "C" int stemgnn_block_pack(const float* const* params_host, const float* 
 }
 
 // ---- unpack -------------------------------------------------------------------------------------------------
-struct SgRegions {   // slab table for the split reduction
-  size_t off[11];
-  size_t slab[11];
-  size_t prefix[12];
-  int n;
-};
-
-// slab 0 += sum_{s>=1} slab s, for every region (deterministic order)
-__global__ void sg_reduce_splits_kernel(float* __restrict__ part, SgRegions R, int nsplit) {
-  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= R.prefix[R.n]) return;
-  int g = 0;
-  while (g + 1 < R.n && idx >= R.prefix[g + 1]) ++g;
-  const size_t e = idx - R.prefix[g];
-  float* base = part + R.off[g] + e;
-  float s = base[0];
-  for (int k = 1; k < nsplit; ++k) s += base[(size_t)k * R.slab[g]];
-  base[0] = s;
-}
-
 struct SgParamOffsets { size_t prefix[SG_BLOCK_NPARAMS + 1]; };
 
 __global__ void sg_unpack_kernel(const float* __restrict__ part, const float* __restrict__ tab, SgBlockGrads gr,
@@ -267,14 +248,9 @@ extern "C" int stemgnn_block_unpack_grads(const float* gradpart, int nsplit, con
   const SgTableLayout T = sg_table_layout(d);
   hipStream_t st = (hipStream_t)stream;
   if (nsplit > 1) {
-    SgRegions R;
+    // only the heads' regions: the GLU regions arrive reduced (stemgnn_spectral_glu_bwd leaves the sum in slab 0)
+    SgSlabRegions R;
     int n = 0;
-    for (int r = 0; r < 2; ++r)
-      for (int l = 0; l < 3; ++l) {
-        R.off[n] = G.w[r][l];
-        R.slab[n] = (size_t)sg_glu_np(d, l, r) * (sg_glu_kin(d, l) + 1);
-        ++n;
-      }
     R.off[n] = G.wfold; R.slab[n] = (size_t)d.KF * d.WmP; ++n;
     R.off[n] = G.fr; R.slab[n] = (size_t)d.W * (d.Wm + 1); ++n;
     R.off[n] = G.fc; R.slab[n] = (size_t)d.Wm * (d.Wm + 1); ++n;
@@ -283,11 +259,7 @@ extern "C" int stemgnn_block_unpack_grads(const float* gradpart, int nsplit, con
       R.off[n] = G.bs; R.slab[n] = (size_t)d.W * (d.W + 1); ++n;
     }
     R.n = n;
-    R.prefix[0] = 0;
-    for (int i = 0; i < n; ++i) R.prefix[i + 1] = R.prefix[i] + R.slab[i];
-    const unsigned blocks = (unsigned)((R.prefix[n] + 255) / 256);
-    hipLaunchKernelGGL(sg_reduce_splits_kernel, dim3(blocks), dim3(256), 0, st, const_cast<float*>(gradpart), R, nsplit);
-    SG_TRY(hipGetLastError());
+    SG_TRY(sg_reduce_slabs(const_cast<float*>(gradpart), R, nsplit, st));
   }
   SgBlockGrads gr;
   for (int i = 0; i < SG_BLOCK_NPARAMS; ++i) gr.p[i] = grads_host[i];

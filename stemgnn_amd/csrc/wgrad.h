@@ -1,0 +1,464 @@
+// Weight-gradient GEMM family (reduction over the M = B*N series rows) for gfx950, round 3.
+//
+//     Out_g[i][j] = sum_{k < K} A_g[k][i] * B_g[k][j]        (column j == ones_col of B reads as 1.0: bias gradient)
+//
+// for a LIST of products per launch (the six GLU weight gradients of one StockBlock; the GRU's dW_hh): both operands
+// are row-major with the reduction index as the ROW (d(pre-activation) [M x 2CP] and the saved layer input [M x K_in]),
+// i.e. they are K-major in memory already -- exactly the image the MFMA fragment reads want in LDS.
+//
+// What replaced the round-1/2 design (32 split-M slabs per product + a separate reduce kernel, gemm2.h G2SlabEpi):
+//   * operand tiles go HBM/L2 -> LDS with direct-to-LDS loads (`global_load_lds_dwordx4`: 64 lanes x 16 B = two 128-float
+//     rows per wave instruction, lane-linear LDS image = the K-major tile, no VGPR round trip, no ds_write pass), into a
+//     ring of STAGES buffers; a wave waits with a COUNTED `s_waitcnt vmcnt(N)` that leaves STAGES-2 stages in flight
+//     across the one raw `s_barrier` per stage -- so ONE workgroup per CU hides the load latency of its K loop, which the
+//     2-stage register-staged pipeline of gemm2.h could not (why 8 / 16 splits lost in round 2);
+//   * few, long K ranges: S = ~(CUs x workgroups per CU) / tiles splits (8 at PEMS07 instead of 32);
+//   * the split reduction happens IN the kernel: every workgroup stores its fp32 partial tile (lane-linear 16-byte
+//     stores), publishes it (agent-scope release, arrival ticket), and the LAST arriver of a tile sums the S partials
+//     in FIXED split order 0..S-1 -- the ticket only decides WHO reduces, never the order, so results stay bitwise
+//     reproducible -- and writes the finished tile.  No slab re-read by a second kernel, no reduce launch;
+//   * the ones column (bias gradient) and a ragged last K tile are patched in REGISTERS on the fragment values
+//     (v_cndmask next to the MFMAs), since a DMA'd LDS image cannot be edited for free;
+//   * XCD-aware block order: all tiles of one (product, split) share their operand panels and get block ids equal mod 8.
+//
+// Hand-off protocol = cdna_hip_programming.md "in-launch split-K reduction" recipe, write-through form (sc1 16-byte slab
+// stores -> every wave vmcnt(0) -> barrier -> lane-0 relaxed agent ticket; reducer: ONE agent acquire -> barrier -> plain
+// loads); correct for any placement of a tile's splits over XCDs; counters are zeroed by a memset node ahead of every
+// launch.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "gemm2.h"
+
+constexpr int WG_MAXG = 8;        // products per launch
+constexpr int WG_TILE = 128;      // output tile 128 x 128, 4 waves as 2 x 2, each 64 x 64 = 2 x 2 MFMA tiles of 32 x 32
+constexpr int WG_TILE_FLOATS = WG_TILE * WG_TILE;
+#ifndef WG_ABL
+#define WG_ABL 0                  // compile-time ablation bits of the timing probes (tools/probe): results wrong by design
+#endif
+#define WG_SCHED() do { if (!(WG_ABL & 256)) __builtin_amdgcn_sched_barrier(0); } while (0)
+#ifndef WG_PF
+#define WG_PF 2                   // fragment prefetch distance in k-steps (one k-step = 4 MFMAs = 256 cycles)
+#endif
+
+struct WgGemm {
+  const float* A;   // [K][lda]: A[k][i], i < Mi
+  const float* B;   // [K][ldb]: B[k][j], j < ncolB;   column `ones_col` (== ncolB when >= 0) reads as 1.0
+  float* out;       // [Mi][Nj] row-major, Nj = ncolB + (ones_col >= 0)
+  int lda, ldb, Mi, Nj, ones_col;
+  int nx, ny;       // tiles along i / j
+  int tile0;        // index of this product's first tile (workspace / counter numbering)
+};
+
+struct WgArgs {
+  WgGemm g[WG_MAXG];
+  int ngemm;
+  int K;            // reduction length (rows of every operand)
+  int S;            // splits of the K range
+  int ktps;         // K tiles (of BK rows) per split
+  int tmax;         // max nx * ny over the products (grid padding of the XCD-aware order)
+  float* ws;        // partial tiles [tile][split][WG_TILE_FLOATS] (lane-linear image), unused when S == 1
+  unsigned* cnt;    // arrival counters [tiles], zero at launch
+  int dbg;          // phase-ablation bits, honoured only by -DSG_WG_DEBUG builds (tools/wg_dbg.sh): 1 stop after the K loop,
+};                  // 2 no MFMA, 4 no DMA inside the K loop, 8 publish but never reduce.  Results are wrong by design.
+#ifdef SG_WG_DEBUG
+#define WG_DBG(g, bit) ((g).dbg & (bit))
+#else
+#define WG_DBG(g, bit) 0
+#endif
+
+typedef float wg_f4 __attribute__((ext_vector_type(4)));
+// 16-byte write-through (sc1) store: leaves the producer XCD's L2 for the fabric, so another XCD's reader sees it after
+// the writer's vmcnt(0) without an agent-scope release fence (cdna_hip_programming.md Guideline 16, R1)
+__device__ __forceinline__ void wg_store_wt(float* p, const wg_f4& v) {
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+}
+
+template <int N>
+__device__ __forceinline__ void wg_wait_vm() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// ---- operand stream --------------------------------------------------------------------------------------------------
+// One stage = BK rows of the A tile (BK x 128 floats) followed by BK rows of the B tile; every wave moves BK/8 two-row
+// pieces of each (NP = BK/4 pieces per wave per stage: its A pieces, then its B pieces).  The cursor keeps, per piece,
+// this lane's source pointer for the stage that will be requested NEXT; a stage that lies completely inside [0, K) is a
+// pointer bump per piece (fast path).  Stages that touch or pass the end of the K range (the ragged last stage when
+// K % BK != 0, and the ring's run-ahead behind the last stage) take the slow path: rows >= K read ZEROS for the A operand
+// (so a ragged stage needs no masking in registers: 0 * finite = 0) and the clamped last row for B.
+static __device__ float wg_zero_row[WG_TILE];   // zero-initialised
+
+template <int BK>
+struct WgCursor {
+  static constexpr int NP = BK / 4, PW = BK / 8;
+  const float* p[NP];
+  const float* A;
+  const float* B;
+  int lda, ldb, acol, bcol, K, lane, wave;
+  int knext;                                     // first row of the stage the pointers stand at
+
+  __device__ __forceinline__ void init(const float* A_, const float* B_, int lda_, int ldb_, int acol_, int bcol_, int K_,
+                                       int k0, int wave_, int lane_) {
+    A = A_; B = B_; lda = lda_; ldb = ldb_; acol = acol_; bcol = bcol_; K = K_; lane = lane_; wave = wave_; knext = k0;
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+      const bool isB = q >= PW;
+      const int k = k0 + 2 * (wave * PW + (isB ? q - PW : q)) + (lane >> 5);
+      p[q] = isB ? B + (size_t)k * ldb + bcol : A + (size_t)k * lda + acol;
+    }
+  }
+  // request piece q of the stage at `knext` into `stage`; `fast` (wave-uniform) = the whole stage is inside [0, K)
+  __device__ __forceinline__ void issue(int q, float* stage, bool fast) {
+    const bool isB = q >= PW;
+    const int piece = wave * PW + (isB ? q - PW : q);
+    const float* g = p[q];
+    if (!fast) {
+      const int k = knext + 2 * piece + (lane >> 5);
+      if (k >= K) g = isB ? B + (size_t)(K - 1) * ldb + bcol : wg_zero_row + (lane & 31) * 4;
+    }
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)(stage + (isB ? BK * WG_TILE : 0) + piece * 256),
+                                     16, 0, 0);
+    p[q] += (size_t)BK * (isB ? ldb : lda);
+  }
+  __device__ __forceinline__ bool fast() const { return knext + BK <= K; }
+  __device__ __forceinline__ void next_stage() { knext += BK; }
+};
+
+// One stage of MFMA work for a wave's 64 x 64 block, with the NEXT ring stage's DMA pieces issued from inside it.
+//
+// Fragment reads: ONE ds_read_b64 per operand per k-step.  Lane (fi, fk) reads the float2 at columns 2 fi, 2 fi + 1 of
+// row ks + fk: .x feeds MFMA tile 0, .y tile 1, i.e. the wave's two 32-wide MFMA tiles along i (and along j) are
+// INTERLEAVED -- tile t row r is block row 2 r + t.  (b64 reads run at 256 B/clk and reach that rate from one wave per
+// SIMD; the two ds_read2_b32 this replaces need ~4 waves per SIMD -- MI355X_MICROARCH.md, LDS table.)
+//
+// Hand-placed order per k-step (pinned with sched_barrier; hipcc's own order was: all DMA pieces right behind the barrier,
+// then per k-step ds_read -> lgkmcnt(0) -> 4 MFMAs, which leaves the pipe idle for the LDS latency of every k-step and for
+// the issue cost of every piece):
+//     MFMA 1 | request the fragments of k-step st + PF | MFMA 2 | one DMA piece (every other k-step) | MFMA 3 | MFMA 4
+// -- an f32 32x32x2 MFMA keeps the SIMD's matrix pipe busy for 64 cycles, the instructions between two of them issue in
+// that shadow.  ONES (wave-uniform, a template parameter so the other waves pay nothing): this wave's columns contain the
+// ones column of B (bias gradient); its B fragment is replaced by 1.0 in registers.
+template <int BK, int PF, bool ONES>
+__device__ __forceinline__ void wg_stage(const float* __restrict__ As, sg_f32x16 (&acc)[2][2], int aoff, int boff,
+                                         bool one0, bool one1, int fk, WgCursor<BK>& cur, float* stage_next) {
+  constexpr int NP = BK / 4;                 // DMA pieces per wave per stage
+  constexpr int STEPS = BK / 2;              // k-steps per stage
+  constexpr int EVERY = STEPS / NP;          // one piece every EVERY k-steps (2)
+  const float* Ap = As + fk * WG_TILE + aoff;
+  const float* Bp = As + BK * WG_TILE + fk * WG_TILE + boff;
+  const bool fast = cur.fast();
+  float2 fa[STEPS], fb[STEPS];               // fully unrolled: only PF + 1 of them are live at a time
+#pragma unroll
+  for (int st = 0; st < PF && st < STEPS; ++st) {
+    fa[st] = *reinterpret_cast<const float2*>(Ap + 2 * st * WG_TILE);
+    fb[st] = *reinterpret_cast<const float2*>(Bp + 2 * st * WG_TILE);
+  }
+#pragma unroll
+  for (int st = 0; st < STEPS; ++st) {
+    const float x0 = fa[st].x, x1 = fa[st].y;
+    float y0 = fb[st].x, y1 = fb[st].y;
+    if (ONES && !(WG_ABL & 128)) { y0 = one0 ? 1.f : y0; y1 = one1 ? 1.f : y1; }
+    WG_SCHED();
+    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(x0, y0, acc[0][0], 0, 0, 0);
+    if (st + PF < STEPS) {
+      if (WG_ABL & 64) { fa[st + PF] = make_float2(x0 + 1.f, x1); fb[st + PF] = make_float2(y0, y1 + 1.f); }
+      else {
+        fa[st + PF] = *reinterpret_cast<const float2*>(Ap + 2 * (st + PF) * WG_TILE);
+        fb[st + PF] = *reinterpret_cast<const float2*>(Bp + 2 * (st + PF) * WG_TILE);
+      }
+    }
+    WG_SCHED();
+    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(x0, y1, acc[0][1], 0, 0, 0);
+    if (!(WG_ABL & 4) && st % EVERY == 0 && st / EVERY < NP) cur.issue(st / EVERY, stage_next, fast);
+    WG_SCHED();
+    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(x1, y0, acc[1][0], 0, 0, 0);
+    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(x1, y1, acc[1][1], 0, 0, 0);
+  }
+  cur.next_stage();
+}
+
+// the K loop of one workgroup: STAGES-deep ring.  Stage t+STAGES-1 is requested from inside the MFMA stream of stage t; the
+// ring is ALWAYS kept full (stages past the end of the range are harmless re-reads that are never multiplied), so the
+// counted wait is the same constant in every iteration -- no tail cases.
+template <int BK, int STAGES, bool ONES>
+__device__ __forceinline__ void wg_kloop(float* lds, sg_f32x16 (&acc)[2][2], WgCursor<BK>& cur, int nk, int aoff, int boff,
+                                         bool one0, bool one1, int fk) {
+  constexpr int STAGE = BK * 2 * WG_TILE;        // floats per stage
+  constexpr int NI = BK / 4;                     // DMA instructions per wave per stage
+#pragma unroll
+  for (int p = 0; p < STAGES - 1; ++p) {
+    const bool fast = cur.fast();
+#pragma unroll
+    for (int q = 0; q < NI; ++q) cur.issue(q, lds + p * STAGE, fast);
+    cur.next_stage();
+  }
+  int rbuf = 0, wbuf = STAGES - 1;
+  for (int t = 0; t < nk; ++t) {
+    if (!(WG_ABL & 32)) {
+      wg_wait_vm<(STAGES - 2) * NI>();                   // my pieces of stage t have landed
+      __builtin_amdgcn_s_barrier();                      // everybody's have; and stage t-1's buffer is free
+    }
+    wg_stage<BK, WG_PF, ONES>(lds + rbuf * STAGE, acc, aoff, boff, one0, one1, fk, cur, lds + wbuf * STAGE);
+    rbuf = rbuf + 1 == STAGES ? 0 : rbuf + 1;
+    wbuf = wbuf + 1 == STAGES ? 0 : wbuf + 1;
+  }
+  wg_wait_vm<0>();                                       // drain the run-ahead pieces before the LDS word is reused
+}
+
+template <int BK, int STAGES>
+__global__ __launch_bounds__(256, (STAGES * BK * 1024 <= 80 * 1024 ? 2 : 1)) void sg_wgrad_kernel(const WgArgs g) {
+  static_assert(BK == 16 || BK == 32, "BK");
+  static_assert(STAGES >= 3 && STAGES <= 8, "STAGES");
+  constexpr int STAGE = BK * 2 * WG_TILE;        // floats per stage
+  constexpr int NI = BK / 4;                     // glds instructions per wave per stage
+  static_assert((STAGES - 2) * NI <= 63, "vmcnt range");
+  // ONE shared array (a second __shared__ object makes hipcc drain vmcnt before every ds_read of a glds pipeline)
+  __shared__ __attribute__((aligned(16))) float lds[STAGES * STAGE];
+
+  int gi, s, bx, by;
+  {
+    const int L = blockIdx.x, c = L & 7, idx = L >> 3;
+    const int t = idx % g.tmax, group = c + 8 * (idx / g.tmax);
+    if (group >= g.ngemm * g.S) return;
+    gi = group / g.S;
+    s = group - gi * g.S;
+    if (t >= g.g[gi].nx * g.g[gi].ny) return;
+    bx = t % g.g[gi].nx;
+    by = t / g.g[gi].nx;
+  }
+#ifdef SG_WG_DEBUG
+  const unsigned long long t_start = __builtin_amdgcn_s_memtime();
+#endif
+  const WgGemm& G = g.g[gi];
+  const float* __restrict__ A = G.A;
+  const float* __restrict__ B = G.B;
+  const int lda = G.lda, ldb = G.ldb, Mi = G.Mi, Nj = G.Nj, ones_col = G.ones_col;
+  const int K = g.K;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = bx * WG_TILE, n0 = by * WG_TILE;
+  const int fi = lane & 31, fk = lane >> 5;
+
+  // per-lane source columns of the DMA pieces (16 B = 4 floats per lane, 32 lanes per row); columns that do not exist
+  // are redirected to column 0: they only feed output rows / columns that are never stored
+  const int ncolB = ones_col >= 0 ? ones_col : Nj;
+  int acol = m0 + (lane & 31) * 4, bcol = n0 + (lane & 31) * 4;
+  acol = acol < Mi ? acol : 0;
+  bcol = bcol < ncolB ? bcol : 0;
+  // fragment columns of this lane inside the stage image: floats 2 fi, 2 fi + 1 of the wave's 64-wide block
+  const int aoff = wm * 64 + 2 * fi, boff = wn * 64 + 2 * fi;
+  const bool one0 = (n0 + boff) == ones_col, one1 = (n0 + boff + 1) == ones_col;
+
+  const int KT = (K + BK - 1) / BK;
+  const int kt0 = s * g.ktps, kt1 = min(KT, kt0 + g.ktps);
+  const int nk = kt1 - kt0;
+
+  sg_f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  WgCursor<BK> cur;
+  cur.init(A, B, lda, ldb, acol, bcol, K, kt0 * BK, wave, lane);
+  // does this wave's 64-column block contain the ones column?  (wave-uniform: the K loop is instantiated both ways)
+  const int cw0 = n0 + wn * 64;
+  const bool has_ones = ones_col >= cw0 && ones_col < cw0 + 64;
+  if (has_ones) wg_kloop<BK, STAGES, true>(lds, acc, cur, nk, aoff, boff, one0, one1, fk);
+  else wg_kloop<BK, STAGES, false>(lds, acc, cur, nk, aoff, boff, one0, one1, fk);
+#ifdef SG_WG_DEBUG
+  if ((g.dbg & 16) && threadIdx.x == 0) {                // per-workgroup trace: placement and K-loop span (shader clocks)
+    const unsigned long long t_end = __builtin_amdgcn_s_memtime();
+    const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+    printf("WGTRACE blk %d gemm %d split %d tile %d,%d xcc %u se %u cu %u start %llu end %llu nk %d\n", (int)blockIdx.x, gi, s,
+           bx, by, xcc & 15, (hw >> 13) & 7, (hw >> 8) & 15, t_start, t_end, nk);
+  }
+#endif
+  if (WG_DBG(g, 1)) {
+    if (acc[0][0][0] + acc[1][1][3] == 1.2345e-30f) lds[0] = 1.f;   // keep the accumulators alive
+    return;
+  }
+
+  // ---- epilogue ------------------------------------------------------------------------------------------------------
+  const int S = g.S;
+  if (S > 1) {
+    const int tile = G.tile0 + by * G.nx + bx;
+    float* wsl = g.ws + ((size_t)tile * S) * WG_TILE_FLOATS;
+    {   // publish this split's partial tile, image [wave][ni][nj][reg/4][lane][4]: WRITE-THROUGH (sc1) 16-byte stores, so
+        // no release fence (which would write back this CU's L2 lines: ~6 us behind 64 KB of fresh partials) is needed
+      float* my = wsl + (size_t)s * WG_TILE_FLOATS + wave * 4096 + lane * 4;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const wg_f4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+            wg_store_wt(my + ((i * 2 + j) * 4 + q) * 256, v);
+          }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // EVERY storing wave drains its write-through stores
+    __syncthreads();
+    // the single shared array doubles as the "I am last" broadcast word (the K loop is over, the ring is drained)
+    if (tid == 0) {
+      const unsigned ticket = __hip_atomic_fetch_add(&g.cnt[tile], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const bool last = ticket == (unsigned)(S - 1);
+      if (last) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");           // ONE invalidate of this CU's L1, then plain loads
+        __hip_atomic_store(&g.cnt[tile], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (the memset node also does)
+      }
+      reinterpret_cast<volatile int*>(lds)[0] = last ? 1 : 0;
+    }
+    __syncthreads();
+    if (reinterpret_cast<volatile int*>(lds)[0] == 0 || WG_DBG(g, 8)) return;
+    // last arriver: sum the S partial tiles in split order 0, 1, .. S-1 (fixed association -> bitwise reproducible).
+    // Two partials (32 x 16 B per lane) are requested before the first is added: the sum is latency-bound otherwise.
+    const float* rd = wsl + wave * 4096 + lane * 4;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      const float4 v = *reinterpret_cast<const float4*>(rd + c * 256);
+      acc[c >> 3][(c >> 2) & 1][4 * (c & 3)] = v.x; acc[c >> 3][(c >> 2) & 1][4 * (c & 3) + 1] = v.y;
+      acc[c >> 3][(c >> 2) & 1][4 * (c & 3) + 2] = v.z; acc[c >> 3][(c >> 2) & 1][4 * (c & 3) + 3] = v.w;
+    }
+    int ss = 1;
+    for (; ss + 1 < S; ss += 2) {
+      const float* r0 = rd + (size_t)ss * WG_TILE_FLOATS;
+      const float* r1 = r0 + WG_TILE_FLOATS;
+      float4 u[16], w[16];
+#pragma unroll
+      for (int c = 0; c < 16; ++c) u[c] = *reinterpret_cast<const float4*>(r0 + c * 256);
+#pragma unroll
+      for (int c = 0; c < 16; ++c) w[c] = *reinterpret_cast<const float4*>(r1 + c * 256);
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        sg_f32x16& a = acc[c >> 3][(c >> 2) & 1];
+        const int e = 4 * (c & 3);
+        a[e] = (a[e] + u[c].x) + w[c].x; a[e + 1] = (a[e + 1] + u[c].y) + w[c].y;
+        a[e + 2] = (a[e + 2] + u[c].z) + w[c].z; a[e + 3] = (a[e + 3] + u[c].w) + w[c].w;
+      }
+    }
+    if (ss < S) {
+      const float* r0 = rd + (size_t)ss * WG_TILE_FLOATS;
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        const float4 v = *reinterpret_cast<const float4*>(r0 + c * 256);
+        sg_f32x16& a = acc[c >> 3][(c >> 2) & 1];
+        const int e = 4 * (c & 3);
+        a[e] += v.x; a[e + 1] += v.y; a[e + 2] += v.z; a[e + 3] += v.w;
+      }
+    }
+  }
+  // final store.  Interleaved fragment mapping: MFMA tile (i, j), register row r, lane column c is output element
+  // (m0 + wm*64 + 2 r + i,  n0 + wn*64 + 2 c + j); the j = 0 / 1 values of a lane are neighbours -> one 8-byte store.
+  float* __restrict__ out = G.out;
+  const int col = n0 + wn * 64 + 2 * fi;
+  const bool vec2 = (Nj & 1) == 0 && ((reinterpret_cast<uintptr_t>(out) & 7) == 0);
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      const int row = m0 + wm * 64 + 2 * g2_row_of(reg, lane) + i;
+      if (row >= Mi) continue;
+      float* o = out + (size_t)row * Nj + col;
+      if (vec2 && col + 1 < Nj) *reinterpret_cast<float2*>(o) = make_float2(acc[i][0][reg], acc[i][1][reg]);
+      else {
+        if (col < Nj) o[0] = acc[i][0][reg];
+        if (col + 1 < Nj) o[1] = acc[i][1][reg];
+      }
+    }
+}
+
+// ---- host side -------------------------------------------------------------------------------------------------------
+struct WgPlan {
+  int bk, stages, per_cu;   // kernel variant + target workgroups per CU
+};
+static inline WgPlan wg_plan_from_env() {
+  // STEMGNN_WG_CFG = "<BK>,<STAGES>,<workgroups per CU>"   (instantiated: 16,6 | 16,4 | 16,3 | 32,3)
+  WgPlan p{16, 6, 1};
+  if (const char* e = getenv("STEMGNN_WG_CFG")) {
+    int a = 0, b = 0, c = 0;
+    if (sscanf(e, "%d,%d,%d", &a, &b, &c) == 3 && c >= 1 && c <= 4) {
+      if ((a == 16 && (b == 6 || b == 4 || b == 3)) || (a == 32 && b == 3)) p = WgPlan{a, b, c};
+    }
+  }
+  return p;
+}
+
+static inline bool wg_operand_ok(const void* p, int ld) { return (((uintptr_t)p) & 15) == 0 && (ld & 3) == 0; }
+
+// the alignment rules of the DMA path: 16-byte aligned rows, column counts that are multiples of 4
+static inline bool wg_gemm_ok(const WgGemm& q) {
+  const int ncolB = q.ones_col >= 0 ? q.ones_col : q.Nj;
+  return wg_operand_ok(q.A, q.lda) && wg_operand_ok(q.B, q.ldb) && (q.Mi & 3) == 0 && (ncolB & 3) == 0 && q.Mi > 0 &&
+         ncolB > 0 && (q.ones_col < 0 || q.ones_col == ncolB);
+}
+
+// number of splits for `ntiles` output tiles and a K range of `K` rows (pure function: the workspace is sized by it)
+static inline int wg_splits(int ntiles, int K, int bk, int per_cu, int smax) {
+  const int KT = (K + bk - 1) / bk;
+  int S = (256 * per_cu + ntiles / 2) / (ntiles > 0 ? ntiles : 1);
+  if (S < 1) S = 1;
+  if (S > smax) S = smax;
+  const int min_kt = 8;                       // a split shorter than the ring depth only adds reduction traffic
+  if (S > KT / min_kt) S = KT / min_kt > 0 ? KT / min_kt : 1;
+  return S;
+}
+
+// fills nx / ny / tile0, returns the tile count
+static inline int wg_tile_index(WgGemm* q, int n) {
+  int t = 0;
+  for (int i = 0; i < n; ++i) {
+    q[i].nx = (q[i].Mi + WG_TILE - 1) / WG_TILE;
+    q[i].ny = (q[i].Nj + WG_TILE - 1) / WG_TILE;
+    q[i].tile0 = t;
+    t += q[i].nx * q[i].ny;
+  }
+  return t;
+}
+
+// ws: >= ntiles * S * WG_TILE_FLOATS floats (when S > 1); cnt: >= ntiles unsigned.  S <= smax_ws is guaranteed.
+static inline hipError_t wg_launch(WgGemm* q, int n, int K, float* ws, unsigned* cnt, int smax_ws, hipStream_t st,
+                                   bool zero_counters = true) {
+  if (n <= 0 || n > WG_MAXG || K <= 0) return hipErrorInvalidValue;
+  const WgPlan p = wg_plan_from_env();
+  WgArgs a;
+  int tmax = 0;
+  const int ntiles = wg_tile_index(q, n);
+  for (int i = 0; i < n; ++i) {
+    a.g[i] = q[i];
+    const int t = q[i].nx * q[i].ny;
+    tmax = t > tmax ? t : tmax;
+  }
+  a.ngemm = n; a.K = K; a.tmax = tmax; a.ws = ws; a.cnt = cnt;
+#ifdef SG_WG_DEBUG
+  a.dbg = getenv("STEMGNN_WG_DEBUG") ? atoi(getenv("STEMGNN_WG_DEBUG")) : 0;
+#else
+  a.dbg = 0;
+#endif
+  const int KT = (K + p.bk - 1) / p.bk;
+  int S = wg_splits(ntiles, K, p.bk, p.per_cu, smax_ws);
+  a.ktps = (KT + S - 1) / S;
+  a.S = (KT + a.ktps - 1) / a.ktps;              // no empty split
+  if (a.S > 1 && zero_counters) {
+    hipError_t e = hipMemsetAsync(cnt, 0, sizeof(unsigned) * ntiles, st);
+    if (e != hipSuccess) return e;
+  }
+  const int groups = n * a.S;
+  dim3 grid(8 * ((groups + 7) / 8) * tmax);
+  if (p.bk == 16 && p.stages == 6) hipLaunchKernelGGL((sg_wgrad_kernel<16, 6>), grid, dim3(256), 0, st, a);
+  else if (p.bk == 16 && p.stages == 4) hipLaunchKernelGGL((sg_wgrad_kernel<16, 4>), grid, dim3(256), 0, st, a);
+  else if (p.bk == 16 && p.stages == 3) hipLaunchKernelGGL((sg_wgrad_kernel<16, 3>), grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((sg_wgrad_kernel<32, 3>), grid, dim3(256), 0, st, a);
+  return hipGetLastError();
+}
+
+// timing probes only (tools/probe): back-to-back launches without the memset node (the last arriver leaves its counter
+// at zero, so a clean sequence of launches keeps reducing; the product path zeroes the counters per launch regardless)
+static inline hipError_t wg_launch_nomemset(WgGemm* q, int n, int K, float* ws, unsigned* cnt, int smax_ws, hipStream_t st) {
+  return wg_launch(q, n, K, ws, cnt, smax_ws, st, false);
+}

@@ -33,6 +33,10 @@ def _launch(script_args, timeout=600):
 def test_rccl_single_rank_group_collectives_and_graph_capture_probe():
     res = _launch([os.path.join(ROOT, "tests", "helpers", "rccl_probe.py")])
     print("RCCL probe:", json.dumps(res))
+    out_dir = os.path.join(ROOT, "gpurun_out")          # keep the probe's answer (pytest -q swallows stdout)
+    if os.path.isdir(out_dir):
+        with open(os.path.join(out_dir, "rccl_probe.json"), "w") as f:
+            json.dump(res, f, indent=1)
     assert res["backend"] == "nccl" and res["world"] == 1
     assert res["allreduce_world"] == 1 and res["allreduce_unchanged"]
     assert res["mode_collective"].startswith("hipgraph(fwd+bwd) + rccl all-reduce"), res
