@@ -156,8 +156,9 @@ int stemgnn_gru_bwd(const float* dh_all, const float* x, const float* w_hh, cons
  * (host array). */
 int stemgnn_block_pack(const float* const* params_host, const float* tables, float* packed,
                        int W, int multi, void* stream);
-/* adjoint of the above: reduce the split partials and scatter them into the parameter gradients
- * grads_host[SG_BLOCK_NPARAMS] (entries may be NULL to skip). */
+/* adjoint of the above: scatter the weight gradients (slab 0 of every gradpart region, left complete by
+ * stemgnn_block_wgrad or by the parts & 2 calls of stemgnn_igft_heads_bwd / stemgnn_spectral_glu_bwd) into the parameter
+ * gradients grads_host[SG_BLOCK_NPARAMS] (entries may be NULL to skip).  nsplit = the value gradpart was sized with. */
 int stemgnn_block_unpack_grads(const float* gradpart, int nsplit, const float* tables,
                                float* const* grads_host, int W, int multi, int has_backcast, void* stream);
 
@@ -198,6 +199,17 @@ int stemgnn_igft_heads_bwd(const float* const* params_host, const float* packed,
                            const float* dforecast, const float* dbackcast, const float* backcast,
                            float* scratch, float* gradpart, int nsplit, int parts,
                            int B, int N, int W, int multi, void* stream);
+
+/* ALL weight gradients of one StockBlock (autograd of models/base_model.py:12-13, 66-74 via models/handler.py:164): the
+ * six GLU products and the heads' FR / F / BC / graph-conv products in ONE launch of the fused weight-gradient kernel
+ * (direct-to-LDS operand ring, in-kernel fixed-order split reduction), the short-cut head BS beside it.  Needs the data
+ * parts (parts & 1) of stemgnn_igft_heads_bwd and stemgnn_spectral_glu_bwd; leaves complete gradients in slab 0 of every
+ * gradpart region (-> stemgnn_block_unpack_grads).  has_bc: block 0 (backcast heads present).  cu_percent (10..100):
+ * share of the CUs the big launch should fill -- lower it when latency-critical kernels run beside it on another stream. */
+int stemgnn_block_wgrad(const float* const* params_host, const float* packed, const float* saved,
+                        const float* X, long xs_b, long xs_n, long xs_t, const float* dforecast, int has_bc,
+                        float* scratch, float* gradpart, int nsplit, int cu_percent,
+                        int B, int N, int W, int multi, void* stream);
 
 /* ---- callers on either side of the blocks, fused ------------------------------------------------
  * fc tail (models/base_model.py:97-101,174-179): fsum [B*N, W] (block forecast sum) ->

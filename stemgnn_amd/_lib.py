@@ -73,6 +73,8 @@ SIGNATURES = {
                                        c_int, c_int, c_int, c_int, _P]),
     "stemgnn_igft_heads_bwd": (c_int, [_PP, _P, _P, _P, c_long, c_long, c_long, _P, _P, _P, _P, _P, c_int, c_int,
                                        c_int, c_int, c_int, c_int, _P]),
+    "stemgnn_block_wgrad": (c_int, [_PP, _P, _P, _P, c_long, c_long, c_long, _P, c_int, _P, _P, c_int, c_int,
+                                    c_int, c_int, c_int, c_int, _P]),
 }
 
 _lib = None

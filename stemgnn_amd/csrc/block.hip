@@ -741,6 +741,7 @@ extern "C" int stemgnn_spectral_glu_bwd(const float* packed, const float* saved,
         q.B = l == 0 ? saved + S.G : saved + S.out[r][l - 1]; q.ldb = l == 0 ? d.KG : d.CP;
         q.out = gradpart + Gl.w[r][l];
         q.Mi = sg_glu_np(d, l, r); q.Nj = sg_glu_kin(d, l) + 1; q.ones_col = sg_glu_kin(d, l);
+        q.ldo = q.Nj; q.out_bias = nullptr;
         fused = fused && wg_gemm_ok(q);
       }
   }
@@ -842,6 +843,21 @@ extern "C" int stemgnn_igft_heads_fwd(const float* const* params_host, const flo
   return 0;
 }
 
+// fixed-order reduce of the heads' split slabs; which: bit 0 Wfold, 1 FR, 2 F, 3 BC, 4 BS (BC / BS only with a backcast head)
+static hipError_t heads_reduce(const SgDims& d, const SgGradLayout& G, float* gradpart, int nsplit, int has_bc, int which,
+                               hipStream_t st) {
+  if (nsplit <= 1) return hipSuccess;
+  SgSlabRegions R;
+  int n = 0;
+  if (which & 1) { R.off[n] = G.wfold; R.slab[n] = (size_t)d.KF * d.WmP; ++n; }
+  if (which & 2) { R.off[n] = G.fr; R.slab[n] = (size_t)d.W * (d.Wm + 1); ++n; }
+  if (which & 4) { R.off[n] = G.fc; R.slab[n] = (size_t)d.Wm * (d.Wm + 1); ++n; }
+  if (has_bc && (which & 8)) { R.off[n] = G.bc; R.slab[n] = (size_t)d.W * (d.Wm + 1); ++n; }
+  if (has_bc && (which & 16)) { R.off[n] = G.bs; R.slab[n] = (size_t)d.W * (d.W + 1); ++n; }
+  R.n = n;
+  return sg_reduce_slabs(gradpart, R, nsplit, st);
+}
+
 extern "C" int stemgnn_igft_heads_bwd(const float* const* params_host, const float* packed, const float* saved,
                                       const float* X, long xs_b, long xs_n, long xs_t,
                                       const float* dforecast, const float* dbackcast, const float* backcast,
@@ -909,6 +925,76 @@ extern "C" int stemgnn_igft_heads_bwd(const float* const* params_host, const flo
     op.M = d.M; op.S = nsplit; op.chunk = split_chunk(d.M, nsplit);
     const int maxM = d.KF > d.Wm ? d.KF : d.Wm;
     SG_TRY((sg_launch_gemm<HeadsWgradOp, 64, 64, false, false, false, 64>(op, maxM, d.Wm + 1, 5 * nsplit, st)));
+    SG_TRY(heads_reduce(d, Gl, gradpart, nsplit, has_bc, 31, st));      // complete gradients in slab 0 of every region
+  }
+  return 0;
+}
+
+// =================================================================================================
+// ALL weight gradients of one StockBlock in (at most) three launches: the six GLU products and the heads' FR / F / BC /
+// graph-conv (Wfold) products ride in ONE launch of the fused weight-gradient kernel (csrc/wgrad.h); the short-cut head
+// BS (block 0 only; its operand is the strided model input, not a K-major matrix) stays on the descriptor GEMM + a
+// reduce over its 32 tiny slabs.  Needs the data-gradient parts (parts & 1) of stemgnn_igft_heads_bwd and
+// stemgnn_spectral_glu_bwd to have run.  cu_percent: share of the CUs the fused launch should fill (<= 100): the caller
+// lowers it when latency-critical kernels run beside it on another stream.
+// =================================================================================================
+extern "C" int stemgnn_block_wgrad(const float* const* params_host, const float* packed, const float* saved,
+                                   const float* X, long xs_b, long xs_n, long xs_t, const float* dforecast, int has_bc,
+                                   float* scratch, float* gradpart, int nsplit, int cu_percent, int B, int N, int W,
+                                   int multi, void* stream) {
+  if (!params_host || !packed || !saved || !X || !dforecast || !scratch || !gradpart || nsplit <= 0 || B <= 0 || N <= 0 ||
+      W <= 0 || multi <= 0)
+    return SG_EINVAL;
+  const SgDims d = sg_dims(B, N, W, multi);
+  const SgSavedLayout S = sg_saved_layout(d);
+  const SgScratchLayout C = sg_scratch_layout(d);
+  const SgGradLayout Gl = sg_grad_layout(d, nsplit);
+  hipStream_t st = (hipStream_t)stream;
+  has_bc = has_bc ? 1 : 0;
+  if (has_bc && !params_host[5]) return SG_EINVAL;
+  WgGemm q[WG_MAXG];
+  int n = 0;
+  bool ok = wg_fused_on();
+  auto add = [&](const float* A, int lda, int Mi, const float* Bp, int ldb, int ncolB, bool ones, float* out, int ldo) {
+    WgGemm& g = q[n++];
+    g.A = A; g.lda = lda; g.Mi = Mi; g.B = Bp; g.ldb = ldb; g.Nj = ncolB + (ones ? 1 : 0); g.ones_col = ones ? ncolB : -1;
+    g.out = out; g.ldo = ldo; g.out_bias = nullptr;
+    ok = ok && wg_gemm_ok(g);
+  };
+  for (int l = 0; l < 3; ++l)
+    for (int r = 0; r < 2; ++r)
+      add(scratch + C.dact[r][l], sg_glu_np(d, l, r), sg_glu_np(d, l, r), l == 0 ? saved + S.G : saved + S.out[r][l - 1],
+          l == 0 ? d.KG : d.CP, sg_glu_kin(d, l), true, gradpart + Gl.w[r][l], sg_glu_kin(d, l) + 1);
+  const int n_glu = n;
+  // FR: dfo^T [fs | 1]; F: dpF^T [ig | 1]; BC: dpB^T [ig | 1]; Wfold: [Re3 | Im3]^T dig  (one product per branch)
+  add(dforecast, W, W, saved + S.fs, d.Wm, d.Wm, true, gradpart + Gl.fr, d.Wm + 1);
+  add(scratch + C.dpF, d.Wm, d.Wm, saved + S.ig, d.Wm, d.Wm, true, gradpart + Gl.fc, d.Wm + 1);
+  if (has_bc) add(scratch + C.dpB, W, W, saved + S.ig, d.Wm, d.Wm, true, gradpart + Gl.bc, d.Wm + 1);
+  for (int r = 0; r < 2; ++r)
+    add(saved + S.out[r][2], d.CP2[r], d.CP2[r], scratch + C.dig, d.Wm, d.Wm, false,
+        gradpart + Gl.wfold + (r ? (size_t)d.CP2[0] * d.WmP : 0), d.WmP);
+  if (!ok) {     // shapes outside the DMA path's 16-byte rules: the per-stage slab GEMMs (each leaves slab 0 complete)
+    const int rc = stemgnn_igft_heads_bwd(params_host, packed, saved, X, xs_b, xs_n, xs_t, dforecast,
+                                          has_bc ? dforecast : nullptr, has_bc ? dforecast : nullptr, scratch, gradpart,
+                                          nsplit, 2, B, N, W, multi, stream);
+    if (rc) return rc;
+    return stemgnn_spectral_glu_bwd(packed, saved, scratch, gradpart, nsplit, 2, B, N, W, multi, stream);
+  }
+  (void)n_glu;
+  SG_TRY(wg_launch(q, n, d.M, gradpart + Gl.wg_ws, reinterpret_cast<unsigned*>(gradpart + Gl.wg_cnt), Gl.wg_smax, st, true,
+                   cu_percent));
+  if (has_bc) {  // BS: -dpB^T [X | 1] on the descriptor GEMM (X is a strided view), 32 tiny slabs + their reduce
+    HeadsWgradOp op;
+    const int huge = 1 << 30;
+    for (int w = 0; w < 5; ++w) {
+      op.pa0[w] = op.pa1[w] = scratch + C.dpB; op.lda0[w] = op.lda1[w] = W; op.split[w] = huge; op.Mw[w] = W; op.Nw[w] = W + 1;
+      op.nb[w] = W; op.rdiv[w] = huge; op.ldp[w] = W + 1; op.on[w] = 0; op.sign[w] = 1.f; op.pb[w] = X; op.sb[w] = 0;
+      op.sn[w] = 0; op.st[w] = 1; op.part[w] = gradpart + Gl.bs;
+    }
+    op.on[3] = 1; op.sign[3] = -1.f; op.rdiv[3] = N; op.sb[3] = xs_b; op.sn[3] = xs_n; op.st[3] = xs_t;
+    op.M = d.M; op.S = nsplit; op.chunk = split_chunk(d.M, nsplit);
+    SG_TRY((sg_launch_gemm<HeadsWgradOp, 64, 64, false, false, false, 64>(op, W, W + 1, 5 * nsplit, st)));
+    SG_TRY(heads_reduce(d, Gl, gradpart, nsplit, 1, 16, st));
   }
   return 0;
 }

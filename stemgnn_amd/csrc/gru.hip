@@ -27,6 +27,7 @@
 
 #include "../../include/stemgnn_hip.h"
 #include "gemm2.h"
+#include "wgrad.h"
 #include "gemm_core.h"
 #include "gru_wide.h"
 
@@ -1043,7 +1044,7 @@ extern "C" size_t stemgnn_gru_fwd_scratch_floats(int B, int S, int Hd) {
 }
 extern "C" size_t stemgnn_gru_bwd_scratch_floats(int B, int S, int Hd, int W) {
   return (size_t)4 * S * B * Hd + (size_t)GRU_NSPLIT * 3 * Hd * (Hd + 1) + (size_t)gru_ih_slabs(B) * 3 * Hd * (W + 1) +
-         gru_xbuf_floats(B, Hd) + 4 + (size_t)B * Hd + 8;     // ... | exchange | carry (time segments) | progress
+         gru_xbuf_floats(B, Hd) + 4 + (size_t)B * Hd + 8 + 136;   // ... | exchange | carry (time segments) | progress | pad + 64 arrival counters of the fused dW_hh kernel
 }
 
 extern "C" int stemgnn_gru_fwd(const float* x, const float* w_ih, const float* w_hh, const float* b_ih,
@@ -1153,9 +1154,9 @@ extern "C" int stemgnn_gru_fwd(const float* x, const float* w_ih, const float* w
 // `slab0` .. `slab0 + nsplit - 1` of the GRU_NSPLIT slabs the final fixed-order reduce sums
 static int gru_wgrad_rows(const float* dgi, const float* dghn, const float* h_ext, const float* x, float* p_hh, float* p_ih,
                           int B, int S, int Hd, int W, int row0, int rows, int slab0, int nsplit, hipStream_t st_hh,
-                          hipStream_t st_ih, bool do_ih = true) {
+                          hipStream_t st_ih, bool do_ih = true, bool do_hh = true) {
   const int chunk = ((rows + nsplit - 1) / nsplit + 15) & ~15;
-  {  // dW_hh | db_hh = dgh^T [3Hd x rows] * [h_prev | 1]: rows 0..2Hd-1 of dgh are dgi's r,z gates, rows 2Hd..3Hd-1 = dghn
+  if (do_hh) {  // dW_hh | db_hh = dgh^T [3Hd x rows] * [h_prev | 1]: rows 0..2Hd-1 of dgh are dgi's r,z gates, rows 2Hd..3Hd-1 = dghn
      // (two "branches" of one 128x128 MFMA GEMM launch); h_prev of row (s,b) is row (s,b) of h_ext (slab 0 = zeros)
     G2Args g;
     G2SlabEpi e;
@@ -1211,7 +1212,7 @@ extern "C" int stemgnn_gru_bwd(const float* dh_all, const float* x, const float*
   float* p_ih = p_hh + (size_t)GRU_NSPLIT * 3 * Hd * (Hd + 1);
   const int P2 = gru_pick_P2(B, Hd);
   const int P = P2 > 0 ? 0 : gru_pick_P(B, Hd);
-  bool segmented = false, fold_ih = false;
+  bool segmented = false, fold_ih = false, hh_fused = false;
   GruWide wide;
   if (gru_pick_wide(B, Hd, P2, &wide) > 0) {
     float* xb = scratch + ((((size_t)(p_ih - scratch) + (size_t)gru_ih_slabs(B) * 3 * Hd * (W + 1)) + 3) & ~(size_t)3);
@@ -1346,8 +1347,32 @@ extern "C" int stemgnn_gru_bwd(const float* dh_all, const float* x, const float*
       SG_TRY(hipEventRecord(ev[10], st));
       SG_TRY(hipStreamWaitEvent(s2, ev[10], 0));
     }
+    // dW_hh | db_hh on the fused weight-gradient kernel (csrc/wgrad.h: direct-to-LDS ring, in-kernel fixed-order split
+    // reduction, results written straight into dw_hh / db_hh; the slab region doubles as its partial-tile workspace) when
+    // the 16-byte rules hold (Hd % 4 == 0); otherwise (and with STEMGNN_GRU_WG_FUSED=0) 32 slabs + the reduce below
+    static const bool wg_on = !(getenv("STEMGNN_GRU_WG_FUSED") && atoi(getenv("STEMGNN_GRU_WG_FUSED")) == 0);
+    if (wg_on) {
+      WgGemm q[2];
+      q[0].A = dgi;  q[0].lda = 3 * Hd; q[0].Mi = 2 * Hd; q[0].out = dw_hh; q[0].out_bias = db_hh;
+      q[1].A = dghn; q[1].lda = Hd;     q[1].Mi = Hd;     q[1].out = dw_hh + (size_t)2 * Hd * Hd; q[1].out_bias = db_hh + 2 * Hd;
+      bool ok = true;
+      for (int r = 0; r < 2; ++r) {
+        q[r].B = h_ext; q[r].ldb = Hd; q[r].Nj = Hd + 1; q[r].ones_col = Hd; q[r].ldo = Hd;
+        ok = ok && wg_gemm_ok(q[r]);
+      }
+      const int ntiles = wg_tile_index(q, 2);
+      const size_t ws_floats = (size_t)GRU_NSPLIT * 3 * Hd * (Hd + 1);
+      const int smax_ws = (int)(ws_floats / ((size_t)ntiles * WG_TILE_FLOATS));
+      if (ok && smax_ws >= 1 && ntiles <= 64) {
+        // arrival counters: the last 64 words of the 16-byte aligned part of the scratch tail (>= 128 spare floats)
+        const size_t tail = (stemgnn_gru_bwd_scratch_floats(B, S, Hd, W) - 64) & ~(size_t)3;
+        unsigned* cnt = reinterpret_cast<unsigned*>(scratch + tail);
+        SG_TRY(wg_launch(q, 2, S * B, p_hh, cnt, smax_ws > 32 ? 32 : smax_ws, st));
+        hh_fused = true;
+      }
+    }
     const int rc = gru_wgrad_rows(dgi, dghn, h_ext, x, p_hh, p_ih, B, S, Hd, W, 0, S * B, 0, GRU_NSPLIT, st,
-                                  ev && tail_par ? s2 : st, !fold_ih);
+                                  ev && tail_par ? s2 : st, !fold_ih, !hh_fused);
     if (rc) return rc;
     if (ev && tail_par) {
       SG_TRY(hipEventRecord(ev[11], s2));
@@ -1362,6 +1387,7 @@ extern "C" int stemgnn_gru_bwd(const float* dh_all, const float* x, const float*
     J.rows[1] = Hd; J.cols[1] = Hd;
     J.part[2] = p_ih; J.out_w[2] = dw_ih; J.out_b[2] = db_ih; J.rows[2] = 3 * Hd; J.cols[2] = W;
     J.nsplit[0] = J.nsplit[1] = GRU_NSPLIT; J.nsplit[2] = fold_ih ? B : GRU_NSPLIT;
+    if (hh_fused) J.rows[0] = J.rows[1] = 0;           // dw_hh / db_hh are complete already
     size_t nmax = n0;
     const size_t n2 = (size_t)3 * Hd * (W + 1);
     if (n2 > nmax) nmax = n2;

@@ -99,6 +99,10 @@ SG_HD int sg_wg_tiles(const SgDims& d) {
   int t = 0;
   for (int r = 0; r < 2; ++r)
     for (int l = 0; l < 3; ++l) t += sg_ceil_div(sg_glu_np(d, l, r), 128) * sg_ceil_div(sg_glu_kin(d, l) + 1, 128);
+  // + the heads' products when they ride in the same launch (stemgnn_block_wgrad): FR, F, BC and the two Wfold halves
+  const int tw = sg_ceil_div(d.Wm + 1, 128);
+  t += 2 * sg_ceil_div(d.W, 128) * tw + sg_ceil_div(d.Wm, 128) * tw;
+  for (int r = 0; r < 2; ++r) t += sg_ceil_div(d.CP2[r], 128) * sg_ceil_div(d.Wm, 128);
   return t;
 }
 SG_HD int sg_wg_smax(int tiles) {

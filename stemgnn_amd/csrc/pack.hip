@@ -12,7 +12,6 @@
 
 #include "../../include/stemgnn_hip.h"
 #include "layout.h"
-#include "reduce.h"
 
 #define SG_TRY(e)                                \
   do {                                           \
@@ -247,20 +246,9 @@ extern "C" int stemgnn_block_unpack_grads(const float* gradpart, int nsplit, con
   const SgGradLayout G = sg_grad_layout(d, nsplit);
   const SgTableLayout T = sg_table_layout(d);
   hipStream_t st = (hipStream_t)stream;
-  if (nsplit > 1) {
-    // only the heads' regions: the GLU regions arrive reduced (stemgnn_spectral_glu_bwd leaves the sum in slab 0)
-    SgSlabRegions R;
-    int n = 0;
-    R.off[n] = G.wfold; R.slab[n] = (size_t)d.KF * d.WmP; ++n;
-    R.off[n] = G.fr; R.slab[n] = (size_t)d.W * (d.Wm + 1); ++n;
-    R.off[n] = G.fc; R.slab[n] = (size_t)d.Wm * (d.Wm + 1); ++n;
-    if (has_backcast) {
-      R.off[n] = G.bc; R.slab[n] = (size_t)d.W * (d.Wm + 1); ++n;
-      R.off[n] = G.bs; R.slab[n] = (size_t)d.W * (d.W + 1); ++n;
-    }
-    R.n = n;
-    SG_TRY(sg_reduce_slabs(const_cast<float*>(gradpart), R, nsplit, st));
-  }
+  // every weight-gradient stage leaves the COMPLETE gradient in slab 0 of its region (stemgnn_block_wgrad, or the
+  // parts & 2 calls of stemgnn_igft_heads_bwd / stemgnn_spectral_glu_bwd): this stage only scatters; `nsplit` is the
+  // layout parameter the regions were sized with
   SgBlockGrads gr;
   for (int i = 0; i < SG_BLOCK_NPARAMS; ++i) gr.p[i] = grads_host[i];
   SgParamOffsets PO;

@@ -31,7 +31,8 @@
 
 #include "gemm2.h"
 
-constexpr int WG_MAXG = 8;        // products per launch
+constexpr int WG_MAXG = 12;       // products per launch
+constexpr int WG_SLOTS = 40;      // work items per XCD the block table holds (32 CUs per XCD + slack)
 constexpr int WG_TILE = 128;      // output tile 128 x 128, 4 waves as 2 x 2, each 64 x 64 = 2 x 2 MFMA tiles of 32 x 32
 constexpr int WG_TILE_FLOATS = WG_TILE * WG_TILE;
 #ifndef WG_ABL
@@ -45,8 +46,9 @@ constexpr int WG_TILE_FLOATS = WG_TILE * WG_TILE;
 struct WgGemm {
   const float* A;   // [K][lda]: A[k][i], i < Mi
   const float* B;   // [K][ldb]: B[k][j], j < ncolB;   column `ones_col` (== ncolB when >= 0) reads as 1.0
-  float* out;       // [Mi][Nj] row-major, Nj = ncolB + (ones_col >= 0)
-  int lda, ldb, Mi, Nj, ones_col;
+  float* out;       // [Mi][ldo] row-major (ldo >= the columns stored there)
+  float* out_bias;  // optional: column `ones_col` goes to out_bias[row] instead of out[row][ones_col] (then ldo may be ncolB)
+  int lda, ldb, Mi, Nj, ones_col, ldo;   // Nj = ncolB + (ones_col >= 0) output columns
   int nx, ny;       // tiles along i / j
   int tile0;        // index of this product's first tile (workspace / counter numbering)
 };
@@ -57,7 +59,9 @@ struct WgArgs {
   int K;            // reduction length (rows of every operand)
   int S;            // splits of the K range
   int ktps;         // K tiles (of BK rows) per split
-  int tmax;         // max nx * ny over the products (grid padding of the XCD-aware order)
+  int tmax;         // max nx * ny over the products (grid padding of the formula block order, `use_tab` == 0)
+  int use_tab;      // 1: blockIdx -> work item through `tab` (balanced XCD assignment built by the host)
+  unsigned short tab[8][WG_SLOTS];   // per XCD (= blockIdx % 8): (group << 6) | tile-in-group, 0xFFFF = no work
   float* ws;        // partial tiles [tile][split][WG_TILE_FLOATS] (lane-linear image), unused when S == 1
   unsigned* cnt;    // arrival counters [tiles], zero at launch
   int dbg;          // phase-ablation bits, honoured only by -DSG_WG_DEBUG builds (tools/wg_dbg.sh): 1 stop after the K loop,
@@ -217,11 +221,22 @@ __global__ __launch_bounds__(256, (STAGES * BK * 1024 <= 80 * 1024 ? 2 : 1)) voi
   // ONE shared array (a second __shared__ object makes hipcc drain vmcnt before every ds_read of a glds pipeline)
   __shared__ __attribute__((aligned(16))) float lds[STAGES * STAGE];
 
+  // block -> (product gi, split s, tile bx/by).  The dispatcher places block L on XCD L % 8 (8 private L2s): all tiles of
+  // one (product, split) GROUP share their operand panels, so a group stays on one XCD; the host deals the groups to the
+  // XCDs so that every XCD gets (nearly) the same number of workgroups (`tab`), or, for launches too big for the table,
+  // the closed-form order (group g on XCD g % 8, padded to the largest tile count).
   int gi, s, bx, by;
   {
     const int L = blockIdx.x, c = L & 7, idx = L >> 3;
-    const int t = idx % g.tmax, group = c + 8 * (idx / g.tmax);
-    if (group >= g.ngemm * g.S) return;
+    int t, group;
+    if (g.use_tab) {
+      const unsigned it = g.tab[c][idx];
+      if (it == 0xFFFFu) return;
+      group = (int)(it >> 6); t = (int)(it & 63);
+    } else {
+      t = idx % g.tmax; group = c + 8 * (idx / g.tmax);
+      if (group >= g.ngemm * g.S) return;
+    }
     gi = group / g.S;
     s = group - gi * g.S;
     if (t >= g.g[gi].nx * g.g[gi].ny) return;
@@ -356,19 +371,26 @@ __global__ __launch_bounds__(256, (STAGES * BK * 1024 <= 80 * 1024 ? 2 : 1)) voi
   // final store.  Interleaved fragment mapping: MFMA tile (i, j), register row r, lane column c is output element
   // (m0 + wm*64 + 2 r + i,  n0 + wn*64 + 2 c + j); the j = 0 / 1 values of a lane are neighbours -> one 8-byte store.
   float* __restrict__ out = G.out;
+  float* __restrict__ out_bias = G.out_bias;
+  const int ldo = G.ldo;
   const int col = n0 + wn * 64 + 2 * fi;
-  const bool vec2 = (Nj & 1) == 0 && ((reinterpret_cast<uintptr_t>(out) & 7) == 0);
+  const int nstore = out_bias ? ncolB : Nj;              // columns that live in `out`
+  const bool vec2 = (ldo & 1) == 0 && ((reinterpret_cast<uintptr_t>(out) & 7) == 0);
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) {
       const int row = m0 + wm * 64 + 2 * g2_row_of(reg, lane) + i;
       if (row >= Mi) continue;
-      float* o = out + (size_t)row * Nj + col;
-      if (vec2 && col + 1 < Nj) *reinterpret_cast<float2*>(o) = make_float2(acc[i][0][reg], acc[i][1][reg]);
+      float* o = out + (size_t)row * ldo + col;
+      if (vec2 && col + 1 < nstore) *reinterpret_cast<float2*>(o) = make_float2(acc[i][0][reg], acc[i][1][reg]);
       else {
-        if (col < Nj) o[0] = acc[i][0][reg];
-        if (col + 1 < Nj) o[1] = acc[i][1][reg];
+        if (col < nstore) o[0] = acc[i][0][reg];
+        if (col + 1 < nstore) o[1] = acc[i][1][reg];
+      }
+      if (out_bias) {
+        if (col == ones_col) out_bias[row] = acc[i][0][reg];
+        if (col + 1 == ones_col) out_bias[row] = acc[i][1][reg];
       }
     }
 }
@@ -395,13 +417,15 @@ static inline bool wg_operand_ok(const void* p, int ld) { return (((uintptr_t)p)
 static inline bool wg_gemm_ok(const WgGemm& q) {
   const int ncolB = q.ones_col >= 0 ? q.ones_col : q.Nj;
   return wg_operand_ok(q.A, q.lda) && wg_operand_ok(q.B, q.ldb) && (q.Mi & 3) == 0 && (ncolB & 3) == 0 && q.Mi > 0 &&
-         ncolB > 0 && (q.ones_col < 0 || q.ones_col == ncolB);
+         ncolB > 0 && (q.ones_col < 0 || q.ones_col == ncolB) && q.ldo >= (q.out_bias ? ncolB : q.Nj) &&
+         (!q.out_bias || q.ones_col >= 0);
 }
 
 // number of splits for `ntiles` output tiles and a K range of `K` rows (pure function: the workspace is sized by it)
-static inline int wg_splits(int ntiles, int K, int bk, int per_cu, int smax) {
+static inline int wg_splits(int ntiles, int K, int bk, int per_cu, int smax, int cu_percent = 100) {
   const int KT = (K + bk - 1) / bk;
-  int S = (256 * per_cu + ntiles / 2) / (ntiles > 0 ? ntiles : 1);
+  const int slots = 256 * per_cu * (cu_percent < 10 ? 10 : (cu_percent > 100 ? 100 : cu_percent)) / 100;
+  int S = slots / (ntiles > 0 ? ntiles : 1);      // never more workgroups than slots: one straggler round doubles the time
   if (S < 1) S = 1;
   if (S > smax) S = smax;
   const int min_kt = 8;                       // a split shorter than the ring depth only adds reduction traffic
@@ -421,9 +445,12 @@ static inline int wg_tile_index(WgGemm* q, int n) {
   return t;
 }
 
-// ws: >= ntiles * S * WG_TILE_FLOATS floats (when S > 1); cnt: >= ntiles unsigned.  S <= smax_ws is guaranteed.
+// ws: >= ntiles * S * WG_TILE_FLOATS floats (when S > 1); cnt: 16-byte aligned, >= round_up(ntiles, 64) unsigned.
+// S <= smax_ws is guaranteed.
+// cu_percent: share of the chip the launch should fill (100 = every CU; 50 leaves half of the CUs to whatever runs
+// beside it on another stream) -- fewer, longer splits, same results
 static inline hipError_t wg_launch(WgGemm* q, int n, int K, float* ws, unsigned* cnt, int smax_ws, hipStream_t st,
-                                   bool zero_counters = true) {
+                                   bool zero_counters = true, int cu_percent = 100) {
   if (n <= 0 || n > WG_MAXG || K <= 0) return hipErrorInvalidValue;
   const WgPlan p = wg_plan_from_env();
   WgArgs a;
@@ -441,15 +468,34 @@ static inline hipError_t wg_launch(WgGemm* q, int n, int K, float* ws, unsigned*
   a.dbg = 0;
 #endif
   const int KT = (K + p.bk - 1) / p.bk;
-  int S = wg_splits(ntiles, K, p.bk, p.per_cu, smax_ws);
+  int S = wg_splits(ntiles, K, p.bk, p.per_cu, smax_ws, cu_percent);
   a.ktps = (KT + S - 1) / S;
   a.S = (KT + a.ktps - 1) / a.ktps;              // no empty split
   if (a.S > 1 && zero_counters) {
-    hipError_t e = hipMemsetAsync(cnt, 0, sizeof(unsigned) * ntiles, st);
+    // one aligned fill (a ragged range is split into head / body / tail fill kernels, ~5 us each): cnt is 16-byte aligned
+    // and holds at least the tile count rounded up to 64 words
+    hipError_t e = hipMemsetAsync(cnt, 0, sizeof(unsigned) * (((size_t)ntiles + 63) & ~(size_t)63), st);
     if (e != hipSuccess) return e;
   }
   const int groups = n * a.S;
-  dim3 grid(8 * ((groups + 7) / 8) * tmax);
+  // deal the groups to the XCDs: each to the XCD with the fewest workgroups so far (host-side, a few hundred operations)
+  int load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  a.use_tab = groups < 1024 && tmax <= 64;
+  if (a.use_tab) {
+    for (int c = 0; c < 8; ++c)
+      for (int k = 0; k < WG_SLOTS; ++k) a.tab[c][k] = 0xFFFFu;
+    for (int grp = 0; grp < groups && a.use_tab; ++grp) {
+      const int gi = grp / a.S, nt = q[gi].nx * q[gi].ny;
+      int best = 0;
+      for (int c = 1; c < 8; ++c)
+        if (load[c] < load[best]) best = c;
+      if (load[best] + nt > WG_SLOTS) { a.use_tab = 0; break; }
+      for (int t = 0; t < nt; ++t) a.tab[best][load[best]++] = (unsigned short)((grp << 6) | t);
+    }
+  }
+  int maxload = 0;
+  for (int c = 0; c < 8; ++c) maxload = load[c] > maxload ? load[c] : maxload;
+  dim3 grid(a.use_tab ? 8 * maxload : 8 * ((groups + 7) / 8) * tmax);
   if (p.bk == 16 && p.stages == 6) hipLaunchKernelGGL((sg_wgrad_kernel<16, 6>), grid, dim3(256), 0, st, a);
   else if (p.bk == 16 && p.stages == 4) hipLaunchKernelGGL((sg_wgrad_kernel<16, 4>), grid, dim3(256), 0, st, a);
   else if (p.bk == 16 && p.stages == 3) hipLaunchKernelGGL((sg_wgrad_kernel<16, 3>), grid, dim3(256), 0, st, a);

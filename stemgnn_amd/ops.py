@@ -107,6 +107,10 @@ def set_direct_grad(model, flag=True, overlap=False):
 
 
 _NCHUNK = int(os.environ.get("STEMGNN_ATTN_CHUNKS", "16"))  # row chunks of the attention backward
+# share of the CUs (percent) the fused weight-gradient launches fill in side-stream mode: [0] the first launch on the side
+# stream (beside GEMM / Chebyshev kernels of the main stream), [1] the second (under the GRU recurrence: half of the CUs)
+_WG_CU = (int(os.environ.get("STEMGNN_WG_CU0", "100")), int(os.environ.get("STEMGNN_WG_CU1", "50")))
+_WG_SCHED = os.environ.get("STEMGNN_WG_SCHED", "late")
 
 
 def _stream():
@@ -392,9 +396,12 @@ class StockBlockFn(torch.autograd.Function):
         _lib.check(lib.stemgnn_igft_heads_bwd(
             parr, pk.data_ptr(), sv.data_ptr(), X.data_ptr(), sb, sn, stt, dforecast.data_ptr(),
             dbackcast.contiguous().data_ptr() if use_bc else None, backcast.data_ptr() if use_bc else None,
-            scratch.data_ptr(), gradpart.data_ptr(), nsplit, 3, B, N, W, multi, st), "igft_heads_bwd")
+            scratch.data_ptr(), gradpart.data_ptr(), nsplit, 1, B, N, W, multi, st), "igft_heads_bwd")
         _lib.check(lib.stemgnn_spectral_glu_bwd(pk.data_ptr(), sv.data_ptr(), scratch.data_ptr(), gradpart.data_ptr(),
-                                                nsplit, 3, B, N, W, multi, st), "spectral_glu_bwd")
+                                                nsplit, 1, B, N, W, multi, st), "spectral_glu_bwd")
+        _lib.check(lib.stemgnn_block_wgrad(parr, pk.data_ptr(), sv.data_ptr(), X.data_ptr(), sb, sn, stt,
+                                           dforecast.data_ptr(), int(use_bc), scratch.data_ptr(), gradpart.data_ptr(),
+                                           nsplit, 100, B, N, W, multi, st), "block_wgrad")
         _lib.check(lib.stemgnn_gft_bwd(mul_L.data_ptr(), X.data_ptr(), sb, sn, stt, dG.data_ptr(), dX.data_ptr(),
                                        dmul_L.data_ptr(), 0, B, N, W, st), "gft_bwd")
         grads = [None] * 33
@@ -595,45 +602,61 @@ class SpectralHotPath(torch.autograd.Function):
             garr = _lib.ptr_array(grads[s])
             keep.append((parr, garr))
 
-            def heads(parts, stream):
+            def heads(stream):                  # data part: dpF, dpB, dig, d(pre-activation) of the last GLU layer
                 _lib.check(lib.stemgnn_igft_heads_bwd(
                     parr, packed[s].data_ptr(), saved[s].data_ptr(), X.data_ptr(), sb, sn, stt, dfsum.data_ptr(),
                     dbackcast.data_ptr() if has_bc else None, backcast.data_ptr() if has_bc else None,
-                    scratch.data_ptr(), gradpart.data_ptr(), nsplit, parts, B, N, W, multi, stream), "igft_heads_bwd")
+                    scratch.data_ptr(), gradpart.data_ptr(), nsplit, 1, B, N, W, multi, stream), "igft_heads_bwd")
 
-            def glu(parts, stream):
+            def glu(stream):                    # data-gradient chain of the three GLU layers -> dG
                 _lib.check(lib.stemgnn_spectral_glu_bwd(
-                    packed[s].data_ptr(), saved[s].data_ptr(), scratch.data_ptr(), gradpart.data_ptr(), nsplit, parts,
+                    packed[s].data_ptr(), saved[s].data_ptr(), scratch.data_ptr(), gradpart.data_ptr(), nsplit, 1,
                     B, N, W, multi, stream), "spectral_glu_bwd")
+
+            def wgrad(stream, cu_percent):      # every weight gradient of the block (fused kernel + the BS head)
+                _lib.check(lib.stemgnn_block_wgrad(
+                    parr, packed[s].data_ptr(), saved[s].data_ptr(), X.data_ptr(), sb, sn, stt, dfsum.data_ptr(),
+                    int(has_bc), scratch.data_ptr(), gradpart.data_ptr(), nsplit, cu_percent, B, N, W, multi, stream),
+                    "block_wgrad")
 
             def unpack(stream):
                 _lib.check(lib.stemgnn_block_unpack_grads(
                     gradpart.data_ptr(), nsplit, tables.data_ptr(), garr, W, multi, int(has_bc), stream),
                     "block_unpack_grads")
 
-            return heads, glu, unpack
+            return heads, glu, wgrad, unpack
 
+        # side-stream schedule (STEMGNN_WG_SCHED): "late" (default): both launches behind block 0's data-gradient chain --
+        # block 0's beside the Chebyshev / attention backward chain, block 1's (sized for half of the CUs) under the GRU
+        # recurrence.  "early" forks block 1's right behind its own chain, beside block 0's MFMA-bound data-gradient
+        # kernels: measured 170 us SLOWER per step (two GEMM streams on one chip are zero-sum, profiles/r03_wgrad.md).
+        early = overlap and defer_b1 and _WG_SCHED == "early"
         for s in (1, 0):
             scratch = bufs[s][0]
             dG = scratch[off_dG:]
             X, sb, sn, stt = xviews[s]
-            heads, glu, unpack = stage_fns(s)
+            heads, glu, wgrad, unpack = stage_fns(s)
+            heads(st)
+            glu(st)
             if overlap and (s == 0 or defer_b1):
-                heads(1, st)
-                glu(1, st)
-                if s == 0:
+                if early:
+                    side.wait_stream(main)                   # fork behind THIS block's data-gradient chain
+                    with torch.cuda.stream(side):
+                        wgrad(side.cuda_stream, _WG_CU[1 - s])   # _WG_CU[0]: launch beside the GEMM chain, [1]: under the GRU
+                        unpack(side.cuda_stream)
+                    if s == 0:
+                        keep.append(bufs)                    # alive until the join
+                elif s == 0:
                     side.wait_stream(main)                   # fork: every data-gradient chain is queued
                     with torch.cuda.stream(side):
                         sst = side.cuda_stream
                         for ss in ((0, 1) if defer_b1 else (0,)):
-                            h2, g2, u2 = (heads, glu, unpack) if ss == 0 else stage_fns(1)
-                            h2(2, sst)
-                            g2(2, sst)
+                            _h, _g, w2, u2 = (heads, glu, wgrad, unpack) if ss == 0 else stage_fns(1)
+                            w2(sst, _WG_CU[ss])
                             u2(sst)
                     keep.append(bufs)                        # alive until the join
             else:
-                heads(3, st)
-                glu(3, st)
+                wgrad(st, 100)
                 unpack(st)
             _lib.check(lib.stemgnn_gft_bwd(
                 mul_L.data_ptr(), X.data_ptr(), sb, sn, stt, dG.data_ptr(),

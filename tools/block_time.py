@@ -59,6 +59,8 @@ def main():
         ("spectral_glu_bwd wgrad", lambda: lib.stemgnn_spectral_glu_bwd(P(pk), P(sv), P(scratch), P(gradpart), nsplit, 2,
                                                                         B, N, W, multi, s)),
         ("gft_bwd", lambda: lib.stemgnn_gft_bwd(P(mul_L), P(X), sb, sn, stt, P(dG), P(dX), P(dmul_L), 0, B, N, W, s)),
+        ("block_wgrad (all weight gradients)", lambda: lib.stemgnn_block_wgrad(
+            parr, P(pk), P(sv), P(X), sb, sn, stt, P(dforecast), 1, P(scratch), P(gradpart), nsplit, 100, B, N, W, multi, s)),
         ("block_unpack_grads", lambda: lib.stemgnn_block_unpack_grads(P(gradpart), nsplit, P(tables), garr, W, multi, 1, s)),
     ]
     total = 0.0

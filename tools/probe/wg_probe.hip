@@ -28,7 +28,7 @@ int main(int argc, char** argv) {
   size_t oa = 0, ob = 0, oo = 0;
   for (int i = 0; i < 6; ++i) {
     q[i].A = A + oa; q[i].lda = np[i]; q[i].B = B + ob; q[i].ldb = kin[i]; q[i].out = O + oo;
-    q[i].Mi = np[i]; q[i].Nj = kin[i] + 1; q[i].ones_col = kin[i];
+    q[i].Mi = np[i]; q[i].Nj = kin[i] + 1; q[i].ones_col = kin[i]; q[i].ldo = q[i].Nj; q[i].out_bias = nullptr;
     oa += (size_t)M * np[i]; ob += (size_t)M * kin[i]; oo += (size_t)np[i] * (kin[i] + 1);
   }
   const int ntiles = wg_tile_index(q, 6);
