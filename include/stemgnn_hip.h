@@ -222,6 +222,15 @@ int stemgnn_fc_tail_fwd(const float* fsum, const float* w0, const float* b0, con
 int stemgnn_fc_tail_bwd(const float* dforecast, const float* fsum, const float* w0, const float* b0, const float* w2,
                         int B, int N, int W, int H, float* scratch, float* dfsum, float* dw0, float* db0,
                         float* dw2, float* db2, void* stream);
+/* training tail in two launches: fc forward -> nn.MSELoss(reduction='mean') against target [B,H,N] -> d(loss)/d(forecast)
+ * (upstream gradient taken as 1: loss.backward(), models/handler.py:162-164) -> fc backward.  Writes the loss (float, and
+ * += into *loss_accum, double, if given), dfsum [B*N, W] and the four fc parameter gradients; forecast [B,H,N] is also
+ * written when non-NULL.  Same arithmetic as stemgnn_fc_tail_fwd + stemgnn_mse_fwd/_bwd + stemgnn_fc_tail_bwd. */
+size_t stemgnn_fc_tail_train_scratch_floats(int B, int N, int W, int H);
+int stemgnn_fc_tail_train(const float* fsum, const float* target, const float* w0, const float* b0, const float* w2,
+                          const float* b2, int B, int N, int W, int H, float* scratch, float* forecast,
+                          float* loss, double* loss_accum, float* dfsum, float* dw0, float* db0, float* dw2,
+                          float* db2, void* stream);
 /* RMSprop step of the reference driver (models/handler.py:127,165; torch defaults alpha=0.99, momentum 0, not
  * centered) over flat, 16-byte aligned parameter / gradient / square_avg buffers of n floats; lr is read from
  * device memory; zero_grad != 0 also clears the gradients for the next step (handler.py:160); every gradient is

@@ -73,6 +73,9 @@ SIGNATURES = {
                                        c_int, c_int, c_int, c_int, _P]),
     "stemgnn_igft_heads_bwd": (c_int, [_PP, _P, _P, _P, c_long, c_long, c_long, _P, _P, _P, _P, _P, c_int, c_int,
                                        c_int, c_int, c_int, c_int, _P]),
+    "stemgnn_fc_tail_train_scratch_floats": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "stemgnn_fc_tail_train": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P,
+                                      _P, _P]),
     "stemgnn_block_wgrad": (c_int, [_PP, _P, _P, _P, c_long, c_long, c_long, _P, c_int, _P, _P, c_int, c_int,
                                     c_int, c_int, c_int, c_int, _P]),
 }

@@ -19,7 +19,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib, ops
-from .ops import FcTail, GruFront, SpectralHotPath, StockBlockFn
+from .ops import FcTail, FcTailMse, GruFront, SpectralHotPath, StockBlockFn
 
 _instance_counter = itertools.count()
 _BLOCK_FIELDS = ("forecast", "forecast_result", "backcast", "backcast_short_cut")
@@ -188,6 +188,20 @@ class Model(nn.Module):
         params = blocks[0] + blocks[1]
         return SpectralHotPath.apply(h, x, self.weight_key, self.weight_query, self.multi_layer, self.alpha,
                                      self.dropout_rate, self.training, seed, hs, *params)
+
+    def loss(self, x, target, loss_out=None, accum=None, unit_grad=False):
+        """MSE training loss of one batch, ``nn.MSELoss()(self(x)[0], target)`` (models/handler.py:161-162), with the fc tail,
+        the loss and both their backwards fused into one autograd node (two launches instead of five; forecast itself is
+        not materialised).  `loss_out` / `accum`: optional static float32 scalar to write the loss into / float64 scalar
+        that receives += loss.  `unit_grad`: the caller promises ``loss.backward()`` with an upstream gradient of 1 (what
+        the driver does), which lets direct-gradient mode write the fc gradients in place.  Falls back to forward() +
+        ops.mse_loss when the fused kernels do not cover (time_step, horizon)."""
+        if not _lib.load().stemgnn_fc_tail_supported(self.time_step, self.horizon):
+            forecast, _ = self.forward(x)
+            return ops.mse_loss(forecast, target, loss_out, accum)
+        fsum, _attention, _ = self.hot_path(x)
+        return FcTailMse.apply(fsum, target, self.fc[0].weight, self.fc[0].bias, self.fc[2].weight, self.fc[2].bias,
+                               self.hot_state, loss_out, accum, unit_grad)
 
     def forward(self, x):
         fsum, attention, _ = self.hot_path(x)

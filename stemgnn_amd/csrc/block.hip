@@ -14,6 +14,8 @@
 #include "layout.h"
 #include "reduce.h"
 #include "wgrad.h"
+#include "heads.h"
+#include "rgemm.h"
 
 #define SG_TRY(e)                                \
   do {                                           \
@@ -357,6 +359,83 @@ struct GluDpreEpi {
   }
 };
 
+// ---- epilogues of the ring-pipelined GEMM (rgemm.h) ------------------------------------------------------------------
+// forward: MFMA tile 0 = linear_left, tile 1 = linear_right of the SAME 32 channels (the DMA de-interleaves the pair
+// panel), so u, v of a channel sit in one lane: no exchange, 128 contiguous bytes per row and store
+struct RgGluFwdEpi {
+  static constexpr bool PAIR = true;
+  const float* bp[2];      // packed bias, pair order
+  float* out[2];
+  float* gate[2];
+  int cp[2];               // padded channels of this layer (= N / 2)
+  __device__ void tile(int r, int row0, int col0, int M, int N, const sg_f32x16 (&acc)[2][2], int lane) const {
+    const int L = lane & 31;
+    const int c = (col0 >> 1) + L;                       // channel
+    const int ld = cp[r];
+    if (c >= ld) return;
+    const int q = ((c >> 4) << 5) + (c & 15);            // pair column of the left value
+    const float bl = bp[r][q], br = bp[r][q + 16];
+    float* po = out[r] + c;
+    float* pg = gate[r] + c;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int row = row0 + i * 32 + g2_row_of(reg, lane);
+        const float u = acc[i][0][reg] + bl, v = acc[i][1][reg] + br;
+        const float gt = sg_sigmoid(v);
+        if (row < M) {
+          po[(size_t)row * ld] = u * gt;
+          pg[(size_t)row * ld] = gt;
+        }
+      }
+    (void)N;
+  }
+};
+// data gradient of layer l -> d(pre-activation) of layer l-1 (pair order): d = dX[row][c]; left: d * gate; right:
+// d * out * (1 - gate).  A lane owns channel c of two MFMA tiles; lanes 0-15 / 16-31 of a tile write the two 64-byte
+// halves [L16 | . ] of consecutive pair groups.
+struct RgGluDpreEpi {
+  static constexpr bool PAIR = false;
+  const float* out[2];
+  const float* gate[2];
+  float* dpre[2];
+  int cp;                  // channels of layer l-1 (= N); its pair panel is 2*cp wide
+  __device__ void tile(int r, int row0, int col0, int M, int N, const sg_f32x16 (&acc)[2][2], int lane) const {
+    const int L = lane & 31;
+    const float* po = out[r];
+    const float* pg = gate[r];
+    float* pd = dpre[r];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int c = col0 + j * 32 + L;
+      if (c >= N) continue;
+      const int q = ((c >> 4) << 5) + (c & 15);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        float y[16], gt[16];
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+          const int row = row0 + i * 32 + g2_row_of(reg, lane);
+          const size_t o = (size_t)(row < M ? row : 0) * cp + c;
+          y[reg] = po[o];
+          gt[reg] = pg[o];
+        }
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+          const int row = row0 + i * 32 + g2_row_of(reg, lane);
+          const float d = acc[i][j][reg];
+          if (row < M) {
+            float* dst = pd + (size_t)row * 2 * cp + q;
+            dst[0] = d * gt[reg];
+            dst[16] = d * y[reg] * (1.f - gt[reg]);
+          }
+        }
+      }
+    }
+  }
+};
+
 // layer-0 data gradient: dG[m][kin] = sum_r sum_q dpre_r[m][q] Wp0_r[kin][q]  (N = 3W is tiny: the 64-wide generic
 // tile wastes far less than a 128-wide one, and K concatenates the two branches in one launch)
 struct GluDgrad0Op {
@@ -601,6 +680,17 @@ static inline int g2_bk32_mask() {
 }
 // reductions longer than this use the two-level accumulating instantiations (large W*multi configurations)
 constexpr int SG_LONG_K = 640;
+// ring-pipelined GLU forward / data-gradient GEMM (rgemm.h): parity-tested, measured NOT faster than the sg_gemm2 tiles at
+// the headline shape (K = 240 per layer: 15 ring stages per tile, the ramp and the epilogue dominate; forward 18.8 / 44.7 /
+// 33.0 us against 17.8 / 45.6 / 28.1, data gradient 37.7 / 57.3 against 31.8 / 50.8 -- profiles/r03_wgrad.md) -> opt-in
+static inline bool heads_fused_on() {
+  static const int v = getenv("STEMGNN_HEADS_FUSED") ? atoi(getenv("STEMGNN_HEADS_FUSED")) : 1;
+  return v != 0;
+}
+static inline bool rg_on() {
+  static const int v = getenv("STEMGNN_RG") ? atoi(getenv("STEMGNN_RG")) : 0;
+  return v != 0;
+}
 static inline bool wg_fused_on() {
   static const int v = getenv("STEMGNN_WG_FUSED") ? atoi(getenv("STEMGNN_WG_FUSED")) : 1;
   return v != 0;
@@ -705,6 +795,19 @@ extern "C" int stemgnn_spectral_glu_fwd(const float* packed, float* saved, int B
       e.cp[r] = sg_glu_cp(d, l, r);
     }
     g.nsplit = 1; g.chunk = (sg_glu_kin(d, l) + 15) & ~15; g.b_ones_col = -1;
+    if (rg_on() && sg_glu_kin(d, l) <= SG_LONG_K) {       // ring-pipelined kernel (rgemm.h) where its 16-byte rules hold
+      RgArgs ra;
+      RgGluFwdEpi re;
+      for (int r = 0; r < 2; ++r) {
+        ra.A[r] = g.A[r]; ra.lda[r] = g.lda[r]; ra.B[r] = g.B[r]; ra.ldb[r] = g.ldb[r];
+        ra.M[r] = g.M[r]; ra.N[r] = g.N[r]; ra.K[r] = g.K[r];
+        re.bp[r] = e.bp[r]; re.out[r] = e.out[r]; re.gate[r] = e.gate[r]; re.cp[r] = e.cp[r];
+      }
+      if (rg_ok(ra, 2, false)) {
+        SG_TRY((rg_launch<RgGluFwdEpi, false>(ra, re, 2, st)));
+        continue;
+      }
+    }
     if (sg_glu_kin(d, l) > SG_LONG_K) SG_TRY((g2_launch<GluFwdEpi, true, false, 64, true>(g, e, 2, st)));
     else if (g2_bk32_mask() & 1) SG_TRY((g2_launch<GluFwdEpi, true, false, 64, false, 32>(g, e, 2, st)));
     else if (g2_bm_mask() & 1) SG_TRY((g2_launch<GluFwdEpi, true, false, 64>(g, e, 2, st)));
@@ -781,6 +884,20 @@ extern "C" int stemgnn_spectral_glu_bwd(const float* packed, const float* saved,
       }
       e.cp = d.CP;
       g.nsplit = 1; g.chunk = (2 * d.CP + 15) & ~15; g.b_ones_col = -1;
+      if (rg_on() && 2 * d.CP <= SG_LONG_K) {
+        RgArgs ra;
+        RgGluDpreEpi re;
+        for (int r = 0; r < 2; ++r) {
+          ra.A[r] = g.A[r]; ra.lda[r] = g.lda[r]; ra.B[r] = g.B[r]; ra.ldb[r] = g.ldb[r];
+          ra.M[r] = g.M[r]; ra.N[r] = g.N[r]; ra.K[r] = g.K[r];
+          re.out[r] = e.out[r]; re.gate[r] = e.gate[r]; re.dpre[r] = e.dpre[r];
+        }
+        re.cp = d.CP;
+        if (rg_ok(ra, 2, true)) {
+          SG_TRY((rg_launch<RgGluDpreEpi, true>(ra, re, 2, st)));
+          continue;
+        }
+      }
       if (2 * d.CP > SG_LONG_K) SG_TRY((g2_launch<GluDpreEpi, true, true, 64, true>(g, e, 2, st)));
       else if (g2_bk32_mask() & 2) SG_TRY((g2_launch<GluDpreEpi, true, true, 64, false, 32>(g, e, 2, st)));
       else if (g2_bm_mask() & 2) SG_TRY((g2_launch<GluDpreEpi, true, true, 64>(g, e, 2, st)));
@@ -823,6 +940,28 @@ extern "C" int stemgnn_igft_heads_fwd(const float* const* params_host, const flo
   hipStream_t st = (hipStream_t)stream;
   const int has_bc = backcast != nullptr;
   if (has_bc && (!params_host[5] || !params_host[6])) return SG_EINVAL;
+  // one fused kernel per block (csrc/heads.h) when the 32-row block fits the LDS budget; STEMGNN_HEADS_FUSED=0 and large
+  // W*multi take the three descriptor GEMMs below
+  const size_t hd_bytes = hd_fwd_lds_floats(d.KF, d.WmP, W) * sizeof(float);
+  if (heads_fused_on() && hd_bytes <= (size_t)150 * 1024 && d.KF <= SG_LONG_K) {
+    HeadsFwdArgs a;
+    for (int r = 0; r < 2; ++r) { a.a3[r] = saved + S.out[r][2]; a.cp2[r] = d.CP2[r]; }
+    a.wfold = packed + P.wfold;
+    a.Fw = params_host[1]; a.Fb = params_host[2]; a.FRw = params_host[3]; a.FRb = params_host[4];
+    a.BCw = params_host[5]; a.BCb = params_host[6]; a.BSw = params_host[7]; a.BSb = params_host[8];
+    a.X = HdXView{X, xs_b, xs_n, xs_t, N};
+    a.ig = saved + S.ig; a.fs = saved + S.fs; a.forecast = forecast; a.backcast = backcast;
+    a.M = d.M; a.W = W; a.Wm = d.Wm; a.WmP = d.WmP; a.KF = d.KF; a.accumulate = accumulate; a.has_bc = has_bc;
+    a.lda = hd_lda(d.KF); a.ldi = d.WmP + 1;
+    static size_t attr_bytes = 0;
+    if (hd_bytes > 64 * 1024 && hd_bytes > attr_bytes) {
+      SG_TRY(hipFuncSetAttribute((const void*)sg_heads_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hd_bytes));
+      attr_bytes = hd_bytes;
+    }
+    hipLaunchKernelGGL(sg_heads_fwd_kernel, dim3((d.M + HD_RB - 1) / HD_RB), dim3(256), hd_bytes, st, a);
+    SG_TRY(hipGetLastError());
+    return 0;
+  }
   {
     IgftOp op;
     for (int r = 0; r < 2; ++r) { op.a3[r] = saved + S.out[r][2]; op.cp2[r] = d.CP2[r]; }
@@ -877,6 +1016,31 @@ extern "C" int stemgnn_igft_heads_bwd(const float* const* params_host, const flo
   float* dpF = scratch + C.dpF;
   float* dpB = scratch + C.dpB;
   float* dig = scratch + C.dig;
+  bool fused_data = false;
+  {
+    const size_t hb = hd_bwd_lds_floats(d.WmP, W) * sizeof(float);
+    if ((parts & 1) && heads_fused_on() && hb <= (size_t)150 * 1024 && d.Wm <= SG_LONG_K) {
+      HeadsBwdArgs a;
+      a.dfo = dforecast; a.dbc = dbackcast; a.bc = backcast; a.fs = saved + S.fs; a.wfold = packed + P.wfold;
+      a.Fw = params_host[1]; a.FRw = params_host[3]; a.BCw = params_host[5];
+      for (int r = 0; r < 2; ++r) {
+        a.out2[r] = saved + S.out[r][2]; a.gate2[r] = saved + S.gate[r][2]; a.dpre2[r] = scratch + C.dact[r][2];
+        a.cp2[r] = d.CP2[r];
+      }
+      a.dpF = dpF; a.dpB = dpB; a.dig = dig;
+      a.M = d.M; a.W = W; a.Wm = d.Wm; a.WmP = d.WmP; a.KF = d.KF; a.has_bc = has_bc;
+      a.ldi = d.WmP + 1; a.ldw = ((W + 3) & ~3) + 1;
+      static size_t attr_bytes = 0;
+      if (hb > 64 * 1024 && hb > attr_bytes) {
+        SG_TRY(hipFuncSetAttribute((const void*)sg_heads_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hb));
+        attr_bytes = hb;
+      }
+      hipLaunchKernelGGL(sg_heads_bwd_kernel, dim3((d.M + HD_RB - 1) / HD_RB), dim3(256), hb, st, a);
+      SG_TRY(hipGetLastError());
+      fused_data = true;
+    }
+  }
+  if (fused_data) parts &= ~1;
   if ((parts & 1) && has_bc) {
     const size_t n = (size_t)d.M * W;
     const int blocks = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);

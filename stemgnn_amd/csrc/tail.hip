@@ -200,6 +200,153 @@ extern "C" int stemgnn_fc_tail_bwd(const float* dforecast, const float* fsum, co
   return 0;
 }
 
+// ---- training tail in two launches (round 3) ------------------------------------------------------------------------
+// fc forward -> MSE(reduction = 'mean') -> d(loss)/d(forecast) -> fc backward, per 64-row block, in ONE kernel: the loss
+// gradient 2 (f - y) / n needs no global quantity, so nothing forces the five launches of the separate stages
+// (fc fwd, MSE, MSE bwd, fc bwd, reduce: 40 us at PEMS07).  Second launch: fixed-order sum of the per-block weight-gradient
+// and loss partials.  d(loss) upstream is taken as 1 (the driver calls loss.backward(), models/handler.py:164); the host
+// wrapper scales for any other value.  partial layout per block: dw0[W*W] | db0[W] | dw2[H*W] | db2[H] | sum (f - y)^2.
+__global__ __launch_bounds__(256) void sg_fc_tail_train_kernel(const float* __restrict__ fsum, const float* __restrict__ target,
+                                                               const float* __restrict__ w0, const float* __restrict__ b0,
+                                                               const float* __restrict__ w2, const float* __restrict__ b2,
+                                                               int B, int N, int W, int H, float* __restrict__ forecast,
+                                                               float* __restrict__ dfsum, float* __restrict__ partial) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int nacc = W * W + W + H * W + H;
+  float* sw0 = sm;
+  float* sb0 = sw0 + W * W;
+  float* sw2 = sb0 + W;
+  float* sb2 = sw2 + H * W;
+  float* sx = sb2 + H;                     // [RB][W+1]
+  float* sdz = sx + TAIL_RB * (W + 1);     // [RB][W+1]   z, then dz
+  float* sa = sdz + TAIL_RB * (W + 1);     // [RB][W+1]
+  float* sdy = sa + TAIL_RB * (W + 1);     // [RB][H+1]
+  float* sred = sdy + TAIL_RB * (H + 1);   // [256]
+  const int tid = threadIdx.x, r = tid & 63, q = tid >> 6;
+  const int M = B * N, m0 = blockIdx.x * TAIL_RB, m = m0 + r;
+  for (int i = tid; i < W * W; i += 256) sw0[i] = w0[i];
+  for (int i = tid; i < W; i += 256) sb0[i] = b0[i];
+  for (int i = tid; i < H * W; i += 256) sw2[i] = w2[i];
+  for (int i = tid; i < H; i += 256) sb2[i] = b2[i];
+  for (int i = tid; i < TAIL_RB * W; i += 256) {
+    const int rr = i / W, t = i - rr * W;
+    sx[rr * (W + 1) + t] = m0 + rr < M ? fsum[(size_t)m0 * W + i] : 0.f;
+  }
+  __syncthreads();
+  for (int t = q; t < W; t += 4) {
+    float z = sb0[t];
+    for (int u = 0; u < W; ++u) z = fmaf(sx[r * (W + 1) + u], sw0[t * W + u], z);
+    sdz[r * (W + 1) + t] = z;
+    sa[r * (W + 1) + t] = m < M ? (z > 0.f ? z : 0.01f * z) : 0.f;
+  }
+  __syncthreads();
+  float sq = 0.f;
+  {
+    const int mc = m < M ? m : 0, b = mc / N, n = mc - b * N;
+    const float scale = 2.f / ((float)B * (float)H * (float)N);
+    for (int h = q; h < H; h += 4) {
+      float y = sb2[h];
+      for (int t = 0; t < W; ++t) y = fmaf(sa[r * (W + 1) + t], sw2[h * W + t], y);
+      const size_t o = ((size_t)b * H + h) * N + n;
+      const float d = m < M ? y - target[o] : 0.f;
+      if (m < M && forecast) forecast[o] = y;
+      sq = fmaf(d, d, sq);
+      sdy[r * (H + 1) + h] = d * scale;
+    }
+  }
+  sred[tid] = sq;
+  __syncthreads();
+  for (int t = q; t < W; t += 4) {
+    const float z = sdz[r * (W + 1) + t];
+    float da = 0.f;
+    for (int h = 0; h < H; ++h) da = fmaf(sdy[r * (H + 1) + h], sw2[h * W + t], da);
+    sdz[r * (W + 1) + t] = m < M ? (z > 0.f ? da : 0.01f * da) : 0.f;     // own element: read z, write dz
+  }
+  __syncthreads();
+  if (m < M)
+    for (int u = q; u < W; u += 4) {
+      float d = 0.f;
+      for (int t = 0; t < W; ++t) d = fmaf(sdz[r * (W + 1) + t], sw0[t * W + u], d);
+      dfsum[(size_t)m * W + u] = d;
+    }
+  for (int e = tid; e < nacc + 1; e += 256) {
+    float sum = 0.f;
+    if (e < W * W) {
+      const int t = e / W, u = e - t * W;
+      for (int rr = 0; rr < TAIL_RB; ++rr) sum = fmaf(sdz[rr * (W + 1) + t], sx[rr * (W + 1) + u], sum);
+    } else if (e < W * W + W) {
+      const int t = e - W * W;
+      for (int rr = 0; rr < TAIL_RB; ++rr) sum += sdz[rr * (W + 1) + t];
+    } else if (e < W * W + W + H * W) {
+      const int qq = e - W * W - W, h = qq / W, t = qq - h * W;
+      for (int rr = 0; rr < TAIL_RB; ++rr) sum = fmaf(sdy[rr * (H + 1) + h], sa[rr * (W + 1) + t], sum);
+    } else if (e < nacc) {
+      const int h = e - W * W - W - H * W;
+      for (int rr = 0; rr < TAIL_RB; ++rr) sum += sdy[rr * (H + 1) + h];
+    } else {
+      for (int i = 0; i < 256; ++i) sum += sred[i];                      // fixed order
+    }
+    partial[(size_t)blockIdx.x * (nacc + 1) + e] = sum;
+  }
+}
+
+__global__ __launch_bounds__(256) void sg_fc_tail_train_reduce_kernel(const float* __restrict__ partial, int nblocks, int W,
+                                                                      int H, float inv_n, float* __restrict__ dw0,
+                                                                      float* __restrict__ db0, float* __restrict__ dw2,
+                                                                      float* __restrict__ db2, float* __restrict__ loss,
+                                                                      double* __restrict__ accum) {
+  __shared__ float red[4][64];
+  const int nacc = W * W + W + H * W + H;
+  const int i = blockIdx.x * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
+  float s = 0.f;
+  if (i <= nacc)
+    for (int b = q; b < nblocks; b += 4) s += partial[(size_t)b * (nacc + 1) + i];
+  red[q][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (q != 0 || i > nacc) return;
+  s = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+  if (i < W * W) dw0[i] = s;
+  else if (i < W * W + W) db0[i - W * W] = s;
+  else if (i < W * W + W + H * W) dw2[i - W * W - W] = s;
+  else if (i < nacc) db2[i - W * W - W - H * W] = s;
+  else {
+    const float l = s * inv_n;
+    loss[0] = l;
+    if (accum) accum[0] += (double)l;
+  }
+}
+
+static size_t fc_tail_train_lds(int W, int H) {
+  return (size_t)(W * W + W + H * W + H + TAIL_RB * (3 * (W + 1) + H + 1) + 256) * sizeof(float);
+}
+extern "C" size_t stemgnn_fc_tail_train_scratch_floats(int B, int N, int W, int H) {
+  return (size_t)((B * N + TAIL_RB - 1) / TAIL_RB) * (W * W + W + H * W + H + 1);
+}
+extern "C" int stemgnn_fc_tail_train(const float* fsum, const float* target, const float* w0, const float* b0, const float* w2,
+                                     const float* b2, int B, int N, int W, int H, float* scratch, float* forecast,
+                                     float* loss, double* loss_accum, float* dfsum, float* dw0, float* db0, float* dw2,
+                                     float* db2, void* stream) {
+  if (!fsum || !target || !w0 || !b0 || !w2 || !b2 || !scratch || !loss || !dfsum || !dw0 || !db0 || !dw2 || !db2 ||
+      B <= 0 || N <= 0 || !stemgnn_fc_tail_supported(W, H) || fc_tail_train_lds(W, H) > 150 * 1024)
+    return SG_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const int nacc = W * W + W + H * W + H;
+  const int nblocks = (B * N + TAIL_RB - 1) / TAIL_RB;
+  const size_t lds = fc_tail_train_lds(W, H);
+  static bool attr_done = false;
+  if (!attr_done && lds > 64 * 1024) {
+    SG_TRY(hipFuncSetAttribute((const void*)sg_fc_tail_train_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(sg_fc_tail_train_kernel, dim3(nblocks), dim3(256), lds, st, fsum, target, w0, b0, w2, b2, B, N, W, H,
+                     forecast, dfsum, scratch);
+  SG_TRY(hipGetLastError());
+  hipLaunchKernelGGL(sg_fc_tail_train_reduce_kernel, dim3((nacc + 1 + 63) / 64), dim3(256), 0, st, scratch, nblocks, W, H,
+                     1.f / ((float)B * (float)H * (float)N), dw0, db0, dw2, db2, loss, loss_accum);
+  SG_TRY(hipGetLastError());
+  return 0;
+}
+
 // ---- fused RMSprop over flat buffers ------------------------------------------------------------------------------
 // torch.optim.RMSprop(momentum=0, centered=False, weight_decay=0):  sq = alpha*sq + (1-alpha)*g*g ;
 // p -= lr * g / (sqrt(sq) + eps).  lr is read from device memory so an LR scheduler can change it under graph replay.

@@ -73,6 +73,7 @@ class TrainStep:
         self.loss = torch.zeros((), device=dev)
         self.loss_sum = torch.zeros((), device=dev, dtype=torch.float64)
         self._one = torch.ones((), device=dev)
+        self.fuse_tail = hasattr(model, "loss") and os.environ.get("STEMGNN_FUSE_TAIL", "1") == "1"
         self.want_graph = bool(graph) and self.fused
         self.group = group
         if self.fused:
@@ -97,10 +98,14 @@ class TrainStep:
                 self.bucket.zero()
             else:
                 self.model.zero_grad()                                  # handler.py:160
-        forecast, _ = self.model(x)                                     # :161
-        # :162 -- the loss lands in the static scalar and is added to the epoch sum inside the reduction kernel
-        # (:166 without the per-step host sync or extra launches)
-        loss = ops.mse_loss(forecast, y, self.loss.detach(), self.loss_sum)   # fresh alias: no history chaining
+        # :161-162 -- forward + loss; the loss lands in the static scalar and is added to the epoch sum inside the
+        # reduction kernel (:166 without the per-step host sync or extra launches).  Model.loss fuses the fc tail, the
+        # MSE and both their backwards (it is this step that promises the upstream gradient of 1 below)
+        if self.fuse_tail:
+            loss = self.model.loss(x, y, self.loss.detach(), self.loss_sum, unit_grad=True)
+        else:
+            forecast, _ = self.model(x)
+            loss = ops.mse_loss(forecast, y, self.loss.detach(), self.loss_sum)   # fresh alias: no history chaining
         torch.autograd.backward(loss, grad_tensors=(self._one,))        # :164 (pre-allocated d(loss) = 1)
         return self.loss
 

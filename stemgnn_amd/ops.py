@@ -287,6 +287,60 @@ class FcTail(torch.autograd.Function):
         return dfsum, dw0, db0, dw2, db2, None
 
 
+class FcTailMse(torch.autograd.Function):
+    """Training tail as one node: fc tail (reference models/base_model.py:175-179) + nn.MSELoss(reduction='mean')
+    (models/handler.py:140,162) + both backwards, two launches (``stemgnn_fc_tail_train``).  forward returns the loss
+    and already holds d(loss)/d(fsum) and the fc parameter gradients for an upstream gradient of 1 (``loss.backward()``,
+    handler.py:164); backward hands them out (scaled by the upstream gradient unless ``unit_grad``).
+    (fsum [B,N,W], target [B,H,N], fc.0.weight, fc.0.bias, fc.2.weight, fc.2.bias) -> loss []."""
+
+    @staticmethod
+    def forward(ctx, fsum, target, w0, b0, w2, b2, state=None, loss_out=None, accum=None, unit_grad=False):
+        lib = _lib.load()
+        ctx.state = _state(state)
+        _require_gpu(fsum, "fsum")
+        _require_gpu(target, "target")
+        fsum, target = fsum.contiguous(), target.contiguous()
+        B, N, W = fsum.shape
+        H = w2.shape[0]
+        if tuple(target.shape) != (B, H, N):
+            raise _lib.StemGNNHipError(f"target must be [B,H,N]=({B},{H},{N}), got {tuple(target.shape)}")
+        dev, f32 = fsum.device, torch.float32
+        prm = (w0, b0, w2, b2)
+        w0c, b0c, w2c, b2c = (t.contiguous() for t in prm)
+        direct = ctx.state.direct and all(p.grad is not None and p.grad.is_contiguous() for p in prm)
+        grads = [p.grad for p in prm] if direct else [torch.empty_like(p) for p in prm]
+        dfsum = torch.empty_like(fsum)
+        loss = loss_out if loss_out is not None else torch.empty((), device=dev, dtype=f32)
+        if accum is not None and (accum.dtype != torch.float64 or accum.device != dev):
+            raise _lib.StemGNNHipError("accum must be a float64 scalar on the forecast's device")
+        scratch = torch.empty(lib.stemgnn_fc_tail_train_scratch_floats(B, N, W, H), device=dev, dtype=f32)
+        _lib.check(lib.stemgnn_fc_tail_train(
+            fsum.data_ptr(), target.data_ptr(), w0c.data_ptr(), b0c.data_ptr(), w2c.data_ptr(), b2c.data_ptr(), B, N, W, H,
+            scratch.data_ptr(), None, loss.data_ptr(), accum.data_ptr() if accum is not None else None, dfsum.data_ptr(),
+            grads[0].data_ptr(), grads[1].data_ptr(), grads[2].data_ptr(), grads[3].data_ptr(), _stream()), "fc_tail_train")
+        ctx.direct, ctx.unit_grad = direct, bool(unit_grad)
+        ctx.held = (dfsum, None if direct else grads)
+        ctx.set_materialize_grads(False)
+        if loss_out is not None:
+            ctx.mark_dirty(loss_out)
+        return loss
+
+    @staticmethod
+    def backward(ctx, grad_loss):
+        dfsum, grads = ctx.held
+        ctx.held = None
+        if not ctx.unit_grad:
+            dfsum = dfsum * grad_loss
+            if grads is not None:
+                grads = [g * grad_loss for g in grads]
+            elif ctx.direct:                      # gradients already sit in p.grad for an upstream gradient of 1
+                raise _lib.StemGNNHipError("FcTailMse in direct-gradient mode needs unit_grad=True (loss.backward())")
+        if grads is None:
+            return dfsum, None, None, None, None, None, None, None, None, None
+        return dfsum, None, grads[0], grads[1], grads[2], grads[3], None, None, None, None
+
+
 class GluFn(torch.autograd.Function):
     """Stand-alone GLU (reference models/base_model.py:6-13): x [M,K] -> (x Wl^T + bl) * sigmoid(x Wr^T + br) [M,C].
     Inside the model the GLU is the epilogue of the fused spectral GEMMs; this composition (general fp32 GEMM entry +

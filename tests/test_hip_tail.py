@@ -6,6 +6,7 @@ import torch
 from tests.util import relerr
 
 pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
 
 
 @pytest.mark.parametrize("B,N,W,H", [(32, 228, 12, 3), (5, 33, 12, 1), (3, 50, 28, 28), (2, 7, 5, 2), (300, 3, 16, 4)])
@@ -113,3 +114,37 @@ def test_train_step_with_fused_adam_captures_a_graph_and_matches_eager():
         assert step.mode.startswith("hipgraph") == graph, step.mode
         outs.append(opt.flat_p.clone())
     assert relerr(outs[0], outs[1]) < 1e-6
+
+
+@pytest.mark.parametrize("B,N,W,H", [(32, 228, 12, 3), (5, 33, 12, 1), (3, 50, 8, 4), (16, 64, 48, 12)])
+def test_fused_train_tail_matches_separate_stages(B, N, W, H):
+    """stemgnn_fc_tail_train (fc fwd + MSE + both backwards, 2 launches) == FcTail -> MSELoss -> backward (5 launches):
+    loss, d(loss)/d(fsum) and the four fc gradients, also with a non-unit upstream gradient."""
+    from stemgnn_amd import ops
+    g = torch.Generator().manual_seed(B * 1000 + N)
+    fsum = torch.randn(B, N, W, generator=g).to(DEV)
+    y = torch.randn(B, H, N, generator=g).to(DEV)
+    prm = [torch.randn(W, W, generator=g).to(DEV) * 0.3, torch.randn(W, generator=g).to(DEV) * 0.1,
+           torch.randn(H, W, generator=g).to(DEV) * 0.3, torch.randn(H, generator=g).to(DEV) * 0.1]
+
+    def run(fused, scale):
+        f = fsum.clone().requires_grad_(True)
+        ps = [p.clone().requires_grad_(True) for p in prm]
+        if fused:
+            loss = ops.FcTailMse.apply(f, y, *ps)
+        else:
+            loss = ops.mse_loss(ops.FcTail.apply(f, *ps), y)
+        (scale * loss).backward()
+        return loss.detach(), f.grad, [p.grad for p in ps]
+
+    for scale in (1.0, 2.5):
+        l0, df0, g0 = run(False, scale)
+        l1, df1, g1 = run(True, scale)
+        assert abs(float(l0) - float(l1)) <= 2e-6 * abs(float(l0))
+        assert float((df0 - df1).abs().max()) <= 2e-6 * float(df0.abs().max())
+        for a, b in zip(g0, g1):
+            assert float((a - b).abs().max()) <= 5e-6 * max(float(a.abs().max()), 1e-6)
+    acc = torch.zeros((), device=DEV, dtype=torch.float64)
+    out = torch.zeros((), device=DEV)
+    l2 = ops.FcTailMse.apply(fsum, y, *prm, None, out, acc)
+    assert float(out) == float(l2) and abs(float(acc) - float(l2)) < 1e-12
