@@ -37,7 +37,7 @@ OTHER_CONFIGS = [
     ("configs[4] N=2048 W=48 H=12, global batch 128 on 8 GPUs -> per-GPU shard 16", dict(N=2048, W=48, H=12, multi=5, B=16)),
 ]
 FP32_MFMA_PEAK_TFLOPS = 157.3                          # MI355X_MICROARCH.md: v_mfma_f32_* dense peak
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")   # HBM bytes per launch from the PMC passes
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")   # HBM bytes / MFMA utilisation per family from the PMC passes
 
 
 def _self_launch(args):
@@ -100,9 +100,10 @@ def time_gemm_families(cfg, iters=20):
         return run
 
     fams = {
-        "glu_fwd": (fwd, 3, "sg_gemm2<GluFwdEpi> (spectral GLU forward, 3 launches per block, both branches per launch)"),
-        "glu_dgrad": (bwd(1), 3, "sg_gemm2<GluDpreEpi> x2 + sg_gemm_f32<GluDgrad0Op> (GLU data gradients)"),
-        "glu_wgrad": (bwd(2), 3, "sg_gemm2 weight-gradient GEMMs (GLU dW, reduction over the M = B*N rows)"),
+        "glu_fwd": (fwd, 3, "sg_gemm2<GluFwdEpi> (spectral GLU forward: 3 launches per block, both branches per launch)"),
+        "glu_dgrad": (bwd(1), 3, "sg_gemm2<GluDpreEpi> x2 + sg_gemm_f32<GluDgrad0Op> (GLU data gradients: 3 launches per block)"),
+        "glu_wgrad": (bwd(2), 1, "sg_wgrad_kernel (all six GLU weight-gradient products of a block in ONE launch: direct-to-LDS "
+                                 "ring, in-kernel fixed-order split reduction -- no reduce kernel)"),
     }
     out = {}
     for name, (fn, launches, kernel) in fams.items():
@@ -128,7 +129,7 @@ def roofline_objects(cfg):
             traffic = json.load(f)
     rows = {}
     for name, t in fams.items():
-        s = t["us_per_call"] * 1e-6
+        s = t["us_per_call"] * 1e-6                      # one call = the family's work for ONE block (3 layers x 2 branches)
         launches = t["launches_per_call"]
         rows[name] = {
             "kernel": t["kernel"], "bound": "mfma", "achieved": alg / s / 1e12, "achieved_executed": exe / s / 1e12,
@@ -136,12 +137,15 @@ def roofline_objects(cfg):
             "frac_executed": exe / s / 1e12 / FP32_MFMA_PEAK_TFLOPS, "avg_launch_us": t["us_per_call"] / launches,
             "launches_per_step": launches * t["calls_per_step"], "sum_us_per_step": t["us_per_call"] * t["calls_per_step"],
             "flops_algorithmic": alg / launches, "flops_executed": exe / launches,
-            "traffic": traffic.get("kernels", {}).get(name), "traffic_source": traffic.get("source"),
+            "traffic": traffic.get("kernels", {}).get(name),      # HBM bytes per launch (PMC, average over the family)
+            "mfma_util": traffic.get("mfma_util", {}).get(name),
+            "traffic_source": traffic.get("source"),
         }
     dominant = max(rows, key=lambda k: rows[k]["sum_us_per_step"])
     main = dict(rows[dominant])
     main["family"] = dominant
-    main["why"] = "largest summed GPU time per step among the MFMA GEMM families (timed live, HIP events)"
+    main["why"] = ("largest summed GPU time per step among the MFMA GEMM families (each timed live in isolation, HIP events "
+                   "on the launch stream; frac = algorithmic FLOPs / time / fp32 MFMA peak, incl. every reduction it needs)")
     return main, rows
 
 

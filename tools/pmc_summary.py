@@ -79,5 +79,6 @@ out = {"source": "rocprofv3 --pmc passes (FETCH_SIZE x 2 gfx950 correction + WRI
        "mfma_util": {f: util(p) for f, p in FAMS.items()},
        "unit": "bytes per launch (average over the launches of the family)",
        "kernels": {f: fam(p) for f, p in FAMS.items()}}
+# "kernels" = bytes per LAUNCH averaged over the family's launches as profiled; bench.py rescales to its own launch count
 json.dump(out, open(OUT_JSON, "w"), indent=1)
 print("\n" + json.dumps({"traffic": out["kernels"], "mfma_util": out["mfma_util"]}))
