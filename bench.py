@@ -120,6 +120,44 @@ def time_gemm_families(cfg, iters=20):
     return out
 
 
+def time_gru(cfg, iters=5):
+    """The GRU front alone (ops.GruFront through the C ABI, HIP events on the launch stream): the recurrence is a chain of
+    N dependent steps, so it is bound by the per-step exchange latency, not by FLOPs or bytes -- reported as microseconds per
+    recurrence step, the figure that says what bounds the large configurations (reference models/base_model.py:137)."""
+    import torch
+    from stemgnn_amd import ops
+
+    B, N, W = cfg["B"], cfg["N"], cfg["W"]
+    dev = torch.device("cuda")
+    gru = torch.nn.GRU(W, N).to(dev)
+    ps = [gru.weight_ih_l0, gru.weight_hh_l0, gru.bias_ih_l0, gru.bias_hh_l0]
+    x = torch.randn(B, W, N, device=dev)
+    dh = torch.randn(N, B, N, device=dev) * 0.01
+
+    def fwd_bwd():
+        for p in ps:
+            p.grad = None
+        ops.GruFront.apply(x, *ps).backward(dh)
+    fwd_bwd()
+    st = torch.cuda.current_stream()
+    e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    with torch.no_grad():
+        e[0].record(st)
+        for _ in range(iters):
+            ops.GruFront.apply(x, *ps)
+        e[1].record(st)
+    for _ in range(iters):
+        fwd_bwd()
+    e[2].record(st)
+    e[2].synchronize()
+    ops.check_gru_status(dev)
+    f = e[0].elapsed_time(e[1]) * 1e3 / iters
+    fb = e[1].elapsed_time(e[2]) * 1e3 / iters
+    return {"bound": "latency (N dependent recurrence steps, one cross-workgroup exchange each)", "recurrence_steps": N,
+            "fwd_us": f, "bwd_incl_weight_grads_us": fb - f, "fwd_us_per_recurrence_step": f / N,
+            "bwd_us_per_recurrence_step": (fb - f) / N}
+
+
 def roofline_objects(cfg):
     fams = time_gemm_families(cfg)
     alg, exe = glu_flops(cfg)
@@ -334,6 +372,8 @@ def main():
     if rank == 0:
         if not args.no_roofline:
             out["roofline"], out["roofline_families"] = roofline_objects(cfg)
+            out["gru"] = time_gru(cfg)
+            out["gru"]["share_of_step"] = (out["gru"]["fwd_us"] + out["gru"]["bwd_incl_weight_grads_us"]) / (out["ms_per_step"] * 1e3)
         if world == 1 and not launched and not args.no_other_configs:
             others = []
             for name, c in OTHER_CONFIGS:
@@ -342,9 +382,20 @@ def main():
                     big = c["N"] >= 1024
                     k, w = (5, 2) if big else (30, 5)
                     el, md, _ = run_training(c, k, w, dev, 1, 0, graph=not args.no_graph, T=4096 if big else 12672)
-                    others.append({"config": name, "workload": workload_name(c), "ms_per_step": el / k * 1e3,
-                                   "value": c["B"] * c["H"] / (el / k), "unit": "forecast-steps/s", "steps": k,
-                                   "warmup": w, "n_gpus": 1, "launch": md})
+                    row = {"config": name, "workload": workload_name(c), "ms_per_step": el / k * 1e3,
+                           "value": c["B"] * c["H"] / (el / k), "unit": "forecast-steps/s", "steps": k,
+                           "warmup": w, "n_gpus": 1, "launch": md}
+                    if not args.no_roofline:        # what bounds this shape: the GEMM families' fractions + the GRU's latency floor
+                        torch.cuda.empty_cache()
+                        _, fams = roofline_objects(c)
+                        row["roofline_families"] = {
+                            f: {q: v[q] for q in ("frac", "frac_executed", "achieved", "avg_launch_us", "sum_us_per_step",
+                                                  "launches_per_step")} for f, v in fams.items()}
+                        row["gru"] = time_gru(c)
+                        row["gru"]["share_of_step"] = ((row["gru"]["fwd_us"] + row["gru"]["bwd_incl_weight_grads_us"])
+                                                       / (row["ms_per_step"] * 1e3))
+                        row["glu_gemm_share_of_step"] = sum(v["sum_us_per_step"] for v in fams.values()) / (row["ms_per_step"] * 1e3)
+                    others.append(row)
                 except Exception as e:  # noqa: BLE001 -- a failing side line must not lose the headline
                     others.append({"config": name, "error": f"{type(e).__name__}: {e}"})
             out["other_configs"] = others

@@ -87,15 +87,20 @@ int stemgnn_cheb_bwd(const float* mul_L, const float* dmul_L, float* dL, float* 
  *   nsweeps <= 0 : direct solver, 7 launches, 3 <= N <= 2048: Householder tridiagonalisation as ONE persistent cluster
  *                  kernel (pending rank-2 update fused with the next symmetric mat-vec, one grid barrier per column) ->
  *                  fp64 multisection (Sturm counts, 16 lanes per eigenvalue) -> fp64 inverse iteration (pivoted
- *                  tridiagonal LU) -> reflector back-transform -> rebuild on the MFMA GEMM core;
+ *                  tridiagonal LU) -> cluster pass (eigenvalues closer than 1e-9 |T|, repeated ones included, are
+ *                  re-orthogonalised and re-iterated as LAPACK dstein does) -> reflector back-transform -> rebuild on
+ *                  the MFMA GEMM core;
  *   nsweeps  > 0 : parallel one-sided Jacobi (one launch per tournament round, fp64 rotation parameters), one
  *                  Newton-Schulz re-orthogonalisation and Rayleigh quotients on MFMA.
  * lam [N] (ascending for the direct solver); U [N,N] with the eigenvectors in ROWS; scratch:
  * stemgnn_eigh_scratch_floats(N) (16-byte aligned).  stemgnn_eigh_status(): host-synchronous read of the solver's
- * device status word (0 ok, 2 = a grid-barrier wait of the tridiagonalisation timed out). */
+ * status word of the CURRENT device (0 ok, 2 = a grid-barrier wait of the tridiagonalisation timed out, 3 = a cluster
+ * re-solve broke down).  stemgnn_eigh_cluster_fixes(): host-synchronous read-and-clear of the number of eigenvectors the
+ * cluster pass re-orthogonalised on the current device (diagnostic; 0 for a spectrum without clusters). */
 size_t stemgnn_eigh_scratch_floats(int N);
 int stemgnn_eigh_fwd(float* mul_L, float* lam, float* U, float* scratch, int N, int nsweeps, void* stream);
 int stemgnn_eigh_status(void);
+int stemgnn_eigh_cluster_fixes(void);
 
 /* ---- split-bf16 GLU GEMM (experiment; BASELINE configs[1] "bf16/fp32", SURVEY 8b `_bf16` entry points) -----------
  * C[M,N] = A[M,K] B[N,K]^T -- the shape of one GLU layer (models/base_model.py:12-13, x W^T) -- with every fp32 operand

@@ -35,6 +35,7 @@ SIGNATURES = {
     "stemgnn_eigh_scratch_floats": (c_size_t, [c_int]),
     "stemgnn_eigh_fwd": (c_int, [_P, _P, _P, _P, c_int, c_int, _P]),
     "stemgnn_eigh_status": (c_int, []),
+    "stemgnn_eigh_cluster_fixes": (c_int, []),
     "stemgnn_split_planes_floats": (c_size_t, [c_int, c_int, c_int]),
     "stemgnn_split_weights_bf16": (c_int, [_P, c_int, c_int, c_int, _P, _P]),
     "stemgnn_glu_gemm_bf16": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P]),

@@ -622,6 +622,121 @@ __global__ __launch_bounds__(64) void eig_invit_kernel(const float* __restrict__
   }
 }
 
+// Clusters (what LAPACK dstein does inside its iteration): independent inverse iteration gives vectors that are orthogonal
+// to ~eps64 |T| / gap, so eigenvalues closer than 1e-9 |T| -- exactly repeated ones in particular (constant or duplicated
+// series, a split tridiagonal) -- would come out parallel and U rank-deficient.  One wave per eigenvalue looks at the gaps
+// either side; the wave of a cluster's FIRST eigenvalue walks the cluster: vector i is orthogonalised (modified
+// Gram-Schmidt, fp64 dots) against the cluster's earlier vectors, restarted from a hashed pseudo-random vector when nothing
+// independent is left, and put through two more inverse-iteration solves (the pivoted LU of T - lam_i I that
+// eig_invit_kernel left in `work`), each followed by the same orthogonalisation.  Any orthonormal basis of the cluster's
+// invariant subspace serves the rebuild (f(lam) is constant across the cluster to 1e-9).  Without clusters every wave
+// returns after two loads.  The recurrences of a solve run on lane 0 out of LDS, operands staged 64 rows at a time.
+__device__ __forceinline__ double cf_hash(unsigned a, unsigned b) {
+  unsigned h = a * 0x9E3779B1u ^ (b + 0x7F4A7C15u) * 0x85EBCA77u;
+  h ^= h >> 15; h *= 0xC2B2AE3Du; h ^= h >> 13; h *= 0x27D4EB2Fu; h ^= h >> 16;
+  return (double)(h & 0xFFFFFFu) * (2.0 / 16777216.0) - 1.0;
+}
+__global__ __launch_bounds__(64) void eig_cluster_fix_kernel(const double* __restrict__ lam64, const double* __restrict__ aux,
+                                                             int N, const double* __restrict__ work, float* __restrict__ Z,
+                                                             int* __restrict__ status) {
+  const int j0 = blockIdx.x, lane = threadIdx.x;
+  const double tol = 1e-9 * fmax(aux[0], 1e-300);
+  const bool prev_close = j0 > 0 && lam64[j0] - lam64[j0 - 1] < tol;
+  const bool next_close = j0 + 1 < N && lam64[j0 + 1] - lam64[j0] < tol;
+  if (prev_close || !next_close) return;
+  extern __shared__ __attribute__((aligned(16))) double cf_sm[];
+  double* xs = cf_sm;                    // [N]
+  double* op = cf_sm + N;                // [4][64]
+  unsigned char* pv = reinterpret_cast<unsigned char*>(op + 4 * 64);   // [64]
+  const size_t NN = (size_t)N * N;
+  int fixed = 0;
+  for (int i = j0 + 1; i < N && lam64[i] - lam64[i - 1] < tol; ++i, ++fixed) {
+    const double* FL = work + i;
+    const double* RD = work + NN + i;
+    const double* DU = work + 2 * NN + i;
+    const double* DU2 = work + 3 * NN + i;
+    const unsigned char* PV = reinterpret_cast<const unsigned char*>(work + 5 * NN) + i;
+    for (int r = lane; r < N; r += 64) xs[r] = Z[(size_t)i * N + r];
+    __syncthreads();
+    for (int round = 0; round < 3; ++round) {
+      for (int attempt = 0; attempt < 2; ++attempt) {
+        for (int p = j0; p < i; ++p) {                       // modified Gram-Schmidt against the cluster's earlier vectors
+          const float* zp = Z + (size_t)p * N;
+          double dot = 0.0;
+          for (int r = lane; r < N; r += 64) dot += xs[r] * (double)zp[r];
+          dot = eig_wave_sum(dot);
+          for (int r = lane; r < N; r += 64) xs[r] -= dot * (double)zp[r];
+        }
+        double nn = 0.0;
+        for (int r = lane; r < N; r += 64) nn += xs[r] * xs[r];
+        nn = sqrt(eig_wave_sum(nn));
+        if (round == 0 && attempt == 0 && !(nn > 1e-2)) {    // nothing independent left: restart from a pseudo-random vector
+          for (int r = lane; r < N; r += 64) xs[r] = cf_hash((unsigned)i, (unsigned)r);
+          continue;
+        }
+        const double inv = nn > 0.0 ? 1.0 / nn : 0.0;
+        for (int r = lane; r < N; r += 64) xs[r] *= inv;
+        break;
+      }
+      __syncthreads();
+      if (round == 2) break;
+      // one inverse-iteration solve (T - lam_i I) x' = x with the stored LU: forward substitution, then back substitution
+      double carry = xs[0];
+      for (int i0 = 0; i0 + 1 < N; i0 += 64) {
+        const int row = i0 + lane < N - 1 ? i0 + lane : N - 2;
+        op[lane] = FL[(size_t)row * N];
+        pv[lane] = PV[(size_t)row * N];
+        __syncthreads();
+        if (lane == 0) {
+          const int cnt = N - 1 - i0 < 64 ? N - 1 - i0 : 64;
+          for (int u = 0; u < cnt; ++u) {
+            const double b1 = xs[i0 + u + 1], f = op[u];
+            const bool sw = pv[u] != 0;
+            xs[i0 + u] = sw ? b1 : carry;
+            carry = sw ? carry - f * b1 : b1 - f * carry;
+          }
+        }
+        __syncthreads();
+      }
+      if (lane == 0) xs[N - 1] = carry;
+      __syncthreads();
+      double x1 = 0.0, x2 = 0.0;
+      for (int i0 = N - 1; i0 >= 0; i0 -= 64) {
+        const int row = i0 - lane >= 0 ? i0 - lane : 0;
+        op[lane] = DU[(size_t)row * N];
+        op[64 + lane] = DU2[(size_t)row * N];
+        op[128 + lane] = RD[(size_t)row * N];
+        __syncthreads();
+        if (lane == 0) {
+          const int cnt = i0 + 1 < 64 ? i0 + 1 : 64;
+          for (int u = 0; u < cnt; ++u) {
+            const double xi = (xs[i0 - u] - op[u] * x1 - op[64 + u] * x2) * op[128 + u];
+            xs[i0 - u] = xi;
+            x2 = x1;
+            x1 = xi;
+          }
+        }
+        __syncthreads();
+      }
+      double amax = 0.0;                                     // keep the magnitudes in range for the next solve
+      for (int r = lane; r < N; r += 64) amax = fmax(amax, fabs(xs[r]));
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) amax = fmax(amax, __shfl_xor(amax, o, 64));
+      if (!(amax > 0.0) || !(amax < 1e300)) {                // a broken solve must not pass silently
+        if (lane == 0) atomicMax(status, 3);
+        amax = 1.0;
+      }
+      const double sc = 1.0 / amax;
+      for (int r = lane; r < N; r += 64) xs[r] *= sc;
+      __syncthreads();
+    }
+    for (int r = lane; r < N; r += 64) Z[(size_t)i * N + r] = (float)xs[r];
+    __threadfence();
+    __syncthreads();
+  }
+  if (lane == 0 && fixed > 0) atomicAdd(status + 1, fixed);   // diagnostic: vectors re-orthogonalised since the last read
+}
+
 // U[e][:] = H_0 H_1 ... H_{N-3} z_e : reflectors applied from the last to the first.  Workgroup = 4 waves x JW = 4
 // eigenvectors held in registers (NC chunks of 64 entries per lane); each reflector is staged once per workgroup in LDS
 // (double buffered: one barrier per reflector).
@@ -723,6 +838,9 @@ static int eig_direct(float* mul_L, float* lam, float* U, float* scratch, int N,
   SG_TRY(hipGetLastError());
   hipLaunchKernelGGL(eig_invit_kernel, dim3((N + 63) / 64), dim3(64), 0, st, dvec, evec, lam64, aux, N, work, Z);
   SG_TRY(hipGetLastError());
+  hipLaunchKernelGGL(eig_cluster_fix_kernel, dim3(N), dim3(64), ((size_t)N + 4 * 64 + 8) * sizeof(double), st, lam64, aux, N, work,
+                     Z, status);
+  SG_TRY(hipGetLastError());
   const dim3 bgrid((N + 15) / 16);
   if (N <= 256) hipLaunchKernelGGL(eig_backtransform_kernel<4>, bgrid, dim3(256), 2 * 64 * 4 * sizeof(float), st, Z, V, tauv, N, U);
   else if (N <= 1024) hipLaunchKernelGGL(eig_backtransform_kernel<16>, bgrid, dim3(256), 2 * 64 * 16 * sizeof(float), st, Z, V, tauv, N, U);
@@ -735,18 +853,29 @@ static int eig_direct(float* mul_L, float* lam, float* U, float* scratch, int N,
 }
 
 
-static int* eig_status_word() {      // device int set to 2 if a grid-barrier spin of the tridiagonalisation timed out
-  static int* w = nullptr;
-  if (!w) {
-    if (hipMalloc((void**)&w, sizeof(int)) != hipSuccess) return nullptr;
-    (void)hipMemset(w, 0, sizeof(int));
+// Per-device status words: [0] set to 2 if a grid-barrier spin of the tridiagonalisation timed out, to 3 if a cluster
+// re-solve broke down; [1] counts the eigenvectors the cluster pass re-orthogonalised (diagnostic).
+static int* eig_status_word() {
+  static int* w[64] = {nullptr};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  if (!w[dev]) {
+    if (hipMalloc((void**)&w[dev], 2 * sizeof(int)) != hipSuccess) return nullptr;
+    (void)hipMemset(w[dev], 0, 2 * sizeof(int));
   }
-  return w;
+  return w[dev];
 }
 extern "C" int stemgnn_eigh_status(void) {
   int* w = eig_status_word();
   int v = -1;
   if (!w || hipMemcpy(&v, w, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  return v;
+}
+extern "C" int stemgnn_eigh_cluster_fixes(void) {      // reads AND clears the count of re-orthogonalised eigenvectors
+  int* w = eig_status_word();
+  int v = -1;
+  if (!w || hipMemcpy(&v, w + 1, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  (void)hipMemset(w + 1, 0, sizeof(int));
   return v;
 }
 

@@ -200,6 +200,77 @@ def test_eigh_stage_reproduces_chebyshev_basis(N, sweeps):
     assert float((torch.sort(lam.cpu().double()).values - ev).abs().max()) < 1e-5
 
 
+def _degenerate(kind, N):
+    g = torch.Generator().manual_seed(3)
+    if kind == "rank_one":            # I - 11^T/N: eigenvalue 1 with multiplicity N - 1 (constant series give this Laplacian)
+        return torch.eye(N) - torch.ones(N, N) / N
+    if kind == "twin_blocks":         # two identical diagonal blocks: EVERY eigenvalue is double (duplicated series)
+        a = torch.randn(N // 2, N // 2, generator=g) * 0.2
+        a = (a + a.T) / 2
+        z = torch.zeros_like(a)
+        return torch.cat([torch.cat([a, z], 1), torch.cat([z, a], 1)], 0)
+    if kind == "tight":               # distinct eigenvalues 1e-12 apart inside groups of five (fp64 cannot separate them)
+        q, _ = torch.linalg.qr(torch.randn(N, N, generator=g, dtype=torch.float64))
+        lam = torch.linspace(-1, 1, N // 5, dtype=torch.float64).repeat_interleave(5)[:N]
+        lam = lam + 1e-12 * torch.arange(N, dtype=torch.float64)
+        return ((q * lam) @ q.T).float()
+    if kind == "split_pairs":         # already tridiagonal and split: T = L exactly, two eigenvalues of multiplicity N / 2
+        return torch.kron(torch.eye(N // 2), torch.tensor([[0.3, 0.2], [0.2, 0.3]]))
+    raise ValueError(kind)
+
+
+@pytest.mark.parametrize("kind,N", [("split_pairs", 64), ("split_pairs", 300), ("rank_one", 96), ("twin_blocks", 128),
+                                    ("tight", 100), ("twin_blocks", 512)])
+def test_eigh_repeated_eigenvalues_keep_an_orthonormal_basis(kind, N):
+    """Exactly repeated / numerically coincident eigenvalues: independent inverse iteration would return
+    parallel vectors and a rank-deficient U; the cluster pass must hand back an orthonormal basis so that the rebuilt
+    slots are still the polynomials of L."""
+    from stemgnn_amd import _lib, ops
+
+    lib = _lib.load()
+    L = _degenerate(kind, N)
+    L = ((L + L.T) / 2).contiguous()
+    mul_L = torch.zeros(4, N, N, device="cuda")
+    mul_L[1] = L.cuda()
+    lam = torch.empty(N, device="cuda")
+    U = torch.empty(N, N, device="cuda")
+    scratch = torch.empty(lib.stemgnn_eigh_scratch_floats(N), device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    lib.stemgnn_eigh_cluster_fixes()                                  # clear the diagnostic counter
+    assert lib.stemgnn_eigh_fwd(mul_L.data_ptr(), lam.data_ptr(), U.data_ptr(), scratch.data_ptr(), N, 0, st) == 0
+    torch.cuda.synchronize()
+    ops.check_eigh_status()
+    fixes = lib.stemgnn_eigh_cluster_fixes()
+    print(f"{kind} N={N}: {fixes} eigenvectors re-orthogonalised by the cluster pass")
+    if kind == "split_pairs":         # every reflector is the identity here, so the clusters are exact by construction
+        assert fixes == N - 2, "the cluster pass did not run on a clustered spectrum"
+    Ud = U.cpu().double()
+    assert float((Ud @ Ud.T - torch.eye(N, dtype=torch.float64)).abs().max()) < 2e-5
+    Ld = L.double()
+    assert relerr((Ud.T * lam.cpu().double()) @ Ud, Ld) < 2e-5
+    ref2 = 2 * Ld @ Ld
+    ref3 = 2 * Ld @ ref2 - Ld
+    assert relerr(mul_L[2], ref2) < TOL and relerr(mul_L[3], ref3) < TOL
+    ev = torch.linalg.eigvalsh(Ld)
+    assert float((torch.sort(lam.cpu().double()).values - ev).abs().max()) < 1e-5
+
+
+def test_eigh_without_clusters_skips_the_cluster_pass():
+    from stemgnn_amd import _lib
+
+    lib = _lib.load()
+    N = 140
+    mul_L = torch.zeros(4, N, N, device="cuda")
+    mul_L[1] = _laplacian(N).cuda()
+    lam, U = torch.empty(N, device="cuda"), torch.empty(N, N, device="cuda")
+    scratch = torch.empty(lib.stemgnn_eigh_scratch_floats(N), device="cuda")
+    lib.stemgnn_eigh_cluster_fixes()
+    assert lib.stemgnn_eigh_fwd(mul_L.data_ptr(), lam.data_ptr(), U.data_ptr(), scratch.data_ptr(), N, 0,
+                                torch.cuda.current_stream().cuda_stream) == 0
+    torch.cuda.synchronize()
+    assert lib.stemgnn_eigh_cluster_fixes() == 0
+
+
 def test_model_eig_route_matches_oracle(monkeypatch):
     from stemgnn_amd import Model
 

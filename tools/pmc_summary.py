@@ -2,8 +2,13 @@
 GRBM_GUI_ACTIVE -- kernel-trace only, separate runs) of bench.py into per-kernel HBM traffic per launch and MFMA
 utilisation: markdown table on stdout + a JSON (profiles/rNN_pmc_traffic.json, read by bench.py).
 
-MFMA utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 256 CUs x 4 SIMDs): the share of the chip's matrix-pipe
-cycles (per SIMD) that were busy while the kernel ran (the gfx94x MfmaUtil formula; ROCm 7.2 has no gfx950 section).
+MFMA utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (dispatch duration x 2.4 GHz x 256 CUs x 4 SIMDs): the share of the chip's
+matrix-pipe cycles (per SIMD) that were busy while the kernel ran.  SQ_VALU_MFMA_BUSY_CYCLES is an exact instruction census
+(64 cycles per v_mfma_f32_32x32x2_f32, summed over every SIMD: GLU forward = 496 128 MFMAs per launch x 64 = the counter
+to the digit).  The denominator uses the dispatch's own Start/End timestamps of the counter pass: GRBM_GUI_ACTIVE on this
+stack is the SUM over the 8 XCDs and carries ~8 us of per-dispatch set-up (GUI / 8 / duration -> 2.5 cycles/ns for a 100 us
+kernel, 4.9 for a 7 us one), so the gfx94x MfmaUtil formula (busy / (GUI x CUs x 4)) under-reads by 8x and more; the
+GUI-based figure (with the / 8) is printed beside it for comparison.
 
 usage: python tools/pmc_summary.py <dir FETCH_SIZE pass> <dir WRITE_SIZE pass> <dir MFMA pass | -> <out.json> [code version]
 Units / corrections exactly as /opt/skills/guides/MI355X_MICROARCH.md (HBM section) prescribes: both counters are in KB;
@@ -15,7 +20,10 @@ import sys
 from collections import defaultdict
 
 
-def collect(d, counter):
+CLOCK_GHZ = 2.4
+
+
+def collect(d, counter, duration=False):
     acc = defaultdict(lambda: [0, 0.0])
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
@@ -23,7 +31,7 @@ def collect(d, counter):
                 continue
             a = acc[r["Kernel_Name"]]
             a[0] += 1
-            a[1] += float(r["Counter_Value"])
+            a[1] += (float(r["End_Timestamp"]) - float(r["Start_Timestamp"])) if duration else float(r["Counter_Value"])
     return {k: (n, tot / n) for k, (n, tot) in acc.items()}
 
 
@@ -34,6 +42,7 @@ OUT_JSON, VERSION = sys.argv[4], (sys.argv[5] if len(sys.argv) > 5 else None)
 mfma = collect(mdir, "SQ_VALU_MFMA_BUSY_CYCLES") if mdir != "-" else {}
 gui = collect(mdir, "GRBM_GUI_ACTIVE") if mdir != "-" else {}
 sqbusy = collect(mdir, "SQ_BUSY_CYCLES") if mdir != "-" else {}
+dur = collect(mdir, "SQ_VALU_MFMA_BUSY_CYCLES", duration=True) if mdir != "-" else {}      # ns per dispatch (counter pass)
 rows = []
 for k in fetch:
     n, f = fetch[k]
@@ -53,28 +62,30 @@ def fam(pred):
 
 
 def util(pred):
-    sel = [k for k in mfma if pred(k) and k in gui and gui[k][1] > 0]
+    sel = [k for k in mfma if pred(k) and k in dur and dur[k][1] > 0]
     if not sel:
         return None
     busy = sum(mfma[k][0] * mfma[k][1] for k in sel)
-    act = sum(gui[k][0] * gui[k][1] for k in sel)
-    return busy / (act * 256 * 4)
+    cyc = sum(dur[k][0] * dur[k][1] * CLOCK_GHZ for k in sel)
+    return busy / (cyc * 256 * 4)
 
 
 if mfma:
-    print("\n| kernel | launches | MFMA_BUSY cycles / launch | GRBM_GUI_ACTIVE / launch | SQ_BUSY_CYCLES / launch | MFMA util |")
-    print("|---|---|---|---|---|---|")
+    print("\n| kernel | launches | MFMA_BUSY cycles / launch | duration us (counter pass) | GRBM_GUI_ACTIVE / launch | "
+          "MFMA util (duration x 2.4 GHz x 1024 SIMDs) | via GUI / 8 |")
+    print("|---|---|---|---|---|---|---|")
     for k in sorted(mfma, key=lambda k: -mfma[k][0] * mfma[k][1])[:20]:
         g = gui.get(k, (0, 0.0))[1]
-        print(f"| `{k[:110]}` | {mfma[k][0]} | {mfma[k][1]:.0f} | {g:.0f} | {sqbusy.get(k, (0, 0.0))[1]:.0f} | "
-              f"{(mfma[k][1] / (g * 1024) if g else 0):.3f} |")
+        dn = dur.get(k, (0, 0.0))[1]
+        print(f"| `{k[:110]}` | {mfma[k][0]} | {mfma[k][1]:.0f} | {dn / 1e3:.1f} | {g:.0f} | "
+              f"{(mfma[k][1] / (dn * CLOCK_GHZ * 1024) if dn else 0):.3f} | {(mfma[k][1] / (g / 8 * 1024) if g else 0):.3f} |")
 
 FAMS = {
     "glu_fwd": lambda k: "GluFwdEpi" in k,
     "glu_dgrad": lambda k: "GluDpreEpi" in k or "GluDgrad0Op" in k,
     "glu_wgrad": lambda k: "G2SlabEpi, false, false, true, 128" in k or "G2SlabEpi, false, false, true, 64" in k or "sg_wgrad" in k,
 }
-out = {"source": "rocprofv3 --pmc passes (FETCH_SIZE x 2 gfx950 correction + WRITE_SIZE; SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 1024))"
+out = {"source": "rocprofv3 --pmc passes (FETCH_SIZE x 2 gfx950 correction + WRITE_SIZE; SQ_VALU_MFMA_BUSY_CYCLES / (dispatch duration x 2.4 GHz x 1024 SIMDs))"
                  + (", code " + VERSION if VERSION else ""),
        "mfma_util": {f: util(p) for f, p in FAMS.items()},
        "unit": "bytes per launch (average over the launches of the family)",
