@@ -399,6 +399,25 @@ def main():
                 except Exception as e:  # noqa: BLE001 -- a failing side line must not lose the headline
                     others.append({"config": name, "error": f"{type(e).__name__}: {e}"})
             out["other_configs"] = others
+            # BASELINE.json configs[1] names "bf16/fp32": the headline above is exact fp32 (the reference's arithmetic); the same
+            # step with the GLU forward / data-gradient layers as split-bf16 products (STEMGNN_DTYPE, csrc/gemm2s.h) is
+            # reported beside it, with the model-level error each setting was tested to (tests/test_hip_splitgemm.py)
+            variants = []
+            for dt, err in (("bf16x3", "<= 4e-6 norm-relative vs the oracle (fp32 class)"),
+                            ("bf16x2", "<= 3e-5 norm-relative vs the oracle (gate: 1e-4)")):
+                os.environ["STEMGNN_DTYPE"] = dt
+                try:
+                    torch.cuda.empty_cache()
+                    el, md, _ = run_training(cfg, 60, 10, dev, 1, 0, graph=not args.no_graph)
+                    variants.append({"dtype": dt, "ms_per_step": el / 60 * 1e3, "value": cfg["B"] * cfg["H"] / (el / 60),
+                                     "unit": "forecast-steps/s", "steps": 60, "warmup": 10, "launch": md,
+                                     "arithmetic": "GLU layers 1-2 forward + d(pre-activation) products on v_mfma_f32_32x32x16_bf16, "
+                                                   "fp32 accumulation; everything else fp32", "tested_error": err})
+                except Exception as e:  # noqa: BLE001
+                    variants.append({"dtype": dt, "error": f"{type(e).__name__}: {e}"})
+                finally:
+                    os.environ.pop("STEMGNN_DTYPE", None)
+            out["dtype_variants"] = variants
         if world == 1 and not launched and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg)
         print(json.dumps(out), flush=True)

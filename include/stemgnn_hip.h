@@ -141,6 +141,9 @@ int stemgnn_colsum(const float* X, int M, int C, float* out, void* stream);
 size_t stemgnn_gru_reserve_floats(int B, int S, int Hd);
 size_t stemgnn_gru_fwd_scratch_floats(int B, int S, int Hd);
 size_t stemgnn_gru_bwd_scratch_floats(int B, int S, int Hd, int W);
+/* CUs (one workgroup each) the backward recurrence occupies for its whole run at this shape: a caller that overlaps other
+ * kernels with it on another stream sizes them for the remaining CUs. */
+int stemgnn_gru_bwd_cus(int B, int Hd);
 int stemgnn_gru_fwd(const float* x, const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh,
                     int B, int S, int Hd, int W, float* scratch, float* h_ext, float* reserve, int* status,
                     void* stream);
@@ -188,6 +191,21 @@ int stemgnn_spectral_glu_fwd(const float* packed, float* saved, int B, int N, in
  * (it is off the critical path of the backward pass); 3 = both, in order. */
 int stemgnn_spectral_glu_bwd(const float* packed, const float* saved, float* scratch, float* gradpart,
                              int nsplit, int parts, int B, int N, int W, int multi, void* stream);
+/* Split-bf16 arithmetic for the same layers (BASELINE.json configs[1] "bf16/fp32"; reference data and weights are fp32,
+ * models/base_model.py:12-13, 52-54): every fp32 operand is the exact sum of `splits` bf16 numbers (3: fp32-class
+ * products from 6 bf16 MFMAs, 2: ~2^-16 relative from 3) with fp32 accumulation on v_mfma_f32_32x32x16_bf16.
+ * stemgnn_glu_split_panels turns the packed fp32 panels of layers 1, 2 (both branches) into the bf16 plane sets the two
+ * entry points read (`split`: caller-owned, 16-byte aligned, stemgnn_glu_split_floats floats; once per step, after
+ * stemgnn_block_pack).  _fwd_split == stemgnn_spectral_glu_fwd, _dgrad_split == stemgnn_spectral_glu_bwd with parts = 1,
+ * with layers 1, 2 on the split kernel (layer 0 and its data gradient stay exact fp32: K = 3W, traffic-bound); saved
+ * activations, scratch layout and every downstream stage are unchanged.  Shapes that break the 16-byte rules of the
+ * split kernel run the fp32 kernels. */
+size_t stemgnn_glu_split_floats(int W, int multi, int splits);
+int stemgnn_glu_split_panels(const float* packed, float* split, int W, int multi, int splits, void* stream);
+int stemgnn_spectral_glu_fwd_split(const float* packed, const float* split, float* saved, int B, int N, int W, int multi,
+                                   int splits, void* stream);
+int stemgnn_spectral_glu_dgrad_split(const float* packed, const float* split, const float* saved, float* scratch,
+                                     int B, int N, int W, int multi, int splits, void* stream);
 
 /* ---- C2R iDFT + graph-conv weight + forecast / backcast heads (models/base_model.py:55-58, 65-74)
  * forecast [M,W]: written (accumulate=0) or added to (accumulate=1: result[0]+result[1], :174).

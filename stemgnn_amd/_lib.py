@@ -47,6 +47,7 @@ SIGNATURES = {
     "stemgnn_gru_reserve_floats": (c_size_t, [c_int, c_int, c_int]),
     "stemgnn_gru_fwd_scratch_floats": (c_size_t, [c_int, c_int, c_int]),
     "stemgnn_gru_bwd_scratch_floats": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "stemgnn_gru_bwd_cus": (c_int, [c_int, c_int]),
     "stemgnn_gru_fwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P]),
     "stemgnn_gru_bwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "stemgnn_fc_tail_supported": (c_int, [c_int, c_int]),
@@ -70,6 +71,10 @@ SIGNATURES = {
     "stemgnn_gft_bwd": (c_int, [_P, _P, c_long, c_long, c_long, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "stemgnn_spectral_glu_fwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
     "stemgnn_spectral_glu_bwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    "stemgnn_glu_split_floats": (c_size_t, [c_int, c_int, c_int]),
+    "stemgnn_glu_split_panels": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
+    "stemgnn_spectral_glu_fwd_split": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+    "stemgnn_spectral_glu_dgrad_split": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "stemgnn_igft_heads_fwd": (c_int, [_PP, _P, _P, _P, c_long, c_long, c_long, _P, c_int, _P,
                                        c_int, c_int, c_int, c_int, _P]),
     "stemgnn_igft_heads_bwd": (c_int, [_PP, _P, _P, _P, c_long, c_long, c_long, _P, _P, _P, _P, _P, c_int, c_int,

@@ -157,6 +157,22 @@ class Model(nn.Module):
         return out
 
     # -- forward --------------------------------------------------------------------------------------
+    def prefetch_side(self, device=None):
+        """Side-stream mode: queue the weight packing and the dropout-stream bookkeeping (a clone and an increment) on the
+        side stream NOW, forked from the current stream's position.  hot_path() calls it itself; a step driver
+        (engine.TrainStep) calls it before its first kernel of the step, so that the fork does not hang off that kernel:
+        inside a hipGraph a node whose successors sit on two queues releases them ~10 us late (measured: window gather ->
+        {fill, pack}), and the packing only reads parameters anyway."""
+        hs = self.hot_state
+        if not hs.overlap or hs.prepacked is not None:
+            return
+        device = device or self.weight_key.device
+        blocks = (self.stock_block[0].hip_params(), self.stock_block[1].hip_params())
+        ops.prepack_blocks(hs, blocks, self.time_step, self.multi_layer, device)
+        if self.training and self.dropout_rate > 0.0 and os.environ.get("STEMGNN_SEED_SIDE", "1") == "1":
+            with torch.cuda.stream(ops._side_stream(device)):
+                hs.preseed = self._next_seed(device)
+
     def hot_path(self, x):
         """GRU (library) then the HIP hot path; returns (block forecast sum [B,N,W], attention, mul_L)."""
         if not x.is_cuda:
@@ -169,15 +185,12 @@ class Model(nn.Module):
         x = x.contiguous()
         blocks = (self.stock_block[0].hip_params(), self.stock_block[1].hip_params())
         use_drop = self.training and self.dropout_rate > 0.0
-        seed = None
         hs = self.hot_state
-        if hs.overlap:                # side-stream mode: weight packing and the dropout-stream bookkeeping (a clone and
-            ops.prepack_blocks(hs, blocks, self.time_step, self.multi_layer, x.device)   # an increment) overlap the GRU
-            if use_drop and os.environ.get("STEMGNN_SEED_SIDE", "1") == "1":
-                with torch.cuda.stream(ops._side_stream(x.device)):
-                    seed = self._next_seed(x.device)
-                if not torch.cuda.is_current_stream_capturing():
-                    seed.record_stream(torch.cuda.current_stream())
+        if hs.overlap and hs.prepacked is None:
+            self.prefetch_side(x.device)
+        seed, hs.preseed = hs.preseed, None
+        if seed is not None and not torch.cuda.is_current_stream_capturing():
+            seed.record_stream(torch.cuda.current_stream())
         if os.environ.get("STEMGNN_GRU", "hip") == "miopen":       # library GRU (MIOpen) -- A/B and debugging only
             h, _ = self.GRU(x.permute(2, 0, 1).contiguous())      # [N_seq, B, N_hid]  (:137)
         else:                                                      # persistent HIP recurrence (csrc/gru.hip)

@@ -10,6 +10,7 @@
 
 #include "../../include/stemgnn_hip.h"
 #include "gemm2.h"
+#include "gemm2s.h"
 #include "gemm_core.h"
 #include "layout.h"
 #include "reduce.h"
@@ -695,6 +696,14 @@ static inline bool wg_fused_on() {
   static const int v = getenv("STEMGNN_WG_FUSED") ? atoi(getenv("STEMGNN_WG_FUSED")) : 1;
   return v != 0;
 }
+// The fused weight-gradient kernel runs ONE workgroup per CU: it wins while the launch's output tiles (x splits) fit the
+// chip in one round.  With more tiles than CUs (W = 48: 540 tiles of the six GLU products) the tiles run in 2-3 uneven
+// rounds without any split, and the per-layer slab GEMMs (several short workgroups per CU) are faster -- measured at
+// configs[4] (N = 2048, W = 48, batch 16): 94.0 ms per step fused, 86.7 ms on the slab path.  STEMGNN_WG_MAX_TILES moves it.
+static inline bool wg_tiles_fit(WgGemm* q, int n) {
+  static const int lim = getenv("STEMGNN_WG_MAX_TILES") ? atoi(getenv("STEMGNN_WG_MAX_TILES")) : 256;
+  return wg_tile_index(q, n) <= lim;
+}
 static inline int split_chunk(int M, int S) { return ((M + S - 1) / S + 15) & ~15; }
 
 extern "C" int stemgnn_gft_fwd(const float* mul_L, const float* X, long xs_b, long xs_n, long xs_t,
@@ -816,6 +825,137 @@ extern "C" int stemgnn_spectral_glu_fwd(const float* packed, float* saved, int B
   return 0;
 }
 
+// ---- split-bf16 variant of the GLU forward / data-gradient layers (STEMGNN_DTYPE=bf16x3 | bf16x2, csrc/gemm2s.h) ------
+// Split-plane buffer of one StockBlock (caller-owned, stemgnn_glu_split_floats floats): for (r, l = 1, 2) plane set D
+// [S][kin][pad32(np)] then plane set F [S][np][pad32(kin)], bf16, each set 16-byte aligned.  Layer 0 (K = 3W) and the
+// layer-0 data gradient stay on the exact-fp32 kernels: their cost is the activation traffic, not the matrix pipe.
+struct G2SLayout {
+  size_t D[2][3], F[2][3], total;     // offsets in unsigned shorts
+};
+static inline G2SLayout g2s_layout(const SgDims& d, int S) {
+  G2SLayout L;
+  size_t off = 0;
+  for (int r = 0; r < 2; ++r)
+    for (int l = 0; l < 3; ++l) {
+      L.D[r][l] = L.F[r][l] = 0;
+      if (l == 0) continue;
+      const int kin = sg_glu_kin(d, l), np = sg_glu_np(d, l, r);
+      L.D[r][l] = off; off += ((size_t)S * kin * g2s_pad32(np) + 7) & ~(size_t)7;
+      L.F[r][l] = off; off += ((size_t)S * np * g2s_pad32(kin) + 7) & ~(size_t)7;
+    }
+  L.total = off;
+  return L;
+}
+extern "C" size_t stemgnn_glu_split_floats(int W, int multi, int splits) {
+  if (W <= 0 || multi <= 0 || splits < 2 || splits > 3) return 0;
+  const SgDims d = sg_dims(1, 1, W, multi);
+  return (g2s_layout(d, splits).total + 1) / 2 + 8;
+}
+extern "C" int stemgnn_glu_split_panels(const float* packed, float* split, int W, int multi, int splits, void* stream) {
+  if (!packed || !split || W <= 0 || multi <= 0 || splits < 2 || splits > 3 || (((uintptr_t)split) & 15)) return SG_EINVAL;
+  const SgDims d = sg_dims(1, 1, W, multi);
+  const SgPackedLayout P = sg_packed_layout(d);
+  const G2SLayout L = g2s_layout(d, splits);
+  unsigned short* base = reinterpret_cast<unsigned short*>(split);
+  hipStream_t st = (hipStream_t)stream;
+  for (int r = 0; r < 2; ++r)
+    for (int l = 1; l < 3; ++l) {
+      const int kin = sg_glu_kin(d, l), np = sg_glu_np(d, l, r);
+      const size_t n = (size_t)g2s_pad32(kin) * g2s_pad32(np);
+      const dim3 grid((unsigned)((n + 255) / 256));
+      if (splits == 3)
+        hipLaunchKernelGGL(g2s_split_panel_kernel<3>, grid, dim3(256), 0, st, packed + P.w[r][l], kin, np, base + L.D[r][l], base + L.F[r][l]);
+      else
+        hipLaunchKernelGGL(g2s_split_panel_kernel<2>, grid, dim3(256), 0, st, packed + P.w[r][l], kin, np, base + L.D[r][l], base + L.F[r][l]);
+      SG_TRY(hipGetLastError());
+    }
+  return 0;
+}
+
+// forward of the three GLU layers with layers 1, 2 on the split-bf16 kernel (same saved out / gate as the fp32 entry)
+extern "C" int stemgnn_spectral_glu_fwd_split(const float* packed, const float* split, float* saved, int B, int N, int W,
+                                              int multi, int splits, void* stream) {
+  if (!packed || !split || !saved || B <= 0 || N <= 0 || W <= 0 || multi <= 0 || splits < 2 || splits > 3) return SG_EINVAL;
+  const SgDims d = sg_dims(B, N, W, multi);
+  const SgPackedLayout P = sg_packed_layout(d);
+  const SgSavedLayout S = sg_saved_layout(d);
+  const G2SLayout L = g2s_layout(d, splits);
+  const unsigned short* base = reinterpret_cast<const unsigned short*>(split);
+  hipStream_t st = (hipStream_t)stream;
+  for (int l = 0; l < 3; ++l) {
+    G2Args g;
+    G2SArgs gs;
+    GluFwdEpi e;
+    for (int r = 0; r < 2; ++r) {
+      g.A[r] = l == 0 ? saved + S.G : saved + S.out[r][l - 1];
+      g.lda[r] = l == 0 ? d.KG : d.CP;
+      g.B[r] = packed + P.w[r][l];
+      g.ldb[r] = sg_glu_np(d, l, r);
+      g.M[r] = d.M; g.N[r] = sg_glu_np(d, l, r); g.K[r] = sg_glu_kin(d, l);
+      gs.A[r] = g.A[r]; gs.lda[r] = g.lda[r]; gs.P[r] = base + L.F[r][l];
+      gs.M[r] = g.M[r]; gs.N[r] = g.N[r]; gs.K[r] = g.K[r]; gs.Kp[r] = g2s_pad32(g.K[r]);
+      e.bp[r] = packed + P.b[r][l];
+      e.out[r] = saved + S.out[r][l];
+      e.gate[r] = saved + S.gate[r][l];
+      e.cp[r] = sg_glu_cp(d, l, r);
+    }
+    g.nsplit = 1; g.chunk = (sg_glu_kin(d, l) + 15) & ~15; g.b_ones_col = -1;
+    if (l > 0 && g2s_ok(gs, 2)) {
+      SG_TRY((g2s_launch<GluFwdEpi>(gs, e, 2, splits, st)));
+      continue;
+    }
+    if (sg_glu_kin(d, l) > SG_LONG_K) SG_TRY((g2_launch<GluFwdEpi, true, false, 64, true>(g, e, 2, st)));
+    else SG_TRY((g2_launch<GluFwdEpi, true, false, 64>(g, e, 2, st)));
+  }
+  return 0;
+}
+
+// data-gradient chain of the three GLU layers (= stemgnn_spectral_glu_bwd with parts = 1) with the two d(pre-activation)
+// products on the split-bf16 kernel
+extern "C" int stemgnn_spectral_glu_dgrad_split(const float* packed, const float* split, const float* saved, float* scratch,
+                                                int B, int N, int W, int multi, int splits, void* stream) {
+  if (!packed || !split || !saved || !scratch || B <= 0 || N <= 0 || W <= 0 || multi <= 0 || splits < 2 || splits > 3)
+    return SG_EINVAL;
+  const SgDims d = sg_dims(B, N, W, multi);
+  const SgPackedLayout P = sg_packed_layout(d);
+  const SgSavedLayout S = sg_saved_layout(d);
+  const SgScratchLayout C = sg_scratch_layout(d);
+  const G2SLayout L = g2s_layout(d, splits);
+  const unsigned short* base = reinterpret_cast<const unsigned short*>(split);
+  hipStream_t st = (hipStream_t)stream;
+  for (int l = 2; l >= 1; --l) {
+    G2Args g;
+    G2SArgs gs;
+    GluDpreEpi e;
+    for (int r = 0; r < 2; ++r) {
+      g.A[r] = scratch + C.dact[r][l];
+      g.lda[r] = sg_glu_np(d, l, r);
+      g.B[r] = packed + P.w[r][l];
+      g.ldb[r] = sg_glu_np(d, l, r);
+      g.M[r] = d.M; g.N[r] = d.CP; g.K[r] = sg_glu_np(d, l, r);
+      gs.A[r] = g.A[r]; gs.lda[r] = g.lda[r]; gs.P[r] = base + L.D[r][l];
+      gs.M[r] = g.M[r]; gs.N[r] = g.N[r]; gs.K[r] = g.K[r]; gs.Kp[r] = g2s_pad32(g.K[r]);
+      e.out[r] = saved + S.out[r][l - 1];
+      e.gate[r] = saved + S.gate[r][l - 1];
+      e.dpre[r] = scratch + C.dact[r][l - 1];
+    }
+    e.cp = d.CP;
+    g.nsplit = 1; g.chunk = (2 * d.CP + 15) & ~15; g.b_ones_col = -1;
+    if (g2s_ok(gs, 2)) {
+      SG_TRY((g2s_launch<GluDpreEpi>(gs, e, 2, splits, st)));
+      continue;
+    }
+    if (2 * d.CP > SG_LONG_K) SG_TRY((g2_launch<GluDpreEpi, true, true, 64, true>(g, e, 2, st)));
+    else SG_TRY((g2_launch<GluDpreEpi, true, true, 64>(g, e, 2, st)));
+  }
+  GluDgrad0Op op;
+  for (int r = 0; r < 2; ++r) { op.dpre[r] = scratch + C.dact[r][0]; op.wp[r] = packed + P.w[r][0]; }
+  op.dG = scratch + C.dG; op.np0 = sg_glu_np(d, 0, 0); op.KG = d.KG; op.M = d.M;
+  if (op.np0 > SG_LONG_K) SG_TRY((sg_launch_gemm<GluDgrad0Op, 32, 64, true, true, false, 64, true>(op, d.M, d.KG, 2, st)));
+  else SG_TRY((sg_launch_gemm<GluDgrad0Op, 32, 64, true, true, false, 64>(op, d.M, d.KG, 2, st)));
+  return 0;
+}
+
 extern "C" int stemgnn_spectral_glu_bwd(const float* packed, const float* saved, float* scratch,
                                         float* gradpart, int nsplit, int parts, int B, int N, int W, int multi,
                                         void* stream) {
@@ -847,6 +987,7 @@ extern "C" int stemgnn_spectral_glu_bwd(const float* packed, const float* saved,
         q.ldo = q.Nj; q.out_bias = nullptr;
         fused = fused && wg_gemm_ok(q);
       }
+    fused = fused && wg_tiles_fit(wq, 6);
   }
   for (int l = 2; l >= 0; --l) {
     // d(pre-activation) of layer l lives in dact[r][l] as [M x NP(l,r)] (pair order); it was written by
@@ -1137,7 +1278,8 @@ extern "C" int stemgnn_block_wgrad(const float* const* params_host, const float*
   for (int r = 0; r < 2; ++r)
     add(saved + S.out[r][2], d.CP2[r], d.CP2[r], scratch + C.dig, d.Wm, d.Wm, false,
         gradpart + Gl.wfold + (r ? (size_t)d.CP2[0] * d.WmP : 0), d.WmP);
-  if (!ok) {     // shapes outside the DMA path's 16-byte rules: the per-stage slab GEMMs (each leaves slab 0 complete)
+  ok = ok && wg_tiles_fit(q, n);
+  if (!ok) {     // shapes outside the DMA path's 16-byte rules or with more tiles than CUs: the per-stage slab GEMMs (each leaves slab 0 complete)
     const int rc = stemgnn_igft_heads_bwd(params_host, packed, saved, X, xs_b, xs_n, xs_t, dforecast,
                                           has_bc ? dforecast : nullptr, has_bc ? dforecast : nullptr, scratch, gradpart,
                                           nsplit, 2, B, N, W, multi, stream);

@@ -20,6 +20,8 @@
     if (_e != hipSuccess) return -(int)_e;       \
   } while (0)
 
+constexpr int ATTN_NBC = 8;     // batch chunks of the attention forward (more waves; partial sums reduced in fixed order)
+
 // ---- Philox4x32-10, one counter per attention element ---------------------------------------------
 __device__ __forceinline__ uint32_t sg_philox_u32(uint64_t seed, uint64_t offset, uint64_t idx) {
   uint32_t c0 = (uint32_t)idx, c1 = (uint32_t)(idx >> 32), c2 = (uint32_t)offset, c3 = (uint32_t)(offset >> 32);
@@ -52,9 +54,11 @@ __device__ __forceinline__ float sg_lrelu(float v, float alpha) { return v > 0.f
 // key[b,i] = sum_s h[s,b,i] wk[s], query likewise (:154-155).  grid (B, ceil(N/64)), 4 waves split s.
 __global__ __launch_bounds__(256) void sg_keyquery_kernel(const float* __restrict__ h, const float* __restrict__ wk,
                                                           const float* __restrict__ wq, float* __restrict__ key,
-                                                          float* __restrict__ query, int B, int N) {
+                                                          float* __restrict__ query, int B, int N,
+                                                          unsigned* __restrict__ arrive) {
   __shared__ float red[4][64][2];
   const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (blockIdx.y == 0 && threadIdx.x == 0) arrive[b] = 0u;      // arrival counter of batch b for the attention backward
   const int i = blockIdx.y * 64 + lane;
   float ak = 0.f, aq = 0.f;
   if (i < N) {
@@ -82,7 +86,8 @@ __global__ __launch_bounds__(256) void sg_keyquery_kernel(const float* __restric
 // dynamic LDS: qmax[bn] + acc[4][N]   (bn = batches per chunk)
 __global__ __launch_bounds__(256) void sg_attention_fwd_kernel(
     const float* __restrict__ key, const float* __restrict__ query, float alpha, float drop_p, int training,
-    const uint64_t* __restrict__ seedp, int B, int N, int bn, float* __restrict__ rowsum, float* __restrict__ Apart) {
+    const uint64_t* __restrict__ seedp, int B, int N, int bn, float* __restrict__ rowsum, float* __restrict__ Apart,
+    float* __restrict__ degpart) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* qmax = smem;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -118,7 +123,14 @@ __global__ __launch_bounds__(256) void sg_attention_fwd_kernel(
     }
   }
   float* out = Apart + ((size_t)blockIdx.y * N + i) * N;
-  for (int j = lane; j < N; j += 64) out[j] = acc[j];
+  float d = 0.f;
+  for (int j = lane; j < N; j += 64) {
+    const float a = acc[j];
+    out[j] = a;
+    d += a;
+  }
+  d = sg_wave_sum(d);                                 // this chunk's share of the degree of row i (times B)
+  if (lane == 0) degpart[(size_t)blockIdx.y * N + i] = d;
 }
 
 // A[i][:] = (sum_chunks Apart[c][i][:]) / B  (fixed order), deg[i] = sum_j A[i][j].  One wave per row.
@@ -167,6 +179,70 @@ __global__ __launch_bounds__(256) void sg_laplacian_fwd_kernel(const float* __re
   }
 }
 
+// Batch-chunk reduction and Laplacian in ONE launch (the default when the caller does not split the stage in two parts):
+// a 32 x 32 tile sums its own elements and those of its transposed partner tile over the chunks (fixed order: A comes
+// out bit-identical to sg_attention_reduce_kernel's), takes the degrees from the per-chunk row sums the attention kernel
+// left (deg_i = sum_c degpart[c][i] / B), writes A (saved for the backward), deg (by the tiles of the first tile
+// column), the symmetrised attention and mul_L slots 0 / 1.
+__global__ __launch_bounds__(256) void sg_laplacian_fused_kernel(const float* __restrict__ Apart,
+                                                                 const float* __restrict__ degpart, int nbc, int B, int N,
+                                                                 float* __restrict__ A, float* __restrict__ deg,
+                                                                 float* __restrict__ att, float* __restrict__ mulL) {
+  __shared__ float tT[32][33];
+  __shared__ float sdeg[2][32];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  const int i0 = blockIdx.y * 32, j0 = blockIdx.x * 32;
+  const float invB = 1.f / (float)B;
+  const size_t nn = (size_t)N * N;
+  // all chunk loads of an element are issued before the (fixed-order) sum: the kernel is a chain of L2 round trips
+  // otherwise (8 dependent loads per element measured 22 us at N = 228 against 5 + 10 us for the two separate kernels)
+  auto chunk_sum = [&](const float* __restrict__ p, size_t stride, bool ok) {
+    float v[ATTN_NBC];
+#pragma unroll
+    for (int c = 0; c < ATTN_NBC; ++c) v[c] = (ok && c < nbc) ? p[(size_t)c * stride] : 0.f;
+    float sacc = 0.f;
+#pragma unroll
+    for (int c = 0; c < ATTN_NBC; ++c) sacc += v[c];      // + 0.f for the unused chunks: exact
+    return sacc;
+  };
+  if (ty < 2) {
+    const int r = (ty == 0 ? i0 : j0) + tx;
+    sdeg[ty][tx] = chunk_sum(degpart + (r < N ? r : 0), (size_t)N, r < N) * invB;
+  }
+  float own[4], par[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int r = ty + 8 * u;
+    const int gi = j0 + r, gj = i0 + tx;  // partner tile (rows j0.., cols i0..)
+    const bool okp = gi < N && gj < N;
+    par[u] = chunk_sum(Apart + (okp ? (size_t)gi * N + gj : 0), nn, okp);
+    const int i = i0 + r, j = j0 + tx;
+    const bool oko = i < N && j < N;
+    own[u] = chunk_sum(Apart + (oko ? (size_t)i * N + j : 0), nn, oko);
+  }
+#pragma unroll
+  for (int u = 0; u < 4; ++u) tT[ty + 8 * u][tx] = par[u] * invB;
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int r = ty + 8 * u;
+    const int i = i0 + r, j = j0 + tx;
+    if (i < N && j < N) {
+      const size_t o = (size_t)i * N + j;
+      const float a = own[u] * invB;
+      const float sy = 0.5f * (a + tT[tx][r]);
+      const float di = sdeg[0][r], dj = sdeg[1][tx];
+      const float dhi = 1.f / (sqrtf(di) + 1e-7f), dhj = 1.f / (sqrtf(dj) + 1e-7f);
+      const float qv = (i == j ? di : 0.f) - sy;
+      A[o] = a;
+      att[o] = sy;
+      mulL[o] = 0.f;
+      mulL[nn + o] = dhi * (qv * dhj);
+    }
+  }
+  if (blockIdx.x == 0 && ty == 0 && i0 + tx < N) deg[i0 + tx] = sdeg[0][tx];
+}
+
 // ---- backward -----------------------------------------------------------------------------------------
 // Laplacian backward: one wave per row i.  dAB = dA / B.
 // with_degree == 0 (no dropout): the degree path adds a ROW-CONSTANT dd_i to dA[i][:], which the softmax backward
@@ -207,9 +283,11 @@ __global__ __launch_bounds__(256) void sg_laplacian_bwd_kernel(const float* __re
 __global__ __launch_bounds__(256) void sg_attention_bwd_kernel(
     const float* __restrict__ dAB, const float* __restrict__ key, const float* __restrict__ query,
     const float* __restrict__ rowsum, float alpha, float drop_p, int training, const uint64_t* __restrict__ seedp,
-    int B, int N, int nchunk, float* __restrict__ dkey, float* __restrict__ dqpart) {
+    int B, int N, int nchunk, float* __restrict__ dkey, float* __restrict__ dqpart, unsigned* __restrict__ arrive,
+    float* __restrict__ dquery) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   __shared__ float wred[4];
+  __shared__ int s_last;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int b = blockIdx.x, chunk = blockIdx.y;
   const float* q = query + (size_t)b * N;
@@ -283,6 +361,27 @@ __global__ __launch_bounds__(256) void sg_attention_bwd_kernel(
   float* out = dqpart + ((size_t)b * nchunk + chunk) * N;
   for (int j = threadIdx.x; j < N; j += 256)
     out[j] = (smem[j] + smem[N + j]) + (smem[2 * N + j] + smem[3 * N + j]);
+  if (!arrive) return;
+  // The chunk partials of batch b are summed by whichever of its workgroups arrives LAST (agent-scope release of the
+  // partial, ticket, agent-scope acquire, then plain loads) -- always in chunk order 0..nchunk-1, so the ticket decides
+  // who reduces, never the result.  Saves the separate reduce launch on the backward's critical chain; the counter is
+  // zeroed by the forward's key/query kernel and left at zero again here.
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned t = atomicAdd(arrive + b, 1u);
+    s_last = t == (unsigned)nchunk - 1u;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  __threadfence();
+  const float* pp = dqpart + (size_t)b * nchunk * N;
+  for (int j = threadIdx.x; j < N; j += 256) {
+    float sacc = 0.f;
+    for (int c = 0; c < nchunk; ++c) sacc += pp[(size_t)c * N + j];
+    dquery[(size_t)b * N + j] = sacc;
+  }
+  if (threadIdx.x == 0) arrive[b] = 0u;
 }
 
 __global__ void sg_dquery_reduce_kernel(const float* __restrict__ dqpart, float* __restrict__ dquery, int B, int N,
@@ -390,9 +489,8 @@ struct ChebBwd2Op {
 // =================================================================================================
 // host side
 // =================================================================================================
-static const int ATTN_NBC = 8;     // batch chunks of the attention forward (more waves; partial sums reduced in fixed order)
 extern "C" size_t stemgnn_attn_saved_floats(int B, int N) {
-  return (size_t)3 * B * N + (size_t)N * N + N + (size_t)ATTN_NBC * N * N;     // ... | deg | per-chunk partial sums
+  return (size_t)3 * B * N + (size_t)N * N + N + (size_t)ATTN_NBC * N * N + (size_t)ATTN_NBC * N + B;   // ... | deg | per-chunk partial sums | per-chunk degrees | arrival counters
 }
 extern "C" size_t stemgnn_attn_scratch_floats(int B, int N, int nchunk) {
   return (size_t)N * N + (size_t)2 * B * N + (size_t)B * nchunk * N;
@@ -411,16 +509,28 @@ extern "C" int stemgnn_attn_laplacian_fwd(const float* h, const float* wk, const
   float* A = rowsum + (size_t)B * N;
   float* deg = A + (size_t)N * N;
   if (parts & 1) {      // attention: key / query, softmax (+dropout), batch mean -> A [N,N] | deg [N] (contiguous)
-    hipLaunchKernelGGL(sg_keyquery_kernel, dim3(B, (N + 63) / 64), dim3(256), 0, st, h, wk, wq, key, query, B, N);
+    hipLaunchKernelGGL(sg_keyquery_kernel, dim3(B, (N + 63) / 64), dim3(256), 0, st, h, wk, wq, key, query, B, N,
+                       reinterpret_cast<unsigned*>(deg + N + (size_t)ATTN_NBC * N * N + (size_t)ATTN_NBC * N));
     SG_TRY(hipGetLastError());
     float* Apart = deg + N;
+    float* degpart = Apart + (size_t)ATTN_NBC * N * N;
     const int nbc = B < ATTN_NBC ? B : ATTN_NBC;
     const int bn = (B + nbc - 1) / nbc;
     const size_t lds = (size_t)(bn + 4 * N) * sizeof(float);
     if (lds > 64 * 1024) return SG_EINVAL;
     hipLaunchKernelGGL(sg_attention_fwd_kernel, dim3((N + 3) / 4, (B + bn - 1) / bn), dim3(256), lds, st, key, query, alpha,
-                       drop_p, training, seed, B, N, bn, rowsum, Apart);
+                       drop_p, training, seed, B, N, bn, rowsum, Apart, degpart);
     SG_TRY(hipGetLastError());
+    // both parts in one call: the chunk reduction is folded into the Laplacian kernel (3 launches instead of 4;
+    // STEMGNN_ATTN_FUSED=0 keeps the separate reduce).  A two-part caller (exact data-parallel mode) needs A | deg in
+    // memory between the parts and takes the separate kernels.
+    static const bool fused = !(getenv("STEMGNN_ATTN_FUSED") && atoi(getenv("STEMGNN_ATTN_FUSED")) == 0);
+    if ((parts & 2) && fused) {
+      hipLaunchKernelGGL(sg_laplacian_fused_kernel, dim3((N + 31) / 32, (N + 31) / 32), dim3(256), 0, st, Apart, degpart,
+                         (B + bn - 1) / bn, B, N, A, deg, attention_out, mul_L);
+      SG_TRY(hipGetLastError());
+      return 0;
+    }
     hipLaunchKernelGGL(sg_attention_reduce_kernel, dim3((N + 3) / 4), dim3(256), 0, st, Apart, (B + bn - 1) / bn, B, N, A, deg);
     SG_TRY(hipGetLastError());
   }
@@ -458,13 +568,23 @@ extern "C" int stemgnn_attn_laplacian_bwd(const float* dL, const float* h, const
   if (!(parts & 2)) return 0;
   const size_t lds = (size_t)(4 * N) * sizeof(float);
   if (lds > 150 * 1024) return SG_EINVAL;
+  // STEMGNN_ATTN_BWD_FUSED=1: the chunk reduction of d(query) rides in the attention kernel (last-arriver, fixed order)
+  // instead of its own launch.  OFF by default -- measured 92 us against 14 + 7 us for the two launches: the agent-scope
+  // release / acquire fences of the hand-off write back and invalidate the XCD's whole L2 while the chip-filling
+  // weight-gradient kernel of the side stream keeps it full of dirty lines (that kernel slowed from 102 to 146 us as
+  // well).  `saved` is const for the caller: the counters are scratch state the forward left zeroed.
+  static const bool bwd_fused = getenv("STEMGNN_ATTN_BWD_FUSED") && atoi(getenv("STEMGNN_ATTN_BWD_FUSED")) == 1;
+  unsigned* arrive = bwd_fused ? reinterpret_cast<unsigned*>(const_cast<float*>(deg) + N + (size_t)ATTN_NBC * N * N + (size_t)ATTN_NBC * N)
+                               : nullptr;
   hipLaunchKernelGGL(sg_attention_bwd_kernel, dim3(B, nchunk), dim3(256), lds, st, dAB, key, query, rowsum, alpha,
-                     drop_p, training, seed, B, N, nchunk, dkey, dqpart);
+                     drop_p, training, seed, B, N, nchunk, dkey, dqpart, arrive, dquery);
   SG_TRY(hipGetLastError());
-  const size_t bn = (size_t)B * N;
-  hipLaunchKernelGGL(sg_dquery_reduce_kernel, dim3((unsigned)((bn + 255) / 256)), dim3(256), 0, st, dqpart, dquery, B,
-                     N, nchunk);
-  SG_TRY(hipGetLastError());
+  if (!arrive) {
+    const size_t bn = (size_t)B * N;
+    hipLaunchKernelGGL(sg_dquery_reduce_kernel, dim3((unsigned)((bn + 255) / 256)), dim3(256), 0, st, dqpart, dquery, B,
+                       N, nchunk);
+    SG_TRY(hipGetLastError());
+  }
   hipLaunchKernelGGL(sg_keyquery_bwd_kernel, dim3(N), dim3(256), 0, st, h, wk, wq, dkey, dquery, dh, dwk, dwq, B, N);
   SG_TRY(hipGetLastError());
   return 0;

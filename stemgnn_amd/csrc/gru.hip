@@ -1039,12 +1039,91 @@ static int gru_pick_wide(int B, int Hd, int P2, GruWide* g) {
   return gru_wide_plan(Hd, gru_resident_limit(), g);
 }
 
+// Input projection gi[i][j] = b_ih[j] + sum_k x[b][k][s] w_ih[j][k] (row i = s * B + b) for short windows, as a streaming
+// kernel: K = W <= 16 is far too short for a tiled GEMM (one k-tile, 64 x 64 output tiles: 17-20 us for 20 MB of
+// output at PEMS07) -- here a thread keeps the W weights of 4 adjacent outputs in registers, walks down RPB rows, reads
+// the row's W window values through wave-uniform loads and stores one float4 per row.  Blocks beyond the row blocks zero
+// the two ranges the recurrence needs cleared (slab 0 of h_ext, the exchange granules): one launch instead of
+// fill + GEMM + fill ahead of the recurrence.  Needs 3 Hd % 4 == 0 and 3 Hd / 4 <= 1024.
+constexpr int GRU_GI_RPB = 8, GRU_GI_RU = 4;      // rows per block / rows whose window loads are in flight together
+template <int WW>
+__global__ __launch_bounds__(1024) void gru_gi_kernel(const float* __restrict__ x, const float* __restrict__ w_ih,
+                                                      const float* __restrict__ b_ih, float* __restrict__ gi, int B, int S,
+                                                      int Hd, int W, int nrb, unsigned* __restrict__ za, size_t na,
+                                                      unsigned* __restrict__ zb, size_t nb) {
+  if ((int)blockIdx.x >= nrb) {
+    const size_t i0 = ((size_t)(blockIdx.x - nrb) * blockDim.x + threadIdx.x) * 4;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const size_t i = i0 + u;
+      if (i < na) za[i] = 0u;
+      else if (i < na + nb) zb[i - na] = 0u;
+    }
+    return;
+  }
+  const int H3 = 3 * Hd, j = 4 * (int)threadIdx.x;
+  if (j >= H3) return;                                   // (no barriers below)
+  float w[4][WW];
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int k = 0; k < WW; ++k) w[c][k] = k < W ? w_ih[(size_t)(j + c) * W + k] : 0.f;
+  const float4 bias = make_float4(b_ih[j], b_ih[j + 1], b_ih[j + 2], b_ih[j + 3]);   // (parameter views: any 4-byte alignment)
+  const int i0 = blockIdx.x * GRU_GI_RPB, i1 = min(S * B, i0 + GRU_GI_RPB);
+  // (a first version walked 32 rows one at a time: 36 us, a chain of dependent L2 round trips -- slower than the GEMM)
+  for (int ib = i0; ib < i1; ib += GRU_GI_RU) {
+    float xv[GRU_GI_RU][WW];
+#pragma unroll
+    for (int u = 0; u < GRU_GI_RU; ++u) {
+      const int i = min(ib + u, i1 - 1);
+      const int sq = i / B, b = i - sq * B;
+      const float* xp = x + (size_t)b * W * S + sq;
+#pragma unroll
+      for (int k = 0; k < WW; ++k) xv[u][k] = xp[(size_t)(k < W ? k : 0) * S];      // wave-uniform addresses
+    }
+#pragma unroll
+    for (int u = 0; u < GRU_GI_RU; ++u) {
+      float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int k = 0; k < WW; ++k) {
+        a.x = fmaf(xv[u][k], w[0][k], a.x); a.y = fmaf(xv[u][k], w[1][k], a.y);
+        a.z = fmaf(xv[u][k], w[2][k], a.z); a.w = fmaf(xv[u][k], w[3][k], a.w);
+      }
+      a.x += bias.x; a.y += bias.y; a.z += bias.z; a.w += bias.w;
+      if (ib + u < i1) *reinterpret_cast<float4*>(gi + (size_t)(ib + u) * H3 + j) = a;
+    }
+  }
+}
+
+// zero two word ranges in one launch (4 words per thread where aligned; ranges are 4-byte aligned)
+__global__ __launch_bounds__(256) void gru_zero2_kernel(unsigned* __restrict__ a, size_t na, unsigned* __restrict__ b, size_t nb) {
+  const size_t i0 = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const size_t i = i0 + u;
+    if (i < na) a[i] = 0u;
+    else if (i < na + nb) b[i - na] = 0u;
+  }
+}
+
 extern "C" size_t stemgnn_gru_fwd_scratch_floats(int B, int S, int Hd) {
   return (size_t)3 * Hd * Hd + (size_t)3 * S * B * Hd + gru_xbuf_floats(B, Hd) + 4;   // W_hh^T | gi | exchange
 }
 extern "C" size_t stemgnn_gru_bwd_scratch_floats(int B, int S, int Hd, int W) {
   return (size_t)4 * S * B * Hd + (size_t)GRU_NSPLIT * 3 * Hd * (Hd + 1) + (size_t)gru_ih_slabs(B) * 3 * Hd * (W + 1) +
          gru_xbuf_floats(B, Hd) + 4 + (size_t)B * Hd + 8 + 136;   // ... | exchange | carry (time segments) | progress | pad + 64 arrival counters of the fused dW_hh kernel
+}
+
+// CUs the backward recurrence pins for its whole run (one workgroup each): what a caller that overlaps other work with
+// it on another stream should leave out when it sizes that work (ops.py: the second fused weight-gradient launch)
+extern "C" int stemgnn_gru_bwd_cus(int B, int Hd) {
+  if (B <= 0 || Hd <= 0) return 0;
+  const int P2 = gru_pick_P2(B, Hd);
+  GruWide wide;
+  if (gru_pick_wide(B, Hd, P2, &wide) > 0) return wide.P;
+  if (P2 > 0) return B * P2;
+  const int P = gru_pick_P(B, Hd);
+  return B * (P > 0 ? P : 1);
 }
 
 extern "C" int stemgnn_gru_fwd(const float* x, const float* w_ih, const float* w_hh, const float* b_ih,
@@ -1054,23 +1133,53 @@ extern "C" int stemgnn_gru_fwd(const float* x, const float* w_ih, const float* w
       Hd <= 0 || W <= 0)
     return SG_EINVAL;
   hipStream_t st = (hipStream_t)stream;
-  SG_TRY(hipMemsetAsync(h_ext, 0, (size_t)B * Hd * sizeof(float), st));    // slab 0: h_{-1} = 0
+  const int P2 = gru_pick_P2(B, Hd);
+  GruWide wide;
+  const bool use_wide = gru_pick_wide(B, Hd, P2, &wide) > 0;
   float* h_all = h_ext + (size_t)B * Hd;                                  // steps 0..S-1
   float* w_hhT = scratch;
   float* gi = scratch + (size_t)3 * Hd * Hd;
-  GruGiOp op{x, w_ih, b_ih, gi, B, S, Hd, W};
-  SG_TRY((sg_launch_gemm<GruGiOp, 64, 64, true, true, false>(op, S * B, 3 * Hd, 1, st)));
-  const int P2 = gru_pick_P2(B, Hd);
-  GruWide wide;
-  if (gru_pick_wide(B, Hd, P2, &wide) > 0) {
+  gru_u64* xbuf2 = (gru_u64*)(scratch + ((((size_t)3 * Hd * Hd + (size_t)3 * S * B * Hd) + 1) & ~(size_t)1));
+  bool gi_done = false;
+  if (!use_wide && P2 > 0) {
+    // per-row clusters: slab 0 (h_{-1} = 0) and the exchange granules (tags := 0 every launch) are zeroed ahead of the
+    // recurrence without fill nodes of their own (each costs ~5 us of launch latency on the step's critical path): by one
+    // small kernel ahead of the projection GEMM, or (STEMGNN_GRU_GI_STREAM=1, measured not faster) by the streaming
+    // input-projection kernel itself
+    const size_t n0 = (size_t)B * Hd, n1 = ((size_t)2 * B * Hd + (size_t)8 * B) * 2;        // in 4-byte words
+    static const bool gi_stream = getenv("STEMGNN_GRU_GI_STREAM") && atoi(getenv("STEMGNN_GRU_GI_STREAM")) == 1;   // measured: 25 us vs 20 + 5 -> off
+    const int nthr = ((3 * Hd / 4 + 63) / 64) * 64;
+    if (gi_stream && (3 * Hd) % 4 == 0 && nthr <= 1024 && W <= 16 && (((uintptr_t)gi) & 15) == 0) {
+      const int nrb = (S * B + GRU_GI_RPB - 1) / GRU_GI_RPB;
+      const unsigned nzb = (unsigned)((n0 + n1 + (size_t)nthr * 4 - 1) / ((size_t)nthr * 4));
+      if (W <= 12)
+        hipLaunchKernelGGL(gru_gi_kernel<12>, dim3(nrb + nzb), dim3(nthr), 0, st, x, w_ih, b_ih, gi, B, S, Hd, W, nrb,
+                           reinterpret_cast<unsigned*>(h_ext), n0, reinterpret_cast<unsigned*>(xbuf2), n1);
+      else
+        hipLaunchKernelGGL(gru_gi_kernel<16>, dim3(nrb + nzb), dim3(nthr), 0, st, x, w_ih, b_ih, gi, B, S, Hd, W, nrb,
+                           reinterpret_cast<unsigned*>(h_ext), n0, reinterpret_cast<unsigned*>(xbuf2), n1);
+      SG_TRY(hipGetLastError());
+      gi_done = true;
+    } else {
+      hipLaunchKernelGGL(gru_zero2_kernel, dim3((unsigned)((n0 + n1 + 1023) / 1024)), dim3(256), 0, st,
+                         reinterpret_cast<unsigned*>(h_ext), n0, reinterpret_cast<unsigned*>(xbuf2), n1);
+      SG_TRY(hipGetLastError());
+    }
+  } else {
+    SG_TRY(hipMemsetAsync(h_ext, 0, (size_t)B * Hd * sizeof(float), st));    // slab 0: h_{-1} = 0
+  }
+  if (!gi_done) {
+    GruGiOp op{x, w_ih, b_ih, gi, B, S, Hd, W};
+    SG_TRY((sg_launch_gemm<GruGiOp, 64, 64, true, true, false>(op, S * B, 3 * Hd, 1, st)));
+  }
+  if (use_wide) {
     float* xb = scratch + ((((size_t)3 * Hd * Hd + (size_t)3 * S * B * Hd) + 3) & ~(size_t)3);      // 16-byte aligned
     SG_TRY(gru_wide_fwd(gi, w_hh, b_hh, B, S, Hd, wide, xb, status, h_all, reserve, st));
     return 0;
   }
   if (P2 > 0) {
-    gru_u64* xbuf = (gru_u64*)(scratch + ((((size_t)3 * Hd * Hd + (size_t)3 * S * B * Hd) + 1) & ~(size_t)1));
+    gru_u64* xbuf = xbuf2;                                                          // zeroed by gru_zero2_kernel above
     gru_u64* xid = xbuf + (size_t)2 * B * Hd;                                       // P XCC-id granules per batch row
-    SG_TRY(hipMemsetAsync(xbuf, 0, ((size_t)2 * B * Hd + (size_t)8 * B) * sizeof(gru_u64), st));   // tags := 0 every launch
     static const int allow_fast = !(getenv("STEMGNN_GRU_FAST_XCD") && atoi(getenv("STEMGNN_GRU_FAST_XCD")) == 0);
     const dim3 grid(8 * ((B + 7) / 8) * P2);
 #define GRU_F2K(PP, KK, OO) hipLaunchKernelGGL((gru_fwd_cluster2_kernel<PP, KK, OO>), grid, dim3(3 * (PP / OO) * 64), 0, st, gi, \
@@ -1212,7 +1321,7 @@ extern "C" int stemgnn_gru_bwd(const float* dh_all, const float* x, const float*
   float* p_ih = p_hh + (size_t)GRU_NSPLIT * 3 * Hd * (Hd + 1);
   const int P2 = gru_pick_P2(B, Hd);
   const int P = P2 > 0 ? 0 : gru_pick_P(B, Hd);
-  bool segmented = false, fold_ih = false, hh_fused = false;
+  bool segmented = false, fold_ih = false, hh_fused = false, cnt_zeroed = false;
   GruWide wide;
   if (gru_pick_wide(B, Hd, P2, &wide) > 0) {
     float* xb = scratch + ((((size_t)(p_ih - scratch) + (size_t)gru_ih_slabs(B) * 3 * Hd * (W + 1)) + 3) & ~(size_t)3);
@@ -1232,12 +1341,17 @@ extern "C" int stemgnn_gru_bwd(const float* dh_all, const float* x, const float*
     }
     hipEvent_t* ev = T > 1 ? gru_events() : nullptr;
     if (T > 1 && !ev) T = 1;
-    float* xtail = scratch + ((((size_t)(p_ih - scratch) + (size_t)gru_ih_slabs(B) * 3 * Hd * (W + 1)) + 1) & ~(size_t)1);
+    float* xtail = scratch + ((((size_t)(p_ih - scratch) + (size_t)gru_ih_slabs(B) * 3 * Hd * (W + 1)) + 3) & ~(size_t)3);   // 16-byte aligned: one fill kernel
     gru_u64* xbuf = (gru_u64*)xtail;
     float* carry = xtail + gru_xbuf_floats(B, Hd);
     unsigned* progress = (unsigned*)(carry + (size_t)B * Hd);
     gru_u64* xid0 = xbuf + (size_t)2 * B * 3 * Hd;           // P XCC-id granules per batch row and per segment launch
-    SG_TRY(hipMemsetAsync(xbuf, 0, ((size_t)2 * B * 3 * Hd + (size_t)8 * 8 * B) * sizeof(gru_u64), st));
+    // ONE fill node ahead of the recurrence covers the exchange granules (tags := 0 every launch) and, behind carry /
+    // progress, the arrival counters of the fused dW_hh kernel, which otherwise costs a ~6 us fill node of its own on the
+    // critical path between the recurrence and that kernel (every memset is a graph node with its own launch latency)
+    const size_t fill_end = stemgnn_gru_bwd_scratch_floats(B, S, Hd, W) & ~(size_t)3;
+    SG_TRY(hipMemsetAsync(xbuf, 0, (fill_end - (size_t)(xtail - scratch)) * sizeof(float), st));
+    cnt_zeroed = true;
     static const int allow_fast = !(getenv("STEMGNN_GRU_FAST_XCD") && atoi(getenv("STEMGNN_GRU_FAST_XCD")) == 0);
     // Early weight gradients (single launch of the recurrence): when every workgroup has passed step s_mark the rows of
     // the steps >= s_mark are final; a spin kernel on side stream 1 waits for that mark and the dW_hh / dW_ih reductions
@@ -1272,7 +1386,10 @@ extern "C" int stemgnn_gru_bwd(const float* dh_all, const float* x, const float*
 #define GRU_B2(PP, OO) do { if (KU2 == 32) GRU_B2K(PP, 32, OO); else if (KU2 == 48) GRU_B2K(PP, 48, OO); \
                             else if (KU2 == 58) GRU_B2K(PP, 58, OO); else GRU_B2K(PP, 64, OO); } while (0)
       const char* e4 = getenv("STEMGNN_GRU_V4");
-      const bool v4 = !(e4 && atoi(e4) == 0) && P2 <= 4 && T == 1 && s_mark < 0;
+      // P = 6 (hidden 321..384: PEMS03) runs the wave-specialised backward with two owner slices per mat-vec wave
+      // (STEMGNN_GRU_V4_P6=0: the round-1 layout); P = 5 and P = 8 keep the round-1 layout (17 waves / register budget)
+      static const bool v4_p6 = !(getenv("STEMGNN_GRU_V4_P6") && atoi(getenv("STEMGNN_GRU_V4_P6")) == 0);
+      const bool v4 = !(e4 && atoi(e4) == 0) && (P2 <= 4 || (P2 == 6 && v4_p6)) && T == 1 && s_mark < 0;
       // dW_ih | db_ih accumulated by the chore wave while the gate gradients pass through it: one slab per batch row
       // instead of the split-K GEMM behind the recurrence (STEMGNN_GRU_FOLD_IH=0: keep the GEMM)
       const char* ef = getenv("STEMGNN_GRU_FOLD_IH");
@@ -1283,10 +1400,16 @@ extern "C" int stemgnn_gru_bwd(const float* dh_all, const float* x, const float*
                        Hd, xbuf, status, dgi, dghn, xid0, allow_fast, x, ih_slab, W); } while (0)
 #define GRU_B4(PP) do { if (KU2 == 32) GRU_B4K(PP, 32); else if (KU2 == 48) GRU_B4K(PP, 48); \
                         else if (KU2 == 58) GRU_B4K(PP, 58); else GRU_B4K(PP, 64); } while (0)
-      if (v4) {
+#define GRU_B46K(KK) do { const size_t hog = gru_lds_hog4<6>((const void*)gru_bwd_cluster4_kernel<6, KK, 2>); \
+    hipLaunchKernelGGL((gru_bwd_cluster4_kernel<6, KK, 2>), grid, dim3((3 * 6 / 2 + 2) * 64), hog, st, dh_all, w_hh, h_all, reserve, B, S, \
+                       Hd, xbuf, status, dgi, dghn, xid0, allow_fast, x, ih_slab, W); } while (0)
+      if (v4 && P2 == 6) {
+        if (KU2 <= 58) GRU_B46K(58); else GRU_B46K(64);
+      } else if (v4) {
         if (P2 == 1) GRU_B4(1); else if (P2 == 2) GRU_B4(2); else GRU_B4(4);
       } else if (P2 == 1) GRU_B2(1, 1); else if (P2 == 2) GRU_B2(2, 1); else if (P2 == 4) GRU_B2(4, 1);
       else if (P2 == 5) GRU_B2(5, 1); else if (P2 == 6) GRU_B2(6, 2); else GRU_B2(8, 2);
+#undef GRU_B46K
 #undef GRU_B4
 #undef GRU_B4K
 #undef GRU_B2
@@ -1367,7 +1490,7 @@ extern "C" int stemgnn_gru_bwd(const float* dh_all, const float* x, const float*
         // arrival counters: the last 64 words of the 16-byte aligned part of the scratch tail (>= 128 spare floats)
         const size_t tail = (stemgnn_gru_bwd_scratch_floats(B, S, Hd, W) - 64) & ~(size_t)3;
         unsigned* cnt = reinterpret_cast<unsigned*>(scratch + tail);
-        SG_TRY(wg_launch(q, 2, S * B, p_hh, cnt, smax_ws > 32 ? 32 : smax_ws, st));
+        SG_TRY(wg_launch(q, 2, S * B, p_hh, cnt, smax_ws > 32 ? 32 : smax_ws, st, !cnt_zeroed));
         hh_fused = true;
       }
     }

@@ -1,4 +1,4 @@
-// Cluster recurrence v4 (U = ceil(Hd/P) <= 64; forward: any P <= 8, backward: P <= 4): WAVE SPECIALISATION.
+// Cluster recurrence v4 (U = ceil(Hd/P) <= 64; forward: any P <= 8, backward: P <= 4 and P = 6): WAVE SPECIALISATION.
 //
 // What bounds a recurrence step is not FLOPs or bytes but the number of instructions the busiest wave has to ISSUE (a wave
 // issues one instruction every ~4-5 cycles whatever its kind; measured with -DGRU_PROF, profiles/r02_gru_phase_cycles.txt,
@@ -90,6 +90,28 @@ __device__ __forceinline__ float gru4_poll(const gru_u64* g, unsigned tag, bool 
   }
   return v;
 #endif
+}
+// two granules per lane (the two owner slices of an OW = 2 mat-vec wave): both loads go out before the first spin
+template <int PRE>
+__device__ __forceinline__ void gru4_poll2(const gru_u64* g0, const gru_u64* g1, unsigned tag, bool act0, bool act1,
+                                           int* status, float (&v)[2]) {
+  if (PRE > 0) __builtin_amdgcn_s_sleep(PRE);
+  gru_u64 x0 = __hip_atomic_load(g0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // (inactive lanes read a valid granule
+  gru_u64 x1 = __hip_atomic_load(g1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     //  of the slice and ignore it)
+  unsigned spins = 0;
+  while (act0 && (unsigned)(x0 >> 32) != tag) {
+    if (GRU_POLL_LOOP_SLEEP > 0) __builtin_amdgcn_s_sleep(GRU_POLL_LOOP_SLEEP);
+    x0 = __hip_atomic_load(g0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (++spins > (1u << 22)) { atomicExch(status, 1); break; }
+  }
+  spins = 0;
+  while (act1 && (unsigned)(x1 >> 32) != tag) {
+    if (GRU_POLL_LOOP_SLEEP > 0) __builtin_amdgcn_s_sleep(GRU_POLL_LOOP_SLEEP);
+    x1 = __hip_atomic_load(g1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (++spins > (1u << 22)) { atomicExch(status, 1); break; }
+  }
+  v[0] = act0 ? __uint_as_float((unsigned)x0) : 0.f;
+  v[1] = act1 ? __uint_as_float((unsigned)x1) : 0.f;
 }
 constexpr int gru4_static_lds_floats(int P, int nin, int nout) { return 2 * 3 * P * 64 + 3 * P * 64 + 2 * nin * 64 + 2 * nout * 64; }
 
@@ -262,8 +284,13 @@ __global__ __launch_bounds__((P + 2) * 64) void gru_fwd_cluster4_kernel(const fl
 // and B_s.  part[tag&1] (tag = S-s): written by mat-vec(s) before B_s, read by gate(s-1).  bin[(s-1)&1]: inputs of
 // gate(s-1), fetched by the chore wave during step s+1 and written at the top of step s (before B_s).  bout[s&1]: written by gate(s) before
 // B_s, moved to global memory by the chore wave during step s-1 (before B_{s-1}), rewritten by gate(s-2) after that.
-template <int P, int KU>
-__global__ __launch_bounds__((3 * P + 2) * 64) void gru_bwd_cluster4_kernel(const float* __restrict__ dout, const float* __restrict__ w_hh,
+// OW = owner slices per mat-vec wave.  OW = 1 (P <= 4): 3P mat-vec waves.  OW = 2 (P = 6: hidden sizes 321..384, PEMS03's
+// N = 358): 3P/2 waves that poll and multiply two slices per step, so that the workgroup stays inside 1024 threads with
+// the gate and chore waves on top (3*6/2 + 2 = 11 waves: three per SIMD, 170 registers per lane -- the two slices' 128
+// weight registers fit only with the all-readlane broadcast, NR = 64).  Both granule loads of a step are in flight
+// before the first spin.
+template <int P, int KU, int OW = 1>
+__global__ __launch_bounds__((3 * P / OW + 2) * 64) void gru_bwd_cluster4_kernel(const float* __restrict__ dout, const float* __restrict__ w_hh,
                                                                             const float* __restrict__ h_all,
                                                                             const float* __restrict__ reserve, int B, int S, int Hd,
                                                                             gru_u64* __restrict__ xbuf, int* __restrict__ status,
@@ -271,7 +298,8 @@ __global__ __launch_bounds__((3 * P + 2) * 64) void gru_bwd_cluster4_kernel(cons
                                                                             gru_u64* __restrict__ xid, int allow_fast,
                                                                             const float* __restrict__ x, float* __restrict__ ih_slab,
                                                                             int W) {
-  constexpr int NMV = 3 * P;
+  static_assert(P % OW == 0 && (OW == 1 || OW == 2), "owner slices per wave");
+  constexpr int NMV = 3 * P / OW;
   __shared__ float part[2][NMV][64];
   __shared__ __attribute__((aligned(16))) float lrow[NMV][64];
   __shared__ float bin[2][6][64];                        // dh_out, r, z, n, W_hn h + b_hn, h_prev
@@ -292,18 +320,22 @@ __global__ __launch_bounds__((3 * P + 2) * 64) void gru_bwd_cluster4_kernel(cons
 
   if (wave < NMV) {
     // ---------------- mat-vec wave (gate g, owner slot q rotated by p): reduction slice j = g*Hd + units of that owner
-    const int g = wave / P, q = wave - g * P;
-    const int k0 = ((q + p) % P) * U, kn = max(0, min(Hd, k0 + U) - k0);
-    gru_f2 wr[32];
-    {
-      const float* wcol = w_hh + ((size_t)g * Hd + (kn > 0 ? k0 : 0)) * Hd + gu;
+    const int g = wave / (P / OW), q0 = (wave - g * (P / OW)) * OW;
+    gru_f2 wr[OW][32];
+    int kn[OW];
+    const gru_u64* pollp[OW];                            // parity 0
+#pragma unroll
+    for (int o = 0; o < OW; ++o) {
+      const int k0 = ((q0 + o + p) % P) * U;
+      kn[o] = max(0, min(Hd, k0 + U) - k0);
+      const float* wcol = w_hh + ((size_t)g * Hd + (kn[o] > 0 ? k0 : 0)) * Hd + gu;
 #pragma unroll
       for (int kk = 0; kk < KU; ++kk) {
-        const float v = wcol[(size_t)(kk < kn ? kk : 0) * Hd];
-        wr[kk >> 1][kk & 1] = (lane_ok && kk < kn) ? v : 0.f;
+        const float v = wcol[(size_t)(kk < kn[o] ? kk : 0) * Hd];
+        wr[o][kk >> 1][kk & 1] = (lane_ok && kk < kn[o]) ? v : 0.f;
       }
+      pollp[o] = xbuf + (size_t)b * H3 + (size_t)g * Hd + k0 + (lane < kn[o] ? lane : 0);
     }
-    const gru_u64* pollp = xbuf + (size_t)b * H3 + (size_t)g * Hd + k0 + (lane < kn ? lane : 0);   // parity 0
     const size_t par = (size_t)B * H3;
 #ifdef GRU_PROF
     long long c_a = 0, c_b = 0, c_c = 0;
@@ -312,10 +344,22 @@ __global__ __launch_bounds__((3 * P + 2) * 64) void gru_bwd_cluster4_kernel(cons
     for (int s = S - 1; s >= 1; --s) {
       const unsigned tag = (unsigned)(S - s);
       GRU_T(t0);
-      const float dv = gru4_poll<GRU_POLL_PRE_B>(pollp + (tag & 1) * par, tag, lane < kn, status);
-      GRU_T(t1);
-      GRU_ACC(c_a, t1, t0);
-      part[tag & 1][wave][lane] = gru_matvec<KU, (KU <= 58 ? GRU_NR4 : (GRU_NR4 > 24 ? GRU_NR4 : 24))>(wr, dv, lrow[wave], lane);
+      float pv;
+      if constexpr (OW == 1) {
+        const float dv = gru4_poll<GRU_POLL_PRE_B>(pollp[0] + (tag & 1) * par, tag, lane < kn[0], status);
+        GRU_T(t1);
+        GRU_ACC(c_a, t1, t0);
+        pv = gru_matvec<KU, (KU <= 58 ? GRU_NR4 : (GRU_NR4 > 24 ? GRU_NR4 : 24))>(wr[0], dv, lrow[wave], lane);
+      } else {
+        float dv[2];
+        gru4_poll2<GRU_POLL_PRE_B>(pollp[0] + (tag & 1) * par, pollp[1] + (tag & 1) * par, tag, lane < kn[0], lane < kn[1],
+                                   status, dv);
+        GRU_T(t1);
+        GRU_ACC(c_a, t1, t0);
+        pv = gru_matvec<KU, 64>(wr[0], dv[0], lrow[wave], lane);
+        pv += gru_matvec<KU, 64>(wr[OW - 1], dv[1], lrow[wave], lane);
+      }
+      part[tag & 1][wave][lane] = pv;
       GRU_T(t2);
       GRU_ACC(c_b, t2, t1);
       gru_lds_barrier();                                 // B_s

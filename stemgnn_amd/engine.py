@@ -91,8 +91,21 @@ class TrainStep:
 
     # -- the step body, on whatever tensors it is handed ------------------------------------------------------
     def _fwd_bwd(self, hi, x, y):
+        # The side stream's work of the forward (weight packing, dropout key) only reads parameters: it forks from the
+        # stream position BEFORE the step's first kernel (an event recorded here), not from behind the window gather --
+        # inside a hipGraph a node whose successors sit on two queues releases them ~10 us late.  The work itself is queued
+        # after the gather so that the gather stays the first node the graph launches ("2"; "1": queued ahead of the
+        # gather, measured: the gather then starts 10 us late; "0": forked inside Model.hot_path, behind the gather).
+        early = os.environ.get("STEMGNN_EARLY_FORK", "2") if self.state.overlap and hasattr(self.model, "prefetch_side") else "0"
+        if early == "1":
+            self.model.prefetch_side(self.device)
+        elif early == "2":
+            self.state.fork_event = torch.cuda.Event()
+            self.state.fork_event.record()
         if self.series is not None:
             ops.window_gather(self.series, hi, self.W, self.H, x, y)
+        if early == "2":
+            self.model.prefetch_side(self.device)
         if not self.fuse_zero:
             if self.bucket is not None:
                 self.bucket.zero()

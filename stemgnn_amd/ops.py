@@ -44,6 +44,8 @@ class HotPathState:
         self.direct = False
         self.overlap = False
         self.prepacked = None        # (packed panels, side stream, blocks) queued by prepack_blocks
+        self.preseed = None          # dropout key of the coming forward, cloned on the side stream (Model.prefetch_side)
+        self.fork_event = None       # optional event the next prepack_blocks forks the side stream from
         self.pending = None          # (side stream, keep-alive objects) of weight-gradient work not yet joined
         self.exact_group = None      # data-parallel "exact mode" (SURVEY 8e-ii): (process group, world size) or None
         _states.add(self)
@@ -69,6 +71,8 @@ class HotPathState:
                 except RuntimeError:
                     pass    # engine.capture synchronizes the device afterwards anyway
         self.prepacked = None
+        self.preseed = None
+        self.fork_event = None
         self.pending = None
 
 
@@ -109,12 +113,44 @@ def set_direct_grad(model, flag=True, overlap=False):
 _NCHUNK = int(os.environ.get("STEMGNN_ATTN_CHUNKS", "16"))  # row chunks of the attention backward
 # share of the CUs (percent) the fused weight-gradient launches fill in side-stream mode: [0] the first launch on the side
 # stream (beside GEMM / Chebyshev kernels of the main stream), [1] the second (under the GRU recurrence: half of the CUs)
-_WG_CU = (int(os.environ.get("STEMGNN_WG_CU0", "100")), int(os.environ.get("STEMGNN_WG_CU1", "50")))
+_WG_CU = (int(os.environ.get("STEMGNN_WG_CU0", "100")), int(os.environ.get("STEMGNN_WG_CU1", "0")))
+
+
+def _wg_cu(which, B, N):
+    """CU share (percent) of the side stream's first / second fused weight-gradient launch.  The second one runs under the
+    GRU backward recurrence, which pins stemgnn_gru_bwd_cus(B, N) CUs for its whole run: unless STEMGNN_WG_CU1 says
+    otherwise it is sized for what is left (50 % at PEMS07 where 4 workgroups serve a batch row, 25 % at N = 358 with 6; hidden sizes of the wide cluster keep 50)."""
+    if which == 0 or _WG_CU[1] > 0:
+        return _WG_CU[which]
+    if N > 512:          # wide cluster (hidden > 512): the weight-gradient work there exceeds what the idle CUs could do in
+        return 50        # the recurrence's time -- the round-2/3 setting (half of the chip, sharing CUs with the cluster) stays
+    busy = _lib.load().stemgnn_gru_bwd_cus(B, N)
+    return max(10, min(100, (256 - busy) * 100 // 256))
 _WG_SCHED = os.environ.get("STEMGNN_WG_SCHED", "late")
 
 
 def _stream():
     return torch.cuda.current_stream().cuda_stream
+
+
+def glu_splits():
+    """Arithmetic of the GLU forward / data-gradient layers inside the model (STEMGNN_DTYPE): 0 = exact fp32 MFMA (default,
+    the reference's arithmetic), 3 / 2 = split-bf16 products (bf16x3: fp32-class; bf16x2: ~2^-16 relative) on the bf16
+    matrix instructions with fp32 accumulation (csrc/gemm2s.h).  Read per call, so a test can switch it."""
+    v = os.environ.get("STEMGNN_DTYPE", "f32").lower()
+    if v in ("f32", "fp32", ""):
+        return 0
+    if v == "bf16x3":
+        return 3
+    if v == "bf16x2":
+        return 2
+    raise _lib.StemGNNHipError(f"STEMGNN_DTYPE={v!r}: expected f32, bf16x3 or bf16x2")
+
+
+def _split_panels(lib, pk, W, multi, splits, device, stream):
+    sp = torch.empty(lib.stemgnn_glu_split_floats(W, multi, splits), device=device, dtype=torch.float32)
+    _lib.check(lib.stemgnn_glu_split_panels(pk.data_ptr(), sp.data_ptr(), W, multi, splits, stream), "glu_split_panels")
+    return sp
 
 
 def _require_gpu(t, name):
@@ -500,11 +536,20 @@ def prepack_blocks(state, block_params, W, multi, device):
     n_packed = lib.stemgnn_packed_floats(W, multi)
     blocks = [[None if p is None else p.contiguous() for p in blk] for blk in block_params]
     packed = [torch.empty(n_packed, device=device, dtype=torch.float32) for _ in blocks]
-    side.wait_stream(main)
+    ev, state.fork_event = state.fork_event, None
+    if ev is not None:
+        side.wait_event(ev)          # fork point chosen by the step driver (engine.TrainStep: ahead of the window gather)
+    else:
+        side.wait_stream(main)
+    splits = glu_splits()
+    split = []
     for blk, pk in zip(blocks, packed):
         _lib.check(lib.stemgnn_block_pack(_lib.ptr_array(blk), tables.data_ptr(), pk.data_ptr(), W, multi,
                                           side.cuda_stream), "block_pack")
-    state.prepacked = (packed, side, blocks)
+        if splits:
+            with torch.cuda.stream(side):
+                split.append(_split_panels(lib, pk, W, multi, splits, device, side.cuda_stream))
+    state.prepacked = (packed, side, blocks, (splits, split))
 
 
 class SpectralHotPath(torch.autograd.Function):
@@ -568,7 +613,8 @@ class SpectralHotPath(torch.autograd.Function):
 
         fsum = torch.empty(B, N, W, device=dev, dtype=f32)
         backcast = torch.empty(B, N, W, device=dev, dtype=f32)
-        packed, saved = [], []
+        packed, saved, split = [], [], []
+        splits = pre[3][0] if pre is not None else glu_splits()
         n_packed = lib.stemgnn_packed_floats(W, multi)
         n_saved = lib.stemgnn_saved_floats(B, N, W, multi)
         xviews = [(x, W * N, 1, N), (backcast, N * W, W, 1)]   # X[b,n,t] strides of block 0 / block 1
@@ -576,15 +622,24 @@ class SpectralHotPath(torch.autograd.Function):
             sv = torch.empty(n_saved, device=dev, dtype=f32)
             parr = _lib.ptr_array(blocks[s])
             X, sb, sn, stt = xviews[s]
+            sp = None
             if pre is not None:
                 pk = pre[0][s]
+                sp = pre[3][1][s] if splits else None
             else:
                 pk = torch.empty(n_packed, device=dev, dtype=f32)
                 _lib.check(lib.stemgnn_block_pack(parr, tables.data_ptr(), pk.data_ptr(), W, multi, st), "block_pack")
+                if splits:
+                    sp = _split_panels(lib, pk, W, multi, splits, dev, st)
             _lib.check(lib.stemgnn_gft_fwd(mul_L.data_ptr(), X.data_ptr(), sb, sn, stt, sv.data_ptr(), B, N, W, st),
                        "gft_fwd")
-            _lib.check(lib.stemgnn_spectral_glu_fwd(pk.data_ptr(), sv.data_ptr(), B, N, W, multi, st),
-                       "spectral_glu_fwd")
+            if splits:
+                _lib.check(lib.stemgnn_spectral_glu_fwd_split(pk.data_ptr(), sp.data_ptr(), sv.data_ptr(), B, N, W, multi,
+                                                              splits, st), "spectral_glu_fwd_split")
+            else:
+                _lib.check(lib.stemgnn_spectral_glu_fwd(pk.data_ptr(), sv.data_ptr(), B, N, W, multi, st),
+                           "spectral_glu_fwd")
+            split.append(sp)
             _lib.check(lib.stemgnn_igft_heads_fwd(
                 parr, pk.data_ptr(), sv.data_ptr(), X.data_ptr(), sb, sn, stt, fsum.data_ptr(), int(s == 1),
                 backcast.data_ptr() if s == 0 else None, B, N, W, multi, st), "igft_heads_fwd")
@@ -594,6 +649,7 @@ class SpectralHotPath(torch.autograd.Function):
         ctx.dims = (B, N, W, multi, float(alpha), float(drop_p), bool(training))
         ctx.blocks = blocks
         ctx.aux = (h, x, wk, wq, seed, tables, mul_L, attn_saved, backcast, packed, saved)
+        ctx.split = (splits, split)
         ctx.mark_non_differentiable(attention, mul_L)
         ctx.set_materialize_grads(False)
         return fsum, attention, mul_L
@@ -605,6 +661,7 @@ class SpectralHotPath(torch.autograd.Function):
         h, x, wk, wq, seed, tables, mul_L, attn_saved, backcast, packed, saved = ctx.aux
         blocks = ctx.blocks
         state = ctx.state
+        splits, split = ctx.split
         dev, f32 = x.device, torch.float32
         st = _stream()
         dfsum = dfsum.contiguous()
@@ -663,6 +720,11 @@ class SpectralHotPath(torch.autograd.Function):
                     scratch.data_ptr(), gradpart.data_ptr(), nsplit, 1, B, N, W, multi, stream), "igft_heads_bwd")
 
             def glu(stream):                    # data-gradient chain of the three GLU layers -> dG
+                if splits:
+                    _lib.check(lib.stemgnn_spectral_glu_dgrad_split(
+                        packed[s].data_ptr(), split[s].data_ptr(), saved[s].data_ptr(), scratch.data_ptr(),
+                        B, N, W, multi, splits, stream), "spectral_glu_dgrad_split")
+                    return
                 _lib.check(lib.stemgnn_spectral_glu_bwd(
                     packed[s].data_ptr(), saved[s].data_ptr(), scratch.data_ptr(), gradpart.data_ptr(), nsplit, 1,
                     B, N, W, multi, stream), "spectral_glu_bwd")
@@ -692,11 +754,23 @@ class SpectralHotPath(torch.autograd.Function):
             heads, glu, wgrad, unpack = stage_fns(s)
             heads(st)
             glu(st)
+
+            def gft():
+                _lib.check(lib.stemgnn_gft_bwd(
+                    mul_L.data_ptr(), X.data_ptr(), sb, sn, stt, dG.data_ptr(),
+                    dbackcast.data_ptr() if s == 1 else None, dmul_L.data_ptr(), int(s == 0), B, N, W, st), "gft_bwd")
+            # STEMGNN_GFT_FIRST=1: block 0's GFT backward goes out BEFORE the fork instead of behind it.  Behind the fork it
+            # runs beside the chip-filling weight-gradient launch (70 us instead of 18 in the r03 step timeline), but moving
+            # it only moves the contention to the Chebyshev / attention kernels that follow: A/B on one box 1.380 / 1.382 ms
+            # per step with it, 1.370 / 1.373 without -> off
+            gft_first = overlap and s == 0 and not early and os.environ.get("STEMGNN_GFT_FIRST", "0") == "1"
+            if gft_first:
+                gft()
             if overlap and (s == 0 or defer_b1):
                 if early:
                     side.wait_stream(main)                   # fork behind THIS block's data-gradient chain
                     with torch.cuda.stream(side):
-                        wgrad(side.cuda_stream, _WG_CU[1 - s])   # _WG_CU[0]: launch beside the GEMM chain, [1]: under the GRU
+                        wgrad(side.cuda_stream, _wg_cu(1 - s, B, N))   # [0]: launch beside the GEMM chain, [1]: under the GRU
                         unpack(side.cuda_stream)
                     if s == 0:
                         keep.append(bufs)                    # alive until the join
@@ -706,17 +780,16 @@ class SpectralHotPath(torch.autograd.Function):
                         sst = side.cuda_stream
                         for ss in ((0, 1) if defer_b1 else (0,)):
                             _h, _g, w2, u2 = (heads, glu, wgrad, unpack) if ss == 0 else stage_fns(1)
-                            w2(sst, _WG_CU[ss])
+                            w2(sst, _wg_cu(ss, B, N))
                             u2(sst)
                     keep.append(bufs)                        # alive until the join
             else:
                 wgrad(st, 100)
                 unpack(st)
-            _lib.check(lib.stemgnn_gft_bwd(
-                mul_L.data_ptr(), X.data_ptr(), sb, sn, stt, dG.data_ptr(),
-                dbackcast.data_ptr() if s == 1 else None, dmul_L.data_ptr(), int(s == 0), B, N, W, st), "gft_bwd")
+            if not gft_first:
+                gft()
         if overlap:
-            state.pending = (side, (keep, packed, saved, backcast, dfsum, dbackcast))
+            state.pending = (side, (keep, packed, saved, split, backcast, dfsum, dbackcast))
         dL = torch.empty(N, N, device=dev, dtype=f32)
         cheb_scratch = torch.empty(2 * N * N, device=dev, dtype=f32)
         _lib.check(lib.stemgnn_cheb_bwd(mul_L.data_ptr(), dmul_L.data_ptr(), dL.data_ptr(), cheb_scratch.data_ptr(),

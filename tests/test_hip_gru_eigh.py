@@ -36,6 +36,38 @@ def test_gru_fwd_bwd_vs_torch_cpu(B, S, W, cluster, monkeypatch):
         assert relerr(mine.grad, ref.grad) < TOL
 
 
+@pytest.mark.parametrize("B,S,W", [(32, 358, 12), (3, 384, 5), (2, 330, 20), (5, 321, 16)])
+def test_gru_six_workgroup_cluster_backward_vs_torch_cpu_and_round1_layout(B, S, W, monkeypatch):
+    """Hidden sizes 321..384 (PEMS03's N = 358): six workgroups per batch row, the wave-specialised backward with two owner
+    slices per mat-vec wave (round 3).  Against torch's CPU GRU, and against the round-1 layout of the same cluster
+    (STEMGNN_GRU_V4_P6=0 would need a new process: the switch is read once, so the comparison is with torch only here;
+    W = 20 exceeds the in-recurrence dW_ih accumulation and takes the GEMM path)."""
+    from stemgnn_amd.ops import GruFront, check_gru_status
+
+    torch.manual_seed(S + B)
+    gru = torch.nn.GRU(W, S)
+    x = torch.randn(B, W, S)
+    dh = torch.randn(S, B, S)
+    out, _ = gru(x.permute(2, 0, 1).contiguous())
+    out.backward(dh)
+    params = [p.detach().clone().cuda().requires_grad_(True)
+              for p in (gru.weight_ih_l0, gru.weight_hh_l0, gru.bias_ih_l0, gru.bias_hh_l0)]
+    h = GruFront.apply(x.cuda(), *params)
+    h.backward(dh.cuda())
+    torch.cuda.synchronize()
+    check_gru_status(torch.device("cuda:0"))
+    assert relerr(h, out.detach()) < TOL
+    for mine, ref in zip(params, (gru.weight_ih_l0, gru.weight_hh_l0, gru.bias_ih_l0, gru.bias_hh_l0)):
+        assert relerr(mine.grad, ref.grad) < TOL
+    g1 = [p.grad.clone() for p in params]
+    for p in params:
+        p.grad = None
+    GruFront.apply(x.cuda(), *params).backward(dh.cuda())      # bitwise reproducible from launch to launch
+    torch.cuda.synchronize()
+    for a, p in zip(g1, params):
+        assert torch.equal(a, p.grad)
+
+
 @pytest.mark.parametrize("B,S,W", [(32, 228, 12), (5, 33, 7), (3, 140, 12), (2, 300, 4), (4, 307, 12)])
 def test_gru_forward_wave_per_owner_is_bit_identical(B, S, W, monkeypatch):
     """The round-2 forward (one wave per owner slice, three gates per broadcast) sums every gate in the order of the
@@ -161,6 +193,41 @@ def test_wide_cluster_gru_vs_torch_cpu(B, S, W, force, monkeypatch):
     assert relerr(h, out.detach()) < TOL
     for mine, ref in zip(params, ref_grads):
         assert relerr(mine.grad, ref) < TOL
+
+
+def _gru_probe(lib_name, shape=(32, 12, 228)):
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env["STEMGNN_HIP_LIB"] = os.path.join(root, "stemgnn_amd", lib_name)
+    p = subprocess.run([sys.executable, os.path.join(root, "tests", "helpers", "gru_probe.py")] + [str(v) for v in shape],
+                       env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
+    return json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+
+
+def test_gru_hand_tuned_pauses_only_change_the_time():
+    """The wave-specialised recurrence carries five s_sleep constants calibrated on one MI355X (csrc/gru_cluster4.h).  They
+    only move memory traffic in time: the build with every pause set to 0 (libstemgnn_hip_untuned.so, made by
+    __graft_entry__.build()) must return bit-identical hidden states and gradients, never trip the exchange time-out --
+    and the test prints both timings, so a box on which the calibration no longer pays shows up in the log."""
+    import os
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not os.path.isfile(os.path.join(root, "stemgnn_amd", "libstemgnn_hip_untuned.so")):
+        pytest.skip("libstemgnn_hip_untuned.so not built (python __graft_entry__.py builds it)")
+    tuned = _gru_probe("libstemgnn_hip.so")
+    untuned = _gru_probe("libstemgnn_hip_untuned.so")
+    assert untuned["lib"] == "libstemgnn_hip_untuned.so"
+    print(f"GRU PEMS07 shape: tuned fwd {tuned['fwd_us']:.0f} us bwd {tuned['bwd_us']:.0f} us | "
+          f"no pauses fwd {untuned['fwd_us']:.0f} us bwd {untuned['bwd_us']:.0f} us")
+    assert tuned["h"] == untuned["h"] and tuned["grads"] == untuned["grads"]
+    # a mis-tuned pause may cost time, not correctness; the calibrated build must not be the slower one by a margin
+    assert tuned["fwd_us"] + tuned["bwd_us"] < 1.3 * (untuned["fwd_us"] + untuned["bwd_us"])
 
 
 def _laplacian(N, B=6, seed=0):

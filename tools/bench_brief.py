@@ -10,6 +10,8 @@ try:
             k, v["avg_launch_us"], v["frac"], v["frac_executed"], v.get("mfma_util")))
     for o in d.get("other_configs", []):
         print("  ", o["config"][:30], "%.3f ms" % o["ms_per_step"] if "ms_per_step" in o else o.get("error"))
+    for v in d.get("dtype_variants", []):
+        print("  ", v["dtype"], "%.4f ms" % v["ms_per_step"] if "ms_per_step" in v else v.get("error"))
     c = d.get("cpu_baseline")
     if c:
         print("  cpu %s: %.1f ms/step on %d threads" % (c["kind"], c["ms_per_step"], c["cores"]))
