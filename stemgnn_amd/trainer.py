@@ -35,7 +35,10 @@ BEST = "_stemgnn.pt"
 
 
 def checkpoint_path(directory, tag=None):
-    return pathlib.Path(directory) / (f"{tag}{BEST}" if tag is not None else BEST)
+    """The reference's file names (models/handler.py:21-22: ``str(epoch) if epoch else ''``): the snapshot of epoch 0
+    shares the best-model slot ``_stemgnn.pt`` there, so a reference loader finds a model after a one-epoch run without
+    validation; kept identical so the files interchange."""
+    return pathlib.Path(directory) / (f"{tag}{BEST}" if tag else BEST)
 
 
 def save_checkpoint(model, directory, tag=None):

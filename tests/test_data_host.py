@@ -103,3 +103,13 @@ def test_data_entry_points_reject_bad_arguments():
     assert lib.stemgnn_normalize_series(p, p, p, 0, p, 0, 4, None) == _lib.SG_EINVAL
     assert lib.stemgnn_eval_out_doubles(3, 5) == 3 + 15 + 9 + 45
     assert lib.stemgnn_eval_scratch_doubles(130, 3, 5) == 3 * 15 * (3 + 1) + 15
+
+
+def test_checkpoint_names_follow_the_reference():
+    """models/handler.py:21-22 names a snapshot ``str(epoch) if epoch else ''`` + '_stemgnn.pt': epoch 0 and the best model
+    share '_stemgnn.pt' (ADVICE round 2)."""
+    from stemgnn_amd.trainer import checkpoint_path
+
+    assert checkpoint_path("out").name == "_stemgnn.pt"
+    assert checkpoint_path("out", 0).name == "_stemgnn.pt"
+    assert checkpoint_path("out", 7).name == "7_stemgnn.pt"
