@@ -80,11 +80,15 @@ class TrainStep:
             # the all-reduce SUMs; the optimizer kernel applies 1 / world.  Passed per step (see _finish): the optimizer
             # object itself is left as it was, so using it elsewhere with all_reduce_mean does not double-scale
             self._grad_scale = 1.0 / world if self.collective else 1.0
-        if exact and world > 1:
+        if exact and (world > 1 or self.collective):
             # exact data-parallel mode: A and dA are averaged over the ranks inside forward / backward
-            # (two host-launched [N,N] collectives), so the step cannot be one captured graph: it runs eagerly
+            # (two [N,N] collectives).  Host-launched collectives cannot sit between the kernels of a captured graph, so the
+            # step runs eagerly -- unless one_graph asks for the collectives to be captured WITH the step (RCCL capture
+            # works on this stack, profiles/r03_rccl_probe.json): then forward, both attention collectives, backward, the
+            # gradient all-reduce and the optimizer replay as one hipGraph; a failed capture falls back to eager.
             self.state.exact_group = (group, world)
-            self.want_graph = False
+            if not self.one_graph:
+                self.want_graph = False
         self.mode = "eager"
         self._replay = None
         self._armed = False
@@ -155,7 +159,9 @@ class TrainStep:
             if rep is not None:
                 self._replay = rep
                 self.mode = "hipgraph(whole step incl. rccl all-reduce)" if self.collective else "hipgraph(whole step)"
-        if self._replay is None and self.collective:
+                if self.state.exact_group is not None:
+                    self.mode = "hipgraph(whole step incl. the exact-mode attention collectives and the rccl all-reduce)"
+        if self._replay is None and self.collective and self.state.exact_group is None:
             box = {}
 
             def part_a():

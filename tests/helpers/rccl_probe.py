@@ -18,7 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 
 
-def train_losses(collective, one_graph, steps=6):
+def train_losses(collective, one_graph, steps=6, exact=False):
     from stemgnn_amd import Model
     from stemgnn_amd.engine import TrainStep
     from stemgnn_amd.optim import FusedRMSprop
@@ -29,7 +29,7 @@ def train_losses(collective, one_graph, steps=6):
     g = torch.Generator().manual_seed(3)
     series = torch.randn(400, N, generator=g).cuda()
     hi = (torch.randperm(380, generator=g)[: steps * B] + W).cuda().view(steps, B)
-    st = TrainStep(model, opt, B, W, H, N, series=series, world=1, collective=collective, one_graph=one_graph)
+    st = TrainStep(model, opt, B, W, H, N, series=series, world=1, collective=collective, one_graph=one_graph, exact=exact)
     out = []
     for i in range(steps):
         st.run_indices(hi[i])
@@ -86,6 +86,12 @@ def main():
     if res["graph_capture_allreduce"]:
         one, mode2, p2 = train_losses(True, True)
         res.update(mode_one_graph=mode2, one_graph_equals_plain=bool(base == one and torch.equal(p0, p2)))
+        # exact data-parallel mode (attention mean / its gradient averaged over the ranks inside forward / backward) with
+        # ALL collectives captured: one rank, so the averages are identities, but the two-part attention stages and the
+        # captured collectives run; the degrees take the two-part route's summation order -> losses agree to rounding
+        ex, mode3, _ = train_losses(True, True, exact=True)
+        res.update(mode_exact_one_graph=mode3,
+                   exact_one_graph_max_rel=max(abs(a - b) / max(abs(a), 1e-12) for a, b in zip(base, ex)))
     dist.barrier()
     dist.destroy_process_group()
     print(json.dumps(res), flush=True)

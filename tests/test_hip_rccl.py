@@ -44,6 +44,8 @@ def test_rccl_single_rank_group_collectives_and_graph_capture_probe():
     if res["graph_capture_allreduce"]:                 # recorded either way; asserted only where the stack supports it
         assert res["mode_one_graph"] == "hipgraph(whole step incl. rccl all-reduce)", res
         assert res["one_graph_equals_plain"], res
+        assert res["mode_exact_one_graph"].startswith("hipgraph(whole step incl. the exact-mode"), res
+        assert res["exact_one_graph_max_rel"] < 1e-5, res
 
 
 def test_bench_launcher_branch_with_one_rank():
