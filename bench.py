@@ -368,6 +368,7 @@ def main():
         "config": {"workload": workload_name(cfg), "global_batch": world * cfg["B"], "per_gpu_batch": cfg["B"],
                    "parallelism": f"dp{world}", "launch": mode},
         "final_loss": final_loss,
+        "steps_per_s": args.steps / elapsed, "samples_per_s": world * cfg["B"] * args.steps / elapsed,   # also reported
     }
     if rank == 0:
         if not args.no_roofline:
