@@ -427,6 +427,19 @@ static inline int wg_splits(int ntiles, int K, int bk, int per_cu, int smax, int
   const int slots = 256 * per_cu * (cu_percent < 10 ? 10 : (cu_percent > 100 ? 100 : cu_percent)) / 100;
   int S = slots / (ntiles > 0 ? ntiles : 1);      // never more workgroups than slots: one straggler round doubles the time
   if (S < 1) S = 1;
+  if (S == 1 && ntiles > 0 && ntiles < slots) {
+    // between one and two tiles per slot (N = 358: 39-46 tiles on the 64 CUs the six-workgroup GRU clusters leave free)
+    // the single round leaves a third of the slots idle for the whole launch; several shorter rounds balance better:
+    // time ~ ceil(tiles S / slots) / S (+ a little per split for the reduction), e.g. 39 tiles on 64 slots: S = 3 -> 0.67
+    int best = 1;
+    double best_cost = 1.0 + 0.003;
+    for (int c = 2; c <= 8 && c <= smax; ++c) {
+      const int rounds = (ntiles * c + slots - 1) / slots;
+      const double cost = (double)rounds / c + 0.003 * c;
+      if (cost < best_cost - 1e-9) { best_cost = cost; best = c; }
+    }
+    S = best;
+  }
   if (S > smax) S = smax;
   const int min_kt = 8;                       // a split shorter than the ring depth only adds reduction traffic
   if (S > KT / min_kt) S = KT / min_kt > 0 ? KT / min_kt : 1;
