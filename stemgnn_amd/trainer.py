@@ -115,12 +115,18 @@ class DeviceTrainer:
     """Owns model + optimizer + LR schedule; `fit` runs epochs of hipGraph train steps with validation in between."""
 
     def __init__(self, units, window, horizon, multi, *, batch_size=32, lr=1e-4, optimizer="RMSProp", decay_rate=0.5,
-                 decay_every=5, norm_method="z_score", device="cuda", model_factory=None, hipgraph=True):
+                 decay_every=5, norm_method="z_score", device="cuda", model_factory=None, hipgraph=True,
+                 dropout_seed=None):
         self.units, self.window, self.horizon, self.multi = units, window, horizon, multi
         self.batch_size, self.norm_method, self.device, self.hipgraph = batch_size, norm_method, device, hipgraph
         self.decay_every = decay_every
         self.model = (model_factory or Model)(units, 2, window, multi, horizon=horizon)
         self.model.to(device)
+        if dropout_seed is not None and hasattr(self.model, "set_dropout_seed"):
+            # an explicit Philox key for the attention dropout: by default the key follows the device generator's seed AND
+            # the model's construction index in this process (two models never share a mask stream), so a run is only
+            # reproducible if models are built in the same order; naming the key removes that dependence
+            self.model.set_dropout_seed(int(dropout_seed), 0, torch.device(device))
         if optimizer == "RMSProp":
             self.optimizer = FusedRMSprop(self.model.parameters(), lr=lr, eps=1e-8)
         else:                                   # the driver's other branch (models/handler.py:128-129), fused as well
