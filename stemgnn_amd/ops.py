@@ -546,9 +546,8 @@ def prepack_blocks(state, block_params, W, multi, device):
     for blk, pk in zip(blocks, packed):
         _lib.check(lib.stemgnn_block_pack(_lib.ptr_array(blk), tables.data_ptr(), pk.data_ptr(), W, multi,
                                           side.cuda_stream), "block_pack")
-        if splits:
-            with torch.cuda.stream(side):
-                split.append(_split_panels(lib, pk, W, multi, splits, device, side.cuda_stream))
+        if splits:      # (allocated on the current stream like the packed panels; the side stream only runs the kernel)
+            split.append(_split_panels(lib, pk, W, multi, splits, device, side.cuda_stream))
     state.prepacked = (packed, side, blocks, (splits, split))
 
 
