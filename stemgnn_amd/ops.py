@@ -127,6 +127,7 @@ def _wg_cu(which, B, N):
     busy = _lib.load().stemgnn_gru_bwd_cus(B, N)
     return max(10, min(100, (256 - busy) * 100 // 256))
 _WG_SCHED = os.environ.get("STEMGNN_WG_SCHED", "late")
+_WG_FORK = os.environ.get("STEMGNN_WG_FORK", "dgrad")
 
 
 def _stream():
@@ -746,6 +747,7 @@ class SpectralHotPath(torch.autograd.Function):
         # recurrence.  "early" forks block 1's right behind its own chain, beside block 0's MFMA-bound data-gradient
         # kernels: measured 170 us SLOWER per step (two GEMM streams on one chip are zero-sum, profiles/r03_wgrad.md).
         early = overlap and defer_b1 and _WG_SCHED == "early"
+        late_fork = None
         for s in (1, 0):
             scratch = bufs[s][0]
             dG = scratch[off_dG:]
@@ -774,14 +776,24 @@ class SpectralHotPath(torch.autograd.Function):
                     if s == 0:
                         keep.append(bufs)                    # alive until the join
                 elif s == 0:
-                    side.wait_stream(main)                   # fork: every data-gradient chain is queued
-                    with torch.cuda.stream(side):
-                        sst = side.cuda_stream
-                        for ss in ((0, 1) if defer_b1 else (0,)):
-                            _h, _g, w2, u2 = (heads, glu, wgrad, unpack) if ss == 0 else stage_fns(1)
-                            w2(sst, _wg_cu(ss, B, N))
-                            u2(sst)
-                    keep.append(bufs)                        # alive until the join
+                    def launch_side(heads=heads, glu=glu, wgrad=wgrad, unpack=unpack):
+                        side.wait_stream(main)               # fork: every data-gradient chain is queued
+                        with torch.cuda.stream(side):
+                            sst = side.cuda_stream
+                            for ss in ((0, 1) if defer_b1 else (0,)):
+                                _h, _g, w2, u2 = (heads, glu, wgrad, unpack) if ss == 0 else stage_fns(1)
+                                w2(sst, _wg_cu(ss, B, N))
+                                u2(sst)
+                        keep.append(bufs)                    # alive until the join
+                    # STEMGNN_WG_FORK: where the side stream forks.  "dgrad" (default): right behind block 0's
+                    # data-gradient chain.  "cheb": behind the GFT / Chebyshev backward products, which run 125 us instead
+                    # of 45 beside the chip-filling weight-gradient launch -- but the side chain's apparent slack under the
+                    # GRU recurrence is not there: measured 1.399 / 1.398 ms per step against 1.367 / 1.368 (A/B on one
+                    # box), the later start of the second launch costs more than the uncontended kernels return
+                    if _WG_FORK == "cheb":
+                        late_fork = launch_side
+                    else:
+                        launch_side()
             else:
                 wgrad(st, 100)
                 unpack(st)
@@ -793,6 +805,8 @@ class SpectralHotPath(torch.autograd.Function):
         cheb_scratch = torch.empty(2 * N * N, device=dev, dtype=f32)
         _lib.check(lib.stemgnn_cheb_bwd(mul_L.data_ptr(), dmul_L.data_ptr(), dL.data_ptr(), cheb_scratch.data_ptr(),
                                         N, st), "cheb_bwd")
+        if late_fork is not None:
+            late_fork()
         dh = torch.empty_like(h)
         kq_direct = state.direct and wk.grad is not None and wq.grad is not None
         dwk = wk.grad if kq_direct else torch.empty_like(wk)
