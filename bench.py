@@ -15,7 +15,10 @@ Weak scaling: every rank trains on its own 32-sample batch ("replicas with a loc
 Rank 0 prints ONE JSON line: the throughput, a `roofline` object for the MFMA GEMM family with the largest summed GPU
 time per step (each family timed live with HIP events on the launch stream; `roofline_families` lists all of them),
 at N=1 a `cpu_baseline` object (the real reference when /root/reference is mounted, else the oracle port, timed on this
-box's host cores) and `other_configs`: short single-GPU runs of the per-GPU shards of BASELINE.json configs[0],[2],[3],[4].
+box's host cores) and `other_configs`: short single-GPU runs of the per-GPU shards of BASELINE.json configs[0],[2],[3],[4],
+`dtype_variants` (split-bf16 GLU products) and `spectral_variants` (the eigensolver route).  The side sections run in CHILD
+processes (`--section`), so a fault in one of them costs that section, never the headline; the headline object is also
+written to stderr as soon as it exists.
 """
 import argparse
 import json
@@ -175,9 +178,12 @@ def roofline_objects(cfg):
             "frac_executed": exe / s / 1e12 / FP32_MFMA_PEAK_TFLOPS, "avg_launch_us": t["us_per_call"] / launches,
             "launches_per_step": launches * t["calls_per_step"], "sum_us_per_step": t["us_per_call"] * t["calls_per_step"],
             "flops_algorithmic": alg / launches, "flops_executed": exe / launches,
-            "traffic": traffic.get("kernels", {}).get(name),      # HBM bytes per launch (PMC, average over the family)
-            "mfma_util": traffic.get("mfma_util", {}).get(name),
-            "traffic_source": traffic.get("source"),
+            # NOT measured in this run: constants from the committed rocprofv3 PMC passes (separate --pmc runs of this
+            # bench, tools/pmc_summary.py), HBM bytes per launch / MFMA-busy fraction averaged over the family's launches
+            "traffic": None,
+            "traffic_static_pmc": traffic.get("kernels", {}).get(name),
+            "mfma_util_static_pmc": traffic.get("mfma_util", {}).get(name),
+            "traffic_static_pmc_source": traffic.get("source"),
         }
     dominant = max(rows, key=lambda k: rows[k]["sum_us_per_step"])
     main = dict(rows[dominant])
@@ -321,6 +327,190 @@ def workload_name(cfg):
             "train step (window gather+fwd+MSE+bwd+RMSprop), dropout 0.5")
 
 
+# the reference itself on the 8-core build container (s per step), per BASELINE config -- another host,
+# shown beside the live figure of this box and labelled as such
+REFERENCE_CONTAINER_S = {
+    "configs[0]": (0.1365, "ECG shape N=140 B=32"), "configs[2]": (0.5499, "PEMS03 shape N=358 B=32"),
+    "configs[3]": (11.50, "N=1024 at the GLOBAL batch 64 (the per-GPU shard of the row is 8)"),
+    "configs[4]": (30.8, "N=2048 W=48 H=12 at the per-GPU shard batch 16"),
+}
+
+
+def cpu_steps_brief(cfg, max_s=12.0):
+    """1 warm-up + up to 2 timed train steps of the oracle port (or the reference when mounted) on this box's host cores;
+    None when one step does not finish inside `max_s` (the labelled container number stands alone then)."""
+    import torch
+    from oracle.stemgnn_oracle import OracleTrainer
+
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(cfg["B"], cfg["W"], cfg["N"], generator=g)
+    y = torch.randn(cfg["B"], cfg["H"], cfg["N"], generator=g)
+    nt = min(os.cpu_count() or 1, 16)
+    torch.set_num_threads(nt)
+    tr = OracleTrainer(cfg["N"], cfg["W"], cfg["multi"], cfg["H"], lr=1e-4, seed=0, dropout_rate=0.5)
+    t0 = time.perf_counter()
+    tr.step(x, y)
+    first = time.perf_counter() - t0
+    if first > max_s:
+        return {"kind": "port", "cores": nt, "ms_per_step": first * 1e3, "steps": 1,
+                "sample": "the single (cold) step of the torch-CPU oracle port; no second step inside the time budget"}
+    n, t0 = 0, time.perf_counter()
+    while n < 2 and time.perf_counter() - t0 < max_s:
+        tr.step(x, y)
+        n += 1
+    dt = (time.perf_counter() - t0) / n
+    return {"kind": "port", "cores": nt, "ms_per_step": dt * 1e3, "value": cfg["B"] * cfg["H"] / dt, "unit": "forecast-steps/s",
+            "steps": n, "sample": f"{n} train steps of the torch-CPU oracle port after one warm-up, {nt} threads"}
+
+
+def section_other_configs(args, dev):
+    import torch
+    others = []
+    for name, c in OTHER_CONFIGS:
+        try:
+            torch.cuda.empty_cache()
+            big = c["N"] >= 1024
+            k, w = (5, 2) if big else (30, 5)
+            el, md, _ = run_training(c, k, w, dev, 1, 0, graph=not args.no_graph, T=4096 if big else 12672)
+            row = {"config": name, "workload": workload_name(c), "ms_per_step": el / k * 1e3,
+                   "value": c["B"] * c["H"] / (el / k), "unit": "forecast-steps/s", "steps": k,
+                   "warmup": w, "n_gpus": 1, "launch": md}
+            if not args.no_roofline:        # what bounds this shape: the GEMM families' fractions + the GRU's latency floor
+                torch.cuda.empty_cache()
+                _, fams = roofline_objects(c)
+                row["roofline_families"] = {
+                    f: {q: v[q] for q in ("frac", "frac_executed", "achieved", "avg_launch_us", "sum_us_per_step",
+                                          "launches_per_step")} for f, v in fams.items()}
+                row["gru"] = time_gru(c)
+                row["gru"]["share_of_step"] = ((row["gru"]["fwd_us"] + row["gru"]["bwd_incl_weight_grads_us"])
+                                               / (row["ms_per_step"] * 1e3))
+                row["glu_gemm_share_of_step"] = sum(v["sum_us_per_step"] for v in fams.values()) / (row["ms_per_step"] * 1e3)
+            key = name.split(" ")[0]
+            cpu = {"reference_container_s_per_step": REFERENCE_CONTAINER_S[key][0],
+                   "reference_container_note": "BASELINE.md section 3 (the reference itself, 8-core build container, another "
+                                               "host): " + REFERENCE_CONTAINER_S[key][1]}
+            if not args.no_cpu_baseline and c["N"] <= 1024:      # configs[4]: 30 s per step -> the container number stands alone
+                try:
+                    cpu.update(cpu_steps_brief(c))
+                except Exception as e:  # noqa: BLE001
+                    cpu["error"] = f"{type(e).__name__}: {e}"
+            row["cpu_baseline"] = cpu
+            others.append(row)
+        except Exception as e:  # noqa: BLE001 -- a failing side line must not lose the others
+            others.append({"config": name, "error": f"{type(e).__name__}: {e}"})
+    return others
+
+
+def section_dtype_variants(args, dev, cfg):
+    """BASELINE.json configs[1] names "bf16/fp32": the headline is exact fp32 (the reference's arithmetic); the same step with
+    the GLU forward / data-gradient layers as split-bf16 products (STEMGNN_DTYPE, csrc/gemm2s.h) is reported beside it,
+    with the model-level error each setting was tested to (tests/test_hip_splitgemm.py)."""
+    import torch
+    variants = []
+    before = os.environ.get("STEMGNN_DTYPE")
+    for dt, err in (("bf16x3", "<= 4e-6 norm-relative vs the oracle (fp32 class)"),
+                    ("bf16x2", "<= 3e-5 norm-relative vs the oracle (gate: 1e-4)")):
+        os.environ["STEMGNN_DTYPE"] = dt
+        try:
+            torch.cuda.empty_cache()
+            el, md, _ = run_training(cfg, 60, 10, dev, 1, 0, graph=not args.no_graph)
+            variants.append({"dtype": dt, "ms_per_step": el / 60 * 1e3, "value": cfg["B"] * cfg["H"] / (el / 60),
+                             "unit": "forecast-steps/s", "steps": 60, "warmup": 10, "launch": md,
+                             "arithmetic": "GLU layers 1-2 forward + d(pre-activation) products on v_mfma_f32_32x32x16_bf16, "
+                                           "fp32 accumulation; everything else fp32", "tested_error": err})
+        except Exception as e:  # noqa: BLE001
+            variants.append({"dtype": dt, "error": f"{type(e).__name__}: {e}"})
+        finally:
+            if before is None:
+                os.environ.pop("STEMGNN_DTYPE", None)
+            else:
+                os.environ["STEMGNN_DTYPE"] = before
+    return variants
+
+
+def time_eigh(N, iters=10):
+    """The eigensolver stage alone (stemgnn_eigh_fwd through the C ABI, HIP events on the launch stream) on a Laplacian-like
+    symmetric matrix: microseconds per decomposition (north_star's first component; reference: none, nearest code
+    models/base_model.py:121-134)."""
+    import torch
+    from stemgnn_amd import _lib, ops
+
+    lib = _lib.load()
+    dev = torch.device("cuda")
+    g = torch.Generator().manual_seed(N)
+    A = torch.rand(N, N, generator=g)
+    A = 0.5 * (A + A.t())
+    d = A.sum(1)
+    L = (torch.diag(d) - A) / torch.sqrt(d[:, None] * d[None, :])
+    mul_L = torch.zeros(4, N, N)
+    mul_L[1] = L
+    mul_L = mul_L.to(dev)
+    lam = torch.empty(N, device=dev)
+    U = torch.empty(N, N, device=dev)
+    scr = torch.empty(lib.stemgnn_eigh_scratch_floats(N), device=dev)
+    st = torch.cuda.current_stream()
+
+    def run():
+        _lib.check(lib.stemgnn_eigh_fwd(mul_L.data_ptr(), lam.data_ptr(), U.data_ptr(), scr.data_ptr(), N, 0, st.cuda_stream), "eigh_fwd")
+    for _ in range(2):
+        run()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(st)
+    for _ in range(iters):
+        run()
+    e1.record(st)
+    e1.synchronize()
+    ops.check_eigh_status(dev)
+    return e0.elapsed_time(e1) * 1e3 / iters
+
+
+def section_spectral_variants(args, dev, cfg):
+    """north_star's eigen route (STEMGNN_SPECTRAL=eig: T_k(L) = U p_k(Lambda) U^T from stemgnn_eigh_fwd instead of the two
+    Chebyshev products): the headline step and the configs[3] shard with it, and the solver's own time."""
+    import torch
+    rows = []
+    before = os.environ.get("STEMGNN_SPECTRAL")
+    os.environ["STEMGNN_SPECTRAL"] = "eig"
+    try:
+        for name, c, k, w, T in (("configs[1] PEMS07 shape", cfg, 60, 10, 12672),
+                                 ("configs[3] N=1024 shard (batch 8)", OTHER_CONFIGS[2][1], 5, 2, 4096)):
+            try:
+                torch.cuda.empty_cache()
+                el, md, _ = run_training(c, k, w, dev, 1, 0, graph=not args.no_graph, T=T)
+                rows.append({"config": name, "spectral": "eig", "ms_per_step": el / k * 1e3,
+                             "value": c["B"] * c["H"] / (el / k), "unit": "forecast-steps/s", "steps": k, "warmup": w,
+                             "launch": md, "eigh_us": time_eigh(c["N"]), "N": c["N"]})
+            except Exception as e:  # noqa: BLE001
+                rows.append({"config": name, "spectral": "eig", "error": f"{type(e).__name__}: {e}"})
+    finally:
+        if before is None:
+            os.environ.pop("STEMGNN_SPECTRAL", None)
+        else:
+            os.environ["STEMGNN_SPECTRAL"] = before
+    return rows
+
+
+SECTIONS = ("other_configs", "dtype_variants", "spectral_variants")
+
+
+def run_section_child(name, args):
+    """Run one side section in a child process (`bench.py --section name`): a GPU fault or abort there costs that section,
+    not the headline.  Returns the child's JSON (or an error object)."""
+    cmd = [sys.executable, os.path.abspath(__file__), "--section", name]
+    for flag, on in (("--no-graph", args.no_graph), ("--no-roofline", args.no_roofline), ("--no-cpu-baseline", args.no_cpu_baseline)):
+        if on:
+            cmd.append(flag)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    try:
+        p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    except subprocess.TimeoutExpired:
+        return {"error": "section timed out after 900 s"}
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{") or ln.startswith("[")]
+    if p.returncode != 0 or not lines:
+        return {"error": f"child exited with {p.returncode}", "stderr_tail": p.stderr[-400:]}
+    return json.loads(lines[-1])
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -328,10 +518,22 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-other-configs", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip every side section (other_configs, dtype / spectral variants)")
     ap.add_argument("--no-roofline", action="store_true",
                     help="skip the isolated GEMM-family timing loops (for a kernel trace that holds in-step launches only)")
+    ap.add_argument("--section", choices=SECTIONS, help="internal: run ONE side section and print its JSON (child process)")
     args = ap.parse_args()
+
+    if args.section:
+        import torch
+        torch.cuda.set_device(0)
+        dev = torch.device("cuda", 0)
+        cfg = bench_workload()
+        res = {"other_configs": lambda: section_other_configs(args, dev),
+               "dtype_variants": lambda: section_dtype_variants(args, dev, cfg),
+               "spectral_variants": lambda: section_spectral_variants(args, dev, cfg)}[args.section]()
+        print(json.dumps(res), flush=True)
+        return
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         _self_launch(args)
@@ -346,18 +548,15 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     # Under a launcher (RANK / WORLD_SIZE in the environment) the run is a data-parallel job even with ONE rank: the RCCL
-    # process group is created and the step runs the collective form (graph / all-reduce / graph) -- what the N > 1 runs
-    # execute, testable on a 1-GPU box.  Plain `python bench.py` (the driver's N = 1 line) has no process group.
+    # process group is created and the step runs the collective form -- what the N > 1 runs execute, testable on a 1-GPU
+    # box.  Plain `python bench.py` (the driver's N = 1 line) has no process group.
     launched = "WORLD_SIZE" in os.environ and "RANK" in os.environ
     if world > 1 or launched:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    cfg = dict(WORKLOAD)
-    if os.environ.get("STEMGNN_BENCH_WORKLOAD"):     # "N,W,H,multi,B": another shape as the main line (experiments only)
-        vals = [int(v) for v in os.environ["STEMGNN_BENCH_WORKLOAD"].split(",")]
-        cfg = dict(zip(("N", "W", "H", "multi", "B"), vals))
+    cfg = bench_workload()
     elapsed, mode, final_loss = run_training(cfg, args.steps, args.warmup, dev, world, rank, graph=not args.no_graph,
                                              collective=True if (world > 1 or launched) else None)
     out = {
@@ -371,60 +570,30 @@ def main():
         "steps_per_s": args.steps / elapsed, "samples_per_s": world * cfg["B"] * args.steps / elapsed,   # also reported
     }
     if rank == 0:
+        print("bench headline (complete line follows on stdout): " + json.dumps(out), file=sys.stderr, flush=True)
         if not args.no_roofline:
             out["roofline"], out["roofline_families"] = roofline_objects(cfg)
             out["gru"] = time_gru(cfg)
             out["gru"]["share_of_step"] = (out["gru"]["fwd_us"] + out["gru"]["bwd_incl_weight_grads_us"]) / (out["ms_per_step"] * 1e3)
-        if world == 1 and not launched and not args.no_other_configs:
-            others = []
-            for name, c in OTHER_CONFIGS:
-                try:
-                    torch.cuda.empty_cache()
-                    big = c["N"] >= 1024
-                    k, w = (5, 2) if big else (30, 5)
-                    el, md, _ = run_training(c, k, w, dev, 1, 0, graph=not args.no_graph, T=4096 if big else 12672)
-                    row = {"config": name, "workload": workload_name(c), "ms_per_step": el / k * 1e3,
-                           "value": c["B"] * c["H"] / (el / k), "unit": "forecast-steps/s", "steps": k,
-                           "warmup": w, "n_gpus": 1, "launch": md}
-                    if not args.no_roofline:        # what bounds this shape: the GEMM families' fractions + the GRU's latency floor
-                        torch.cuda.empty_cache()
-                        _, fams = roofline_objects(c)
-                        row["roofline_families"] = {
-                            f: {q: v[q] for q in ("frac", "frac_executed", "achieved", "avg_launch_us", "sum_us_per_step",
-                                                  "launches_per_step")} for f, v in fams.items()}
-                        row["gru"] = time_gru(c)
-                        row["gru"]["share_of_step"] = ((row["gru"]["fwd_us"] + row["gru"]["bwd_incl_weight_grads_us"])
-                                                       / (row["ms_per_step"] * 1e3))
-                        row["glu_gemm_share_of_step"] = sum(v["sum_us_per_step"] for v in fams.values()) / (row["ms_per_step"] * 1e3)
-                    others.append(row)
-                except Exception as e:  # noqa: BLE001 -- a failing side line must not lose the headline
-                    others.append({"config": name, "error": f"{type(e).__name__}: {e}"})
-            out["other_configs"] = others
-            # BASELINE.json configs[1] names "bf16/fp32": the headline above is exact fp32 (the reference's arithmetic); the same
-            # step with the GLU forward / data-gradient layers as split-bf16 products (STEMGNN_DTYPE, csrc/gemm2s.h) is
-            # reported beside it, with the model-level error each setting was tested to (tests/test_hip_splitgemm.py)
-            variants = []
-            for dt, err in (("bf16x3", "<= 4e-6 norm-relative vs the oracle (fp32 class)"),
-                            ("bf16x2", "<= 3e-5 norm-relative vs the oracle (gate: 1e-4)")):
-                os.environ["STEMGNN_DTYPE"] = dt
-                try:
-                    torch.cuda.empty_cache()
-                    el, md, _ = run_training(cfg, 60, 10, dev, 1, 0, graph=not args.no_graph)
-                    variants.append({"dtype": dt, "ms_per_step": el / 60 * 1e3, "value": cfg["B"] * cfg["H"] / (el / 60),
-                                     "unit": "forecast-steps/s", "steps": 60, "warmup": 10, "launch": md,
-                                     "arithmetic": "GLU layers 1-2 forward + d(pre-activation) products on v_mfma_f32_32x32x16_bf16, "
-                                                   "fp32 accumulation; everything else fp32", "tested_error": err})
-                except Exception as e:  # noqa: BLE001
-                    variants.append({"dtype": dt, "error": f"{type(e).__name__}: {e}"})
-                finally:
-                    os.environ.pop("STEMGNN_DTYPE", None)
-            out["dtype_variants"] = variants
-        if world == 1 and not launched and not args.no_cpu_baseline:
+        solo = world == 1 and not launched
+        if solo and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg)
+        if solo and not args.no_other_configs:
+            torch.cuda.empty_cache()
+            for name in SECTIONS:
+                out[name] = run_section_child(name, args)
         print(json.dumps(out), flush=True)
     if dist.is_initialized():
         dist.barrier()                      # rank 0 may still be timing the roofline kernels
         dist.destroy_process_group()
+
+
+def bench_workload():
+    cfg = dict(WORKLOAD)
+    if os.environ.get("STEMGNN_BENCH_WORKLOAD"):     # "N,W,H,multi,B": another shape as the main line (experiments only)
+        vals = [int(v) for v in os.environ["STEMGNN_BENCH_WORKLOAD"].split(",")]
+        cfg = dict(zip(("N", "W", "H", "multi", "B"), vals))
+    return cfg
 
 
 if __name__ == "__main__":

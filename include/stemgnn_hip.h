@@ -34,6 +34,8 @@ extern "C" {
 
 /* library / build identification: returns a static string "stemgnn_hip <version> gfx950". */
 const char* stemgnn_version(void);
+/* compute units of the current HIP device (256 on MI355X): the launch-sizing formulas use it, never a constant */
+int stemgnn_num_cus(void);
 
 /* ---- sizes (in floats) of the caller-allocated buffers ----------------------------------------- */
 size_t stemgnn_table_floats(int W, int multi);                       /* DFT / C2R tables            */
@@ -93,8 +95,8 @@ int stemgnn_cheb_bwd(const float* mul_L, const float* dmul_L, float* dL, float* 
  *   nsweeps  > 0 : parallel one-sided Jacobi (one launch per tournament round, fp64 rotation parameters), one
  *                  Newton-Schulz re-orthogonalisation and Rayleigh quotients on MFMA.
  * lam [N] (ascending for the direct solver); U [N,N] with the eigenvectors in ROWS; scratch:
- * stemgnn_eigh_scratch_floats(N) (16-byte aligned).  stemgnn_eigh_status(): host-synchronous read of the solver's
- * status word of the CURRENT device (0 ok, 2 = a grid-barrier wait of the tridiagonalisation timed out, 3 = a cluster
+ * stemgnn_eigh_scratch_floats(N) (16-byte aligned).  stemgnn_eigh_status(): host-synchronous read-and-clear of the
+ * solver's status word of the CURRENT device (0 ok, 2 = a grid-barrier wait of the tridiagonalisation timed out, 3 = a cluster
  * re-solve broke down).  stemgnn_eigh_cluster_fixes(): host-synchronous read-and-clear of the number of eigenvectors the
  * cluster pass re-orthogonalised on the current device (diagnostic; 0 for a spectrum without clusters). */
 size_t stemgnn_eigh_scratch_floats(int N);
@@ -147,15 +149,11 @@ int stemgnn_gru_bwd_cus(int B, int Hd);
 int stemgnn_gru_fwd(const float* x, const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh,
                     int B, int S, int Hd, int W, float* scratch, float* h_ext, float* reserve, int* status,
                     void* stream);
-/* dh_all [S,B,Hd] = gradient of every output step -> dw_ih, dw_hh, db_ih, db_hh (x gets no gradient).
- * side_stream / side_stream2 (both or neither; NULL = everything on `stream`): two more hipStream_t of the caller.
- * With them the recurrence runs as STEMGNN_GRU_SEGMENTS (4) time segments and the weight-gradient reductions of a
- * finished segment run on the side streams under the next segment's recurrence; the call forks from and joins back to
- * `stream` with events (capturable), so on return everything is again ordered on `stream`. */
+/* dh_all [S,B,Hd] = gradient of every output step -> dw_ih, dw_hh, db_ih, db_hh (x gets no gradient); everything is
+ * ordered on `stream` (the side-stream schedules of round 2 were measured slower and removed in round 4). */
 int stemgnn_gru_bwd(const float* dh_all, const float* x, const float* w_hh, const float* h_ext,
                     const float* reserve, int B, int S, int Hd, int W, float* scratch,
-                    float* dw_ih, float* dw_hh, float* db_ih, float* db_hh, int* status, void* stream,
-                    void* side_stream, void* side_stream2);
+                    float* dw_ih, float* dw_hh, float* db_ih, float* db_hh, int* status, void* stream);
 
 /* ---- weight packing (per StockBlock, once per optimizer step) -----------------------------------
  * Folds the length-W DFT (:49-51) into the first GLU layer, drops the dead C2R bins,
@@ -222,6 +220,10 @@ int stemgnn_igft_heads_bwd(const float* const* params_host, const float* packed,
                            const float* dforecast, const float* dbackcast, const float* backcast,
                            float* scratch, float* gradpart, int nsplit, int parts,
                            int B, int N, int W, int multi, void* stream);
+
+/* Stand-alone block with a differentiable input only: the short-cut head's direct term (models/base_model.py:71-72),
+ * dX [M,W] -= dpB BS_w, with dpB taken from the scratch the data part (parts & 1) of stemgnn_igft_heads_bwd filled. */
+int stemgnn_shortcut_dx(const float* scratch, const float* bs_w, float* dX, int B, int N, int W, int multi, void* stream);
 
 /* ALL weight gradients of one StockBlock (autograd of models/base_model.py:12-13, 66-74 via models/handler.py:164): the
  * six GLU products and the heads' FR / F / BC / graph-conv products in ONE launch of the fused weight-gradient kernel

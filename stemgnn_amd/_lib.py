@@ -17,6 +17,7 @@ _PP = POINTER(c_void_p)  # host array of device pointers
 # name -> (restype, argtypes); mirrors include/stemgnn_hip.h one to one
 SIGNATURES = {
     "stemgnn_version": (c_char_p, []),
+    "stemgnn_num_cus": (c_int, []),
     "stemgnn_table_floats": (c_size_t, [c_int, c_int]),
     "stemgnn_packed_floats": (c_size_t, [c_int, c_int]),
     "stemgnn_saved_floats": (c_size_t, [c_int, c_int, c_int, c_int]),
@@ -44,12 +45,13 @@ SIGNATURES = {
     "stemgnn_glu_combine_fwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, _P]),
     "stemgnn_glu_combine_bwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, _P]),
     "stemgnn_colsum": (c_int, [_P, c_int, c_int, _P, _P]),
+    "stemgnn_shortcut_dx": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "stemgnn_gru_reserve_floats": (c_size_t, [c_int, c_int, c_int]),
     "stemgnn_gru_fwd_scratch_floats": (c_size_t, [c_int, c_int, c_int]),
     "stemgnn_gru_bwd_scratch_floats": (c_size_t, [c_int, c_int, c_int, c_int]),
     "stemgnn_gru_bwd_cus": (c_int, [c_int, c_int]),
     "stemgnn_gru_fwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P]),
-    "stemgnn_gru_bwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "stemgnn_gru_bwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P]),
     "stemgnn_fc_tail_supported": (c_int, [c_int, c_int]),
     "stemgnn_fc_tail_scratch_floats": (c_size_t, [c_int, c_int, c_int, c_int]),
     "stemgnn_fc_tail_fwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P]),

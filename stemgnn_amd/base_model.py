@@ -153,7 +153,7 @@ class Model(nn.Module):
                 and not torch.cuda.is_current_stream_capturing():
             ops.check_gru_status(dev)
             if os.environ.get("STEMGNN_SPECTRAL", "cheb") == "eig":
-                ops.check_eigh_status()
+                ops.check_eigh_status(dev)
         return out
 
     # -- forward --------------------------------------------------------------------------------------
@@ -169,7 +169,7 @@ class Model(nn.Module):
         device = device or self.weight_key.device
         blocks = (self.stock_block[0].hip_params(), self.stock_block[1].hip_params())
         ops.prepack_blocks(hs, blocks, self.time_step, self.multi_layer, device)
-        if self.training and self.dropout_rate > 0.0 and os.environ.get("STEMGNN_SEED_SIDE", "1") == "1":
+        if self.training and self.dropout_rate > 0.0:
             with torch.cuda.stream(ops._side_stream(device)):
                 hs.preseed = self._next_seed(device)
 
@@ -207,23 +207,24 @@ class Model(nn.Module):
         the loss and both their backwards fused into one autograd node (two launches instead of five; forecast itself is
         not materialised).  `loss_out` / `accum`: optional static float32 scalar to write the loss into / float64 scalar
         that receives += loss.  `unit_grad`: the caller promises ``loss.backward()`` with an upstream gradient of 1 (what
-        the driver does), which lets direct-gradient mode write the fc gradients in place.  Falls back to forward() +
-        ops.mse_loss when the fused kernels do not cover (time_step, horizon)."""
-        if not _lib.load().stemgnn_fc_tail_supported(self.time_step, self.horizon):
-            forecast, _ = self.forward(x)
-            return ops.mse_loss(forecast, target, loss_out, accum)
+        the driver does), which lets direct-gradient mode write the fc gradients in place (only honoured while autograd is
+        recording: a logging call under ``torch.no_grad()`` never touches ``p.grad``)."""
+        self._require_fc_tail()
         fsum, _attention, _ = self.hot_path(x)
         return FcTailMse.apply(fsum, target, self.fc[0].weight, self.fc[0].bias, self.fc[2].weight, self.fc[2].bias,
-                               self.hot_state, loss_out, accum, unit_grad)
+                               self.hot_state, loss_out, accum, bool(unit_grad) and torch.is_grad_enabled())
+
+    def _require_fc_tail(self):
+        """The fc tail kernels (csrc/tail.hip) keep both weight matrices of a row block in LDS: time_step <= 64 and
+        horizon <= 32 (every BASELINE configuration; the reference's own runs use 12 / 3).  No torch fallback exists."""
+        if not _lib.load().stemgnn_fc_tail_supported(self.time_step, self.horizon):
+            raise _lib.StemGNNHipError(f"fc tail: time_step={self.time_step}, horizon={self.horizon} outside the HIP kernels' "
+                                       "range (time_step <= 64, horizon <= 32); stemgnn_amd has no torch fallback")
 
     def forward(self, x):
+        self._require_fc_tail()
         fsum, attention, _ = self.hot_path(x)
-        if _lib.load().stemgnn_fc_tail_supported(self.time_step, self.horizon):
-            # fused fc tail (csrc/tail.hip): Linear - LeakyReLU - Linear and the permute to [B,H,N] in one kernel;
-            # for H == 1 the reference's unsqueeze/squeeze (:176-177) yields the same [B,1,N] tensor
-            return FcTail.apply(fsum, self.fc[0].weight, self.fc[0].bias, self.fc[2].weight, self.fc[2].bias,
-                                self.hot_state), attention
-        forecast = self.fc(fsum)                                   # [B,N,H]  (:175)
-        if forecast.size(-1) == 1:                                 # (:176-177)
-            return forecast.unsqueeze(1).squeeze(-1), attention
-        return forecast.permute(0, 2, 1).contiguous(), attention   # (:178-179)
+        # fused fc tail (csrc/tail.hip, models/base_model.py:175-179): Linear - LeakyReLU - Linear and the permute to [B,H,N]
+        # in one kernel; for H == 1 the reference's unsqueeze/squeeze (:176-177) yields the same [B,1,N] tensor
+        return FcTail.apply(fsum, self.fc[0].weight, self.fc[0].bias, self.fc[2].weight, self.fc[2].bias,
+                            self.hot_state), attention

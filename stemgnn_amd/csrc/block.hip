@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 
 #include "../../include/stemgnn_hip.h"
+#include "devattr.h"
 #include "gemm2.h"
 #include "gemm2s.h"
 #include "gemm_core.h"
@@ -16,7 +17,6 @@
 #include "reduce.h"
 #include "wgrad.h"
 #include "heads.h"
-#include "rgemm.h"
 
 #define SG_TRY(e)                                \
   do {                                           \
@@ -161,148 +161,6 @@ struct GluFwdEpi {
   }
 };
 
-// =================================================================================================
-// Fused forward of the three GLU layers of one branch for a block of 64 series rows (the layers are row-local):
-// the activations of a row block never leave the CU between layers.  LDS: two K-major activation buffers
-// [KA][65] (input / output of the current layer, swapped per layer) + the double-buffered 16 x 128 weight tile.
-// Per layer and 128-column tile: the A fragments come straight from the resident activation buffer, the weight
-// panel streams from L2; the epilogue stores out / gate for the backward pass (fire and forget: the stores drain
-// under the next tile's MFMAs) and drops `out` into the next layer's input buffer.  No launch boundaries, no
-// per-layer prologue, no A traffic.  8 waves = 2 x 4, each one 32 x 32 MFMA tile.
-// =================================================================================================
-constexpr int G3_BM = 64, G3_LDA = 65, G3_BK = 32;
-struct G3Args {
-  const float* G;               // [M][KG]
-  const float* Wp[2][3];        // packed K_in x NP panels
-  const float* bias[2][3];
-  float* out[2][3];
-  float* gate[2][3];
-  int kin[3], np[2][3], cp[2][3];
-  int KG, M, KA;
-  int dbg;                      // phase-ablation bits (-DSG_G2_DEBUG builds only): 1 no epilogue, 2 no MFMA, 4 no weight loads
-};
-
-template <bool VEC>
-__global__ __launch_bounds__(512) void sg_glu3_fwd(const G3Args g) {
-  extern __shared__ __attribute__((aligned(16))) float g3_smem[];
-  float* in = g3_smem;
-  float* outb = in + (size_t)g.KA * G3_LDA;
-  float* bs = outb + (size_t)g.KA * G3_LDA;
-  const int r = blockIdx.y, m0 = blockIdx.x * G3_BM;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 2, wn = wave & 3;          // 8 waves = 2 x 4, each 32 rows x 32 pair columns (one MFMA tile):
-  const int M = g.M;                                // two waves per SIMD hide each other's LDS / barrier latency
-  {  // stage the G rows of this block, K-major, zero padded to a multiple of 16 in k
-    const int KG = g.KG, kpad = (KG + 15) & ~15;
-    for (int idx = tid; idx < G3_BM * kpad; idx += 512) {
-      const int i = idx / kpad, k = idx - i * kpad;
-      const int row = m0 + i;
-      const float v = g.G[(size_t)(row < M ? row : 0) * KG + (k < KG ? k : 0)];
-      in[k * G3_LDA + i] = (row < M && k < KG) ? v : 0.f;
-    }
-  }
-  __syncthreads();
-  const int fi = lane & 31, fk = lane >> 5;
-  const bool right = (lane & 16) != 0;
-  const int kq = lane & 15;
-  // weight tile 32 x 128 (G3_BK = 32: one K tile of MFMAs, ~1 us for the two waves of a SIMD, covers the L2 latency
-  // of the next tile's prefetch): two float4 per thread, rows bk and bk + 16
-  const int bk = tid >> 5, bj = (tid & 31) << 2;
-  auto bload = [&](const float* __restrict__ Wp, int N, int n0, int k, int K) -> float4 {
-    const int j = n0 + bj;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if constexpr (VEC) {
-      const bool ok = k < K && j < N;                     // N % 4 == 0 always (pair panels are multiples of 32 wide)
-      const float4 x = *reinterpret_cast<const float4*>(Wp + (size_t)(ok ? k : 0) * N + (ok ? j : 0));
-      if (ok) v = x;
-    } else {
-      const float* p = Wp + (size_t)(k < K ? k : 0) * N;
-      const bool ko = k < K;
-      const float a = p[j < N ? j : 0], b = p[j + 1 < N ? j + 1 : 0], c = p[j + 2 < N ? j + 2 : 0], d = p[j + 3 < N ? j + 3 : 0];
-      v = make_float4(ko && j < N ? a : 0.f, ko && j + 1 < N ? b : 0.f, ko && j + 2 < N ? c : 0.f, ko && j + 3 < N ? d : 0.f);
-    }
-    return v;
-  };
-  // flat loop over (layer, 128-column tile).  The first weight tile of the NEXT (layer, column tile) is requested
-  // before the epilogue of the current one: its latency hides under the epilogue, and -- vmcnt retires in order --
-  // the K loop's waits for weight tiles never have to wait for the epilogue's out / gate stores to drain.
-  int l = 0, n0 = 0;
-  float4 rb0 = bload(g.Wp[r][0], g.np[r][0], 0, bk, g.kin[0]), rb1 = bload(g.Wp[r][0], g.np[r][0], 0, bk + 16, g.kin[0]);
-#pragma unroll 1
-  while (l < 3) {
-    const int K = g.kin[l], N = g.np[r][l], cp = g.cp[r][l];
-    const float* __restrict__ Wp = g.Wp[r][l];
-    const float* __restrict__ bp = g.bias[r][l];
-    sg_f32x16 acc;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-    *reinterpret_cast<float4*>(bs + bk * G2_LD + bj) = rb0;
-    *reinterpret_cast<float4*>(bs + (bk + 16) * G2_LD + bj) = rb1;
-    __syncthreads();            // weight tile 0 staged; at a layer change also: the new input buffer is complete
-    int buf = 0;
-    for (int kb = 0; kb < K; kb += G3_BK) {
-      const bool more = kb + G3_BK < K;
-      if (more && !G2_DBG(g, 4)) {
-        rb0 = bload(Wp, N, n0, kb + G3_BK + bk, K);
-        rb1 = bload(Wp, N, n0, kb + G3_BK + bk + 16, K);
-      }
-      const float* Bs = bs + buf * (G3_BK * G2_LD) + wn * 32 + fi;
-      const float* As = in + (size_t)kb * G3_LDA + wm * 32 + fi;
-      if (!G2_DBG(g, 2)) {
-#pragma unroll
-        for (int ks = 0; ks < 16; ks += 2)
-          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[(ks + fk) * G3_LDA], Bs[(ks + fk) * G2_LD], acc, 0, 0, 0);
-      }
-      if (kb + 16 < K && !G2_DBG(g, 2)) {                   // second half of the tile (K % 32 may be 16)
-#pragma unroll
-        for (int ks = 16; ks < 32; ks += 2)
-          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[(ks + fk) * G3_LDA], Bs[(ks + fk) * G2_LD], acc, 0, 0, 0);
-      }
-      if (more) {
-        float* Bn = bs + (buf ^ 1) * (G3_BK * G2_LD);
-        *reinterpret_cast<float4*>(Bn + bk * G2_LD + bj) = rb0;
-        *reinterpret_cast<float4*>(Bn + (bk + 16) * G2_LD + bj) = rb1;
-      }
-      __syncthreads();
-      buf ^= 1;
-    }
-    // next (layer, column tile); request its first weight tile now
-    int ln = l, nn = n0 + 128;
-    if (nn >= N) { ln = l + 1; nn = 0; }
-    if (ln < 3) {
-      rb0 = bload(g.Wp[r][ln], g.np[r][ln], nn, bk, g.kin[ln]);
-      rb1 = bload(g.Wp[r][ln], g.np[r][ln], nn, bk + 16, g.kin[ln]);
-    }
-    if (!G2_DBG(g, 1)) {
-      // epilogue: the 32 pair columns of this wave are 16 left | 16 right values of 16 channels
-      const int col0 = n0 + wn * 32;
-      const bool live = col0 < N;
-      const float bl = live ? bp[col0 + kq] : 0.f, br = live ? bp[col0 + 16 + kq] : 0.f;
-      const int c = (col0 >> 1) + kq;
-      float* dst = (right ? g.gate[r][l] : g.out[r][l]) + c;
-      float* nx = outb + (size_t)c * G3_LDA + wm * 32;
-#pragma unroll
-      for (int reg = 0; reg < 16; ++reg) {
-        const float mine = acc[reg];
-        const float other = __shfl_xor(mine, 16, 64);
-        const float u = (right ? other : mine) + bl, v = (right ? mine : other) + br;
-        const float gs = sg_sigmoid(v);
-        const int rl = g2_row_of(reg, lane);
-        const int row = m0 + wm * 32 + rl;
-        const float o = u * gs;
-        if (live) {
-          if (row < M) dst[(size_t)row * cp] = right ? gs : o;
-          if (l < 2 && !right) nx[rl] = row < M ? o : 0.f;
-        }
-      }
-    } else if (acc[0] + acc[7] == 1.2345e-30f) {
-      bs[0] = 1.f;
-    }
-    if (ln != l) { float* t = in; in = outb; outb = t; }     // layer change: the output buffer becomes the input
-    l = ln; n0 = nn;
-  }
-}
-
 // data gradient of layer l -> d(pre-activation) of layer l-1 in pair order:
 //   d = dX[row][c];  left: d * gate ; right: d * out * (1 - gate)       (GLU backward)
 struct GluDpreEpi {
@@ -354,83 +212,6 @@ struct GluDpreEpi {
             if (cl_hi) q[32] = hi ? right : recv;           // [L(cb+16..) | R(cb+16..)]
           }
           (void)cl;
-        }
-      }
-    }
-  }
-};
-
-// ---- epilogues of the ring-pipelined GEMM (rgemm.h) ------------------------------------------------------------------
-// forward: MFMA tile 0 = linear_left, tile 1 = linear_right of the SAME 32 channels (the DMA de-interleaves the pair
-// panel), so u, v of a channel sit in one lane: no exchange, 128 contiguous bytes per row and store
-struct RgGluFwdEpi {
-  static constexpr bool PAIR = true;
-  const float* bp[2];      // packed bias, pair order
-  float* out[2];
-  float* gate[2];
-  int cp[2];               // padded channels of this layer (= N / 2)
-  __device__ void tile(int r, int row0, int col0, int M, int N, const sg_f32x16 (&acc)[2][2], int lane) const {
-    const int L = lane & 31;
-    const int c = (col0 >> 1) + L;                       // channel
-    const int ld = cp[r];
-    if (c >= ld) return;
-    const int q = ((c >> 4) << 5) + (c & 15);            // pair column of the left value
-    const float bl = bp[r][q], br = bp[r][q + 16];
-    float* po = out[r] + c;
-    float* pg = gate[r] + c;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int reg = 0; reg < 16; ++reg) {
-        const int row = row0 + i * 32 + g2_row_of(reg, lane);
-        const float u = acc[i][0][reg] + bl, v = acc[i][1][reg] + br;
-        const float gt = sg_sigmoid(v);
-        if (row < M) {
-          po[(size_t)row * ld] = u * gt;
-          pg[(size_t)row * ld] = gt;
-        }
-      }
-    (void)N;
-  }
-};
-// data gradient of layer l -> d(pre-activation) of layer l-1 (pair order): d = dX[row][c]; left: d * gate; right:
-// d * out * (1 - gate).  A lane owns channel c of two MFMA tiles; lanes 0-15 / 16-31 of a tile write the two 64-byte
-// halves [L16 | . ] of consecutive pair groups.
-struct RgGluDpreEpi {
-  static constexpr bool PAIR = false;
-  const float* out[2];
-  const float* gate[2];
-  float* dpre[2];
-  int cp;                  // channels of layer l-1 (= N); its pair panel is 2*cp wide
-  __device__ void tile(int r, int row0, int col0, int M, int N, const sg_f32x16 (&acc)[2][2], int lane) const {
-    const int L = lane & 31;
-    const float* po = out[r];
-    const float* pg = gate[r];
-    float* pd = dpre[r];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int c = col0 + j * 32 + L;
-      if (c >= N) continue;
-      const int q = ((c >> 4) << 5) + (c & 15);
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        float y[16], gt[16];
-#pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-          const int row = row0 + i * 32 + g2_row_of(reg, lane);
-          const size_t o = (size_t)(row < M ? row : 0) * cp + c;
-          y[reg] = po[o];
-          gt[reg] = pg[o];
-        }
-#pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-          const int row = row0 + i * 32 + g2_row_of(reg, lane);
-          const float d = acc[i][j][reg];
-          if (row < M) {
-            float* dst = pd + (size_t)row * 2 * cp + q;
-            dst[0] = d * gt[reg];
-            dst[16] = d * y[reg] * (1.f - gt[reg]);
-          }
         }
       }
     }
@@ -663,47 +444,18 @@ struct HeadsWgradOp {
 // =================================================================================================
 // host side
 // =================================================================================================
-// which GLU GEMM families use 64-row tiles (more, smaller workgroups): bit 0 forward, 1 data gradient, 2 weight gradient
-static inline int g2_bm_mask() {
-  static const int m = getenv("STEMGNN_G2_BM64") ? atoi(getenv("STEMGNN_G2_BM64")) : 3;   // measured: 1.921 -> 1.890 ms/step
-  return m;
-}
-// small graph products (N <= 512) with 128-deep K tiles; STEMGNN_CHEB_BK=64 restores the round-1 tiles
-static inline bool sg_small_bk128() {
-  static const bool on = !(getenv("STEMGNN_CHEB_BK") && atoi(getenv("STEMGNN_CHEB_BK")) == 64);
-  return on;
-}
-// which GLU GEMM families use 32-deep LDS stages (gemm2.h BK = 32, 64-row tiles only): bit 0 forward, 1 data gradient,
-// 2 weight gradient
-static inline int g2_bk32_mask() {
-  static const int m = getenv("STEMGNN_G2_BK32") ? atoi(getenv("STEMGNN_G2_BK32")) : 0;
-  return m;
-}
+// GLU forward / data-gradient launches use 64-row gemm2 tiles (more, smaller workgroups: 1.921 -> 1.890 ms per step in
+// round 1), the slab weight-gradient fallback 128-row tiles; small graph products (N <= 512) use 128-deep K tiles.
+// (Round 4 removed the switches of measured-and-rejected variants: 32-deep LDS stages, the ring-pipelined per-layer GEMM
+// and the first fused three-layer kernel -- see DESIGN.md section 4 for their numbers.)
 // reductions longer than this use the two-level accumulating instantiations (large W*multi configurations)
 constexpr int SG_LONG_K = 640;
-// ring-pipelined GLU forward / data-gradient GEMM (rgemm.h): parity-tested, measured NOT faster than the sg_gemm2 tiles at
-// the headline shape (K = 240 per layer: 15 ring stages per tile, the ramp and the epilogue dominate; forward 18.8 / 44.7 /
-// 33.0 us against 17.8 / 45.6 / 28.1, data gradient 37.7 / 57.3 against 31.8 / 50.8 -- profiles/r03_wgrad.md) -> opt-in
-static inline bool heads_fused_on() {
-  static const int v = getenv("STEMGNN_HEADS_FUSED") ? atoi(getenv("STEMGNN_HEADS_FUSED")) : 1;
-  return v != 0;
-}
-static inline bool rg_on() {
-  static const int v = getenv("STEMGNN_RG") ? atoi(getenv("STEMGNN_RG")) : 0;
-  return v != 0;
-}
-static inline bool wg_fused_on() {
-  static const int v = getenv("STEMGNN_WG_FUSED") ? atoi(getenv("STEMGNN_WG_FUSED")) : 1;
-  return v != 0;
-}
 // The fused weight-gradient kernel runs ONE workgroup per CU: it wins while the launch's output tiles (x splits) fit the
 // chip in one round.  With more tiles than CUs (W = 48: 540 tiles of the six GLU products) the tiles run in 2-3 uneven
 // rounds without any split, and the per-layer slab GEMMs (several short workgroups per CU) are faster -- measured at
-// configs[4] (N = 2048, W = 48, batch 16): 94.0 ms per step fused, 86.7 ms on the slab path.  STEMGNN_WG_MAX_TILES moves it.
-static inline bool wg_tiles_fit(WgGemm* q, int n) {
-  static const int lim = getenv("STEMGNN_WG_MAX_TILES") ? atoi(getenv("STEMGNN_WG_MAX_TILES")) : 256;
-  return wg_tile_index(q, n) <= lim;
-}
+// configs[4] (N = 2048, W = 48, batch 16): 94.0 ms per step fused, 86.7 ms on the slab path.
+constexpr int SG_WG_MAX_TILES = 256;
+static inline bool wg_tiles_fit(WgGemm* q, int n) { return wg_tile_index(q, n) <= SG_WG_MAX_TILES; }
 static inline int split_chunk(int M, int S) { return ((M + S - 1) / S + 15) & ~15; }
 
 extern "C" int stemgnn_gft_fwd(const float* mul_L, const float* X, long xs_b, long xs_n, long xs_t,
@@ -711,7 +463,7 @@ extern "C" int stemgnn_gft_fwd(const float* mul_L, const float* X, long xs_b, lo
   if (!mul_L || !X || !G || B <= 0 || N <= 0 || W <= 0) return SG_EINVAL;
   GftFwdOp op{mul_L + (size_t)N * N, XView{X, xs_b, xs_n, xs_t, N}, G, B, N, W};
   hipStream_t st = (hipStream_t)stream;
-  if (sg_small_bk128() && N <= 512) {       // latency-bound at small N: half as many load -> LDS -> MFMA rounds
+  if (N <= 512) {       // latency-bound at small N: half as many load -> LDS -> MFMA rounds
     if (xs_n == 1) SG_TRY((sg_launch_gemm<GftFwdOp, 32, 32, true, true, false, 128, true>(op, 3 * N, B * W, 1, st)));
     else SG_TRY((sg_launch_gemm<GftFwdOp, 32, 32, true, false, false, 128, true>(op, 3 * N, B * W, 1, st)));
     return 0;
@@ -726,7 +478,7 @@ extern "C" int stemgnn_gft_bwd(const float* mul_L, const float* X, long xs_b, lo
                                int B, int N, int W, void* stream) {
   if (!mul_L || !X || !dG || !dmul_L || B <= 0 || N <= 0 || W <= 0) return SG_EINVAL;
   hipStream_t st = (hipStream_t)stream;
-  const bool bk128 = sg_small_bk128() && N <= 512;
+  const bool bk128 = N <= 512;
   if (dX) {
     GftBwdDxOp op{mul_L + (size_t)N * N, dG, dX, B, N, W, (size_t)B * N * 3 * W};
     if (bk128) SG_TRY((sg_launch_gemm<GftBwdDxOp, 32, 32, false, false, false, 128, true>(op, N, B * W, 1, st)));
@@ -743,11 +495,6 @@ extern "C" int stemgnn_gft_bwd(const float* mul_L, const float* X, long xs_b, lo
   return 0;
 }
 
-static size_t glu3_lds_bytes(const SgDims& d) {
-  const int ka = sg_ceil16(d.KG) > d.CP ? sg_ceil16(d.KG) : d.CP;
-  return ((size_t)2 * ka * G3_LDA + 2 * G3_BK * G2_LD) * sizeof(float);
-}
-
 extern "C" int stemgnn_spectral_glu_fwd(const float* packed, float* saved, int B, int N, int W, int multi,
                                         void* stream) {
   if (!packed || !saved || B <= 0 || N <= 0 || W <= 0 || multi <= 0) return SG_EINVAL;
@@ -755,40 +502,6 @@ extern "C" int stemgnn_spectral_glu_fwd(const float* packed, float* saved, int B
   const SgPackedLayout P = sg_packed_layout(d);
   const SgSavedLayout S = sg_saved_layout(d);
   hipStream_t st = (hipStream_t)stream;
-  // STEMGNN_GLU3=1: fused three-layer kernel (needs the two activation buffers of a 64-row block in LDS, W*multi <=
-  // ~60).  Opt-in: measured 102 us against 97 us for the three per-layer launches below.
-  const bool fused_on = getenv("STEMGNN_GLU3") && atoi(getenv("STEMGNN_GLU3")) == 1;
-  const size_t lds3 = glu3_lds_bytes(d);
-  if (fused_on && lds3 <= (size_t)159 * 1024) {
-    G3Args g;
-    g.G = saved + S.G; g.KG = d.KG; g.M = d.M;
-#ifdef SG_G2_DEBUG
-    g.dbg = getenv("STEMGNN_G2_DEBUG") ? atoi(getenv("STEMGNN_G2_DEBUG")) : 0;
-#else
-    g.dbg = 0;
-#endif
-    g.KA = sg_ceil16(d.KG) > d.CP ? sg_ceil16(d.KG) : d.CP;
-    for (int l = 0; l < 3; ++l) {
-      g.kin[l] = sg_glu_kin(d, l);
-      for (int r = 0; r < 2; ++r) {
-        g.Wp[r][l] = packed + P.w[r][l]; g.bias[r][l] = packed + P.b[r][l];
-        g.out[r][l] = saved + S.out[r][l]; g.gate[r][l] = saved + S.gate[r][l];
-        g.np[r][l] = sg_glu_np(d, l, r); g.cp[r][l] = sg_glu_cp(d, l, r);
-      }
-    }
-    const bool vec = (((uintptr_t)packed) & 15) == 0;
-    static bool attr_done = false;
-    if (!attr_done) {
-      SG_TRY(hipFuncSetAttribute((const void*)sg_glu3_fwd<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
-      SG_TRY(hipFuncSetAttribute((const void*)sg_glu3_fwd<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
-      attr_done = true;
-    }
-    const dim3 grid((d.M + G3_BM - 1) / G3_BM, 2);
-    if (vec) hipLaunchKernelGGL(sg_glu3_fwd<true>, grid, dim3(512), lds3, st, g);
-    else hipLaunchKernelGGL(sg_glu3_fwd<false>, grid, dim3(512), lds3, st, g);
-    SG_TRY(hipGetLastError());
-    return 0;
-  }
   for (int l = 0; l < 3; ++l) {
     G2Args g;
     GluFwdEpi e;
@@ -804,23 +517,8 @@ extern "C" int stemgnn_spectral_glu_fwd(const float* packed, float* saved, int B
       e.cp[r] = sg_glu_cp(d, l, r);
     }
     g.nsplit = 1; g.chunk = (sg_glu_kin(d, l) + 15) & ~15; g.b_ones_col = -1;
-    if (rg_on() && sg_glu_kin(d, l) <= SG_LONG_K) {       // ring-pipelined kernel (rgemm.h) where its 16-byte rules hold
-      RgArgs ra;
-      RgGluFwdEpi re;
-      for (int r = 0; r < 2; ++r) {
-        ra.A[r] = g.A[r]; ra.lda[r] = g.lda[r]; ra.B[r] = g.B[r]; ra.ldb[r] = g.ldb[r];
-        ra.M[r] = g.M[r]; ra.N[r] = g.N[r]; ra.K[r] = g.K[r];
-        re.bp[r] = e.bp[r]; re.out[r] = e.out[r]; re.gate[r] = e.gate[r]; re.cp[r] = e.cp[r];
-      }
-      if (rg_ok(ra, 2, false)) {
-        SG_TRY((rg_launch<RgGluFwdEpi, false>(ra, re, 2, st)));
-        continue;
-      }
-    }
     if (sg_glu_kin(d, l) > SG_LONG_K) SG_TRY((g2_launch<GluFwdEpi, true, false, 64, true>(g, e, 2, st)));
-    else if (g2_bk32_mask() & 1) SG_TRY((g2_launch<GluFwdEpi, true, false, 64, false, 32>(g, e, 2, st)));
-    else if (g2_bm_mask() & 1) SG_TRY((g2_launch<GluFwdEpi, true, false, 64>(g, e, 2, st)));
-    else SG_TRY((g2_launch<GluFwdEpi, true, false>(g, e, 2, st)));
+    else SG_TRY((g2_launch<GluFwdEpi, true, false, 64>(g, e, 2, st)));
   }
   return 0;
 }
@@ -975,7 +673,7 @@ extern "C" int stemgnn_spectral_glu_bwd(const float* packed, const float* saved,
   // take the round-1 path: per layer a split-M slab GEMM, then one reduce over the GLU slabs.  Either way slab 0 of
   // every GLU region holds the complete gradient when this function returns.
   WgGemm wq[6];
-  bool fused = (parts & 2) && wg_fused_on();
+  bool fused = (parts & 2) != 0;
   if (parts & 2) {
     for (int l = 0; l < 3; ++l)
       for (int r = 0; r < 2; ++r) {
@@ -1005,9 +703,7 @@ extern "C" int stemgnn_spectral_glu_bwd(const float* packed, const float* saved,
         e.part[r] = gradpart + Gl.w[r][l];
       }
       g.nsplit = nsplit; g.chunk = chunk; g.b_ones_col = sg_glu_kin(d, l);
-      if (g2_bk32_mask() & 4) SG_TRY((g2_launch<GluWgradEpi, false, false, 64, false, 32>(g, e, 2, st)));
-      else if (g2_bm_mask() & 4) SG_TRY((g2_launch<GluWgradEpi, false, false, 64>(g, e, 2, st)));
-      else SG_TRY((g2_launch<GluWgradEpi, false, false>(g, e, 2, st)));
+      SG_TRY((g2_launch<GluWgradEpi, false, false>(g, e, 2, st)));
     }
     if (!(parts & 1)) continue;
     if (l > 0) {  // data gradient -> d(pre-activation) of layer l-1
@@ -1025,24 +721,8 @@ extern "C" int stemgnn_spectral_glu_bwd(const float* packed, const float* saved,
       }
       e.cp = d.CP;
       g.nsplit = 1; g.chunk = (2 * d.CP + 15) & ~15; g.b_ones_col = -1;
-      if (rg_on() && 2 * d.CP <= SG_LONG_K) {
-        RgArgs ra;
-        RgGluDpreEpi re;
-        for (int r = 0; r < 2; ++r) {
-          ra.A[r] = g.A[r]; ra.lda[r] = g.lda[r]; ra.B[r] = g.B[r]; ra.ldb[r] = g.ldb[r];
-          ra.M[r] = g.M[r]; ra.N[r] = g.N[r]; ra.K[r] = g.K[r];
-          re.out[r] = e.out[r]; re.gate[r] = e.gate[r]; re.dpre[r] = e.dpre[r];
-        }
-        re.cp = d.CP;
-        if (rg_ok(ra, 2, true)) {
-          SG_TRY((rg_launch<RgGluDpreEpi, true>(ra, re, 2, st)));
-          continue;
-        }
-      }
       if (2 * d.CP > SG_LONG_K) SG_TRY((g2_launch<GluDpreEpi, true, true, 64, true>(g, e, 2, st)));
-      else if (g2_bk32_mask() & 2) SG_TRY((g2_launch<GluDpreEpi, true, true, 64, false, 32>(g, e, 2, st)));
-      else if (g2_bm_mask() & 2) SG_TRY((g2_launch<GluDpreEpi, true, true, 64>(g, e, 2, st)));
-      else SG_TRY((g2_launch<GluDpreEpi, true, true>(g, e, 2, st)));
+      else SG_TRY((g2_launch<GluDpreEpi, true, true, 64>(g, e, 2, st)));
     } else {      // layer 0: both branches feed the same G -> one launch with K = Re columns then Im columns
       GluDgrad0Op op;
       for (int r = 0; r < 2; ++r) { op.dpre[r] = scratch + C.dact[r][slot]; op.wp[r] = packed + P.w[r][0]; }
@@ -1084,7 +764,7 @@ extern "C" int stemgnn_igft_heads_fwd(const float* const* params_host, const flo
   // one fused kernel per block (csrc/heads.h) when the 32-row block fits the LDS budget; STEMGNN_HEADS_FUSED=0 and large
   // W*multi take the three descriptor GEMMs below
   const size_t hd_bytes = hd_fwd_lds_floats(d.KF, d.WmP, W) * sizeof(float);
-  if (heads_fused_on() && hd_bytes <= (size_t)150 * 1024 && d.KF <= SG_LONG_K) {
+  if (hd_bytes <= (size_t)150 * 1024 && d.KF <= SG_LONG_K) {
     HeadsFwdArgs a;
     for (int r = 0; r < 2; ++r) { a.a3[r] = saved + S.out[r][2]; a.cp2[r] = d.CP2[r]; }
     a.wfold = packed + P.wfold;
@@ -1094,11 +774,8 @@ extern "C" int stemgnn_igft_heads_fwd(const float* const* params_host, const flo
     a.ig = saved + S.ig; a.fs = saved + S.fs; a.forecast = forecast; a.backcast = backcast;
     a.M = d.M; a.W = W; a.Wm = d.Wm; a.WmP = d.WmP; a.KF = d.KF; a.accumulate = accumulate; a.has_bc = has_bc;
     a.lda = hd_lda(d.KF); a.ldi = d.WmP + 1;
-    static size_t attr_bytes = 0;
-    if (hd_bytes > 64 * 1024 && hd_bytes > attr_bytes) {
-      SG_TRY(hipFuncSetAttribute((const void*)sg_heads_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hd_bytes));
-      attr_bytes = hd_bytes;
-    }
+    static SgDynLds lds_guard;
+    SG_TRY(sg_ensure_dyn_lds((const void*)sg_heads_fwd_kernel, hd_bytes, lds_guard));
     hipLaunchKernelGGL(sg_heads_fwd_kernel, dim3((d.M + HD_RB - 1) / HD_RB), dim3(256), hd_bytes, st, a);
     SG_TRY(hipGetLastError());
     return 0;
@@ -1160,7 +837,7 @@ extern "C" int stemgnn_igft_heads_bwd(const float* const* params_host, const flo
   bool fused_data = false;
   {
     const size_t hb = hd_bwd_lds_floats(d.WmP, W) * sizeof(float);
-    if ((parts & 1) && heads_fused_on() && hb <= (size_t)150 * 1024 && d.Wm <= SG_LONG_K) {
+    if ((parts & 1) && hb <= (size_t)150 * 1024 && d.Wm <= SG_LONG_K) {
       HeadsBwdArgs a;
       a.dfo = dforecast; a.dbc = dbackcast; a.bc = backcast; a.fs = saved + S.fs; a.wfold = packed + P.wfold;
       a.Fw = params_host[1]; a.FRw = params_host[3]; a.BCw = params_host[5];
@@ -1171,11 +848,8 @@ extern "C" int stemgnn_igft_heads_bwd(const float* const* params_host, const flo
       a.dpF = dpF; a.dpB = dpB; a.dig = dig;
       a.M = d.M; a.W = W; a.Wm = d.Wm; a.WmP = d.WmP; a.KF = d.KF; a.has_bc = has_bc;
       a.ldi = d.WmP + 1; a.ldw = ((W + 3) & ~3) + 1;
-      static size_t attr_bytes = 0;
-      if (hb > 64 * 1024 && hb > attr_bytes) {
-        SG_TRY(hipFuncSetAttribute((const void*)sg_heads_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hb));
-        attr_bytes = hb;
-      }
+      static SgDynLds lds_guard;
+      SG_TRY(sg_ensure_dyn_lds((const void*)sg_heads_bwd_kernel, hb, lds_guard));
       hipLaunchKernelGGL(sg_heads_bwd_kernel, dim3((d.M + HD_RB - 1) / HD_RB), dim3(256), hb, st, a);
       SG_TRY(hipGetLastError());
       fused_data = true;
@@ -1243,6 +917,31 @@ extern "C" int stemgnn_igft_heads_bwd(const float* const* params_host, const flo
 // stemgnn_spectral_glu_bwd to have run.  cu_percent: share of the CUs the fused launch should fill (<= 100): the caller
 // lowers it when latency-critical kernels run beside it on another stream.
 // =================================================================================================
+// Direct input gradient of block 0's short-cut head (:71-72): backcast = sigmoid(BC(ig) - BS(x)) depends on x through BS
+// as well, dX[m][t] -= sum_o dpB[m][o] BS_w[o][t] with dpB = d(backcast pre-activation) left in scratch by the data part of
+// stemgnn_igft_heads_bwd.  Model.forward never needs it (x is data); only a stand-alone block with a differentiable input.
+__global__ void sg_shortcut_dx_kernel(const float* __restrict__ dpB, const float* __restrict__ bs_w, float* __restrict__ dX,
+                                      size_t M, int W) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= M * W) return;
+  const size_t m = idx / W;
+  const int t = (int)(idx - m * W);
+  float acc = 0.f;
+  for (int o = 0; o < W; ++o) acc = fmaf(dpB[m * W + o], bs_w[(size_t)o * W + t], acc);
+  dX[idx] -= acc;
+}
+extern "C" int stemgnn_shortcut_dx(const float* scratch, const float* bs_w, float* dX, int B, int N, int W, int multi,
+                                   void* stream) {
+  if (!scratch || !bs_w || !dX || B <= 0 || N <= 0 || W <= 0 || multi <= 0) return SG_EINVAL;
+  const SgDims d = sg_dims(B, N, W, multi);
+  const SgScratchLayout C = sg_scratch_layout(d);
+  const size_t n = (size_t)d.M * W;
+  hipLaunchKernelGGL(sg_shortcut_dx_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     scratch + C.dpB, bs_w, dX, (size_t)d.M, W);
+  SG_TRY(hipGetLastError());
+  return 0;
+}
+
 extern "C" int stemgnn_block_wgrad(const float* const* params_host, const float* packed, const float* saved,
                                    const float* X, long xs_b, long xs_n, long xs_t, const float* dforecast, int has_bc,
                                    float* scratch, float* gradpart, int nsplit, int cu_percent, int B, int N, int W,
@@ -1259,7 +958,7 @@ extern "C" int stemgnn_block_wgrad(const float* const* params_host, const float*
   if (has_bc && !params_host[5]) return SG_EINVAL;
   WgGemm q[WG_MAXG];
   int n = 0;
-  bool ok = wg_fused_on();
+  bool ok = true;
   auto add = [&](const float* A, int lda, int Mi, const float* Bp, int ldb, int ncolB, bool ones, float* out, int ldo) {
     WgGemm& g = q[n++];
     g.A = A; g.lda = lda; g.Mi = Mi; g.B = Bp; g.ldb = ldb; g.Nj = ncolB + (ones ? 1 : 0); g.ones_col = ones ? ncolB : -1;

@@ -14,6 +14,7 @@
 #include <stdlib.h>
 
 #include "../../include/stemgnn_hip.h"
+#include "devattr.h"
 #include "gemm_core.h"
 
 #define SG_TRY(e)                                \
@@ -822,13 +823,9 @@ static int eig_direct(float* mul_L, float* lam, float* U, float* scratch, int N,
   if (N > 320) { G = N / 16; if (G > 128) G = 128; }
   const size_t lds = (size_t)(3 * N + 32) * sizeof(float);
   if (lds > 150 * 1024) return SG_EINVAL;
-  static bool attr = false;
-  if (!attr) {
-    SG_TRY(hipFuncSetAttribute((const void*)eig_tridiag_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-    attr = true;
-  }
-  static const bool small_on = !(getenv("STEMGNN_EIG_SMALL") && atoi(getenv("STEMGNN_EIG_SMALL")) == 0);
-  if (N <= 256 && small_on)     // register-resident single-workgroup kernel (reads L directly, no working copy)
+  static SgDynLds lds_guard;
+  SG_TRY(sg_ensure_dyn_lds((const void*)eig_tridiag_kernel, lds, lds_guard));
+  if (N <= 256)                 // register-resident single-workgroup kernel (reads L directly, no working copy)
     hipLaunchKernelGGL(eig_tridiag_small_kernel, dim3(1), dim3(1024), 0, st, L, N, V, dvec, evec, tauv);
   else
     hipLaunchKernelGGL(eig_tridiag_kernel, dim3(G), dim3(1024), lds, st, A, N, G, V, dvec, evec, tauv, pbuf, prow, counter, status);
@@ -865,10 +862,11 @@ static int* eig_status_word() {
   }
   return w[dev];
 }
-extern "C" int stemgnn_eigh_status(void) {
+extern "C" int stemgnn_eigh_status(void) {             // reads AND clears the status word of the CURRENT device
   int* w = eig_status_word();
   int v = -1;
   if (!w || hipMemcpy(&v, w, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  if (v != 0) (void)hipMemset(w, 0, sizeof(int));      // report once; the next check sees only new events
   return v;
 }
 extern "C" int stemgnn_eigh_cluster_fixes(void) {      // reads AND clears the count of re-orthogonalised eigenvectors

@@ -54,11 +54,9 @@ __device__ __forceinline__ float sg_lrelu(float v, float alpha) { return v > 0.f
 // key[b,i] = sum_s h[s,b,i] wk[s], query likewise (:154-155).  grid (B, ceil(N/64)), 4 waves split s.
 __global__ __launch_bounds__(256) void sg_keyquery_kernel(const float* __restrict__ h, const float* __restrict__ wk,
                                                           const float* __restrict__ wq, float* __restrict__ key,
-                                                          float* __restrict__ query, int B, int N,
-                                                          unsigned* __restrict__ arrive) {
+                                                          float* __restrict__ query, int B, int N) {
   __shared__ float red[4][64][2];
   const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (blockIdx.y == 0 && threadIdx.x == 0) arrive[b] = 0u;      // arrival counter of batch b for the attention backward
   const int i = blockIdx.y * 64 + lane;
   float ak = 0.f, aq = 0.f;
   if (i < N) {
@@ -283,11 +281,9 @@ __global__ __launch_bounds__(256) void sg_laplacian_bwd_kernel(const float* __re
 __global__ __launch_bounds__(256) void sg_attention_bwd_kernel(
     const float* __restrict__ dAB, const float* __restrict__ key, const float* __restrict__ query,
     const float* __restrict__ rowsum, float alpha, float drop_p, int training, const uint64_t* __restrict__ seedp,
-    int B, int N, int nchunk, float* __restrict__ dkey, float* __restrict__ dqpart, unsigned* __restrict__ arrive,
-    float* __restrict__ dquery) {
+    int B, int N, int nchunk, float* __restrict__ dkey, float* __restrict__ dqpart) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   __shared__ float wred[4];
-  __shared__ int s_last;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int b = blockIdx.x, chunk = blockIdx.y;
   const float* q = query + (size_t)b * N;
@@ -361,52 +357,36 @@ __global__ __launch_bounds__(256) void sg_attention_bwd_kernel(
   float* out = dqpart + ((size_t)b * nchunk + chunk) * N;
   for (int j = threadIdx.x; j < N; j += 256)
     out[j] = (smem[j] + smem[N + j]) + (smem[2 * N + j] + smem[3 * N + j]);
-  if (!arrive) return;
-  // The chunk partials of batch b are summed by whichever of its workgroups arrives LAST (agent-scope release of the
-  // partial, ticket, agent-scope acquire, then plain loads) -- always in chunk order 0..nchunk-1, so the ticket decides
-  // who reduces, never the result.  Saves the separate reduce launch on the backward's critical chain; the counter is
-  // zeroed by the forward's key/query kernel and left at zero again here.
-  __threadfence();
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const unsigned t = atomicAdd(arrive + b, 1u);
-    s_last = t == (unsigned)nchunk - 1u;
-  }
-  __syncthreads();
-  if (!s_last) return;
-  __threadfence();
-  const float* pp = dqpart + (size_t)b * nchunk * N;
-  for (int j = threadIdx.x; j < N; j += 256) {
-    float sacc = 0.f;
-    for (int c = 0; c < nchunk; ++c) sacc += pp[(size_t)c * N + j];
-    dquery[(size_t)b * N + j] = sacc;
-  }
-  if (threadIdx.x == 0) arrive[b] = 0u;
-}
-
-__global__ void sg_dquery_reduce_kernel(const float* __restrict__ dqpart, float* __restrict__ dquery, int B, int N,
-                                        int nchunk) {
-  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= (size_t)B * N) return;
-  const int b = (int)(idx / N), j = (int)(idx - (size_t)b * N);
-  float s = 0.f;
-  for (int c = 0; c < nchunk; ++c) s += dqpart[((size_t)b * nchunk + c) * N + j];
-  dquery[idx] = s;
 }
 
 // dh[s,b,i] = dkey[b,i] wk[s] + dquery[b,i] wq[s];  dwk[s] = sum_{b,i} dkey h ; dwq likewise.  One WG per s.
+// dquery[b,i] = sum_c dqpart[b][c][i] in chunk order c = 0..nchunk-1 (fixed association: every workgroup forms the same
+// bits); the nchunk partial rows are L2-resident (0.47 MB at PEMS07) and all loads of an element are issued before the sum.
 __global__ __launch_bounds__(256) void sg_keyquery_bwd_kernel(const float* __restrict__ h, const float* __restrict__ wk,
                                                               const float* __restrict__ wq, const float* __restrict__ dkey,
-                                                              const float* __restrict__ dquery, float* __restrict__ dh,
-                                                              float* __restrict__ dwk, float* __restrict__ dwq, int B, int N) {
+                                                              const float* __restrict__ dqpart, int nchunk,
+                                                              float* __restrict__ dh, float* __restrict__ dwk,
+                                                              float* __restrict__ dwq, int B, int N) {
   __shared__ float red[4][2];
   const int s = blockIdx.x;
   const size_t BN = (size_t)B * N;
   const float wks = wk[s], wqs = wq[s];
   float ak = 0.f, aq = 0.f;
   for (size_t e = threadIdx.x; e < BN; e += 256) {
-    const float dk = dkey[e], dqv = dquery[e];
+    const int b = (int)(e / N), i = (int)(e - (size_t)b * N);
+    const float* pp = dqpart + (size_t)b * nchunk * N + i;
+    const float dk = dkey[e];
     const float hv = h[(size_t)s * BN + e];
+    float dqv = 0.f;
+    int c = 0;
+    for (; c + 8 <= nchunk; c += 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = pp[(size_t)(c + u) * N];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) dqv += v[u];
+    }
+    for (; c < nchunk; ++c) dqv += pp[(size_t)c * N];
     dh[(size_t)s * BN + e] = dk * wks + dqv * wqs;
     ak = fmaf(dk, hv, ak);
     aq = fmaf(dqv, hv, aq);
@@ -509,8 +489,7 @@ extern "C" int stemgnn_attn_laplacian_fwd(const float* h, const float* wk, const
   float* A = rowsum + (size_t)B * N;
   float* deg = A + (size_t)N * N;
   if (parts & 1) {      // attention: key / query, softmax (+dropout), batch mean -> A [N,N] | deg [N] (contiguous)
-    hipLaunchKernelGGL(sg_keyquery_kernel, dim3(B, (N + 63) / 64), dim3(256), 0, st, h, wk, wq, key, query, B, N,
-                       reinterpret_cast<unsigned*>(deg + N + (size_t)ATTN_NBC * N * N + (size_t)ATTN_NBC * N));
+    hipLaunchKernelGGL(sg_keyquery_kernel, dim3(B, (N + 63) / 64), dim3(256), 0, st, h, wk, wq, key, query, B, N);
     SG_TRY(hipGetLastError());
     float* Apart = deg + N;
     float* degpart = Apart + (size_t)ATTN_NBC * N * N;
@@ -521,11 +500,9 @@ extern "C" int stemgnn_attn_laplacian_fwd(const float* h, const float* wk, const
     hipLaunchKernelGGL(sg_attention_fwd_kernel, dim3((N + 3) / 4, (B + bn - 1) / bn), dim3(256), lds, st, key, query, alpha,
                        drop_p, training, seed, B, N, bn, rowsum, Apart, degpart);
     SG_TRY(hipGetLastError());
-    // both parts in one call: the chunk reduction is folded into the Laplacian kernel (3 launches instead of 4;
-    // STEMGNN_ATTN_FUSED=0 keeps the separate reduce).  A two-part caller (exact data-parallel mode) needs A | deg in
-    // memory between the parts and takes the separate kernels.
-    static const bool fused = !(getenv("STEMGNN_ATTN_FUSED") && atoi(getenv("STEMGNN_ATTN_FUSED")) == 0);
-    if ((parts & 2) && fused) {
+    // both parts in one call: the chunk reduction is folded into the Laplacian kernel (3 launches instead of 4).  A
+    // two-part caller (exact data-parallel mode) needs A | deg in memory between the parts and takes the separate kernels.
+    if (parts & 2) {
       hipLaunchKernelGGL(sg_laplacian_fused_kernel, dim3((N + 31) / 32, (N + 31) / 32), dim3(256), 0, st, Apart, degpart,
                          (B + bn - 1) / bn, B, N, A, deg, attention_out, mul_L);
       SG_TRY(hipGetLastError());
@@ -558,8 +535,7 @@ extern "C" int stemgnn_attn_laplacian_bwd(const float* dL, const float* h, const
   const float* deg = A + (size_t)N * N;
   float* dAB = scratch;
   float* dkey = dAB + (size_t)N * N;
-  float* dquery = dkey + (size_t)B * N;
-  float* dqpart = dquery + (size_t)B * N;
+  float* dqpart = dkey + 2 * (size_t)B * N;      // (one [B,N] slot of the caller's layout is no longer used)
   if (parts & 1) {      // Laplacian backward -> dA / B in scratch[0 .. N*N)  (a data-parallel caller may average it)
     hipLaunchKernelGGL(sg_laplacian_bwd_kernel, dim3((N + 3) / 4), dim3(256), 0, st, dL, A, deg, dAB, B, N,
                        (training && drop_p > 0.f) ? 1 : 0);
@@ -568,24 +544,14 @@ extern "C" int stemgnn_attn_laplacian_bwd(const float* dL, const float* h, const
   if (!(parts & 2)) return 0;
   const size_t lds = (size_t)(4 * N) * sizeof(float);
   if (lds > 150 * 1024) return SG_EINVAL;
-  // STEMGNN_ATTN_BWD_FUSED=1: the chunk reduction of d(query) rides in the attention kernel (last-arriver, fixed order)
-  // instead of its own launch.  OFF by default -- measured 92 us against 14 + 7 us for the two launches: the agent-scope
-  // release / acquire fences of the hand-off write back and invalidate the XCD's whole L2 while the chip-filling
-  // weight-gradient kernel of the side stream keeps it full of dirty lines (that kernel slowed from 102 to 146 us as
-  // well).  `saved` is const for the caller: the counters are scratch state the forward left zeroed.
-  static const bool bwd_fused = getenv("STEMGNN_ATTN_BWD_FUSED") && atoi(getenv("STEMGNN_ATTN_BWD_FUSED")) == 1;
-  unsigned* arrive = bwd_fused ? reinterpret_cast<unsigned*>(const_cast<float*>(deg) + N + (size_t)ATTN_NBC * N * N + (size_t)ATTN_NBC * N)
-                               : nullptr;
+  // d(query): the attention kernel leaves one partial per row chunk; the key / query backward sums the nchunk partials of
+  // every element itself, in chunk order (round 4: the separate reduce launch sat on the backward's critical chain;
+  // folding it into the attention kernel as a last-arriver reduction was measured slower in round 3 -- the agent-scope
+  // fences of that hand-off flush the L2 under the concurrent weight-gradient kernel)
   hipLaunchKernelGGL(sg_attention_bwd_kernel, dim3(B, nchunk), dim3(256), lds, st, dAB, key, query, rowsum, alpha,
-                     drop_p, training, seed, B, N, nchunk, dkey, dqpart, arrive, dquery);
+                     drop_p, training, seed, B, N, nchunk, dkey, dqpart);
   SG_TRY(hipGetLastError());
-  if (!arrive) {
-    const size_t bn = (size_t)B * N;
-    hipLaunchKernelGGL(sg_dquery_reduce_kernel, dim3((unsigned)((bn + 255) / 256)), dim3(256), 0, st, dqpart, dquery, B,
-                       N, nchunk);
-    SG_TRY(hipGetLastError());
-  }
-  hipLaunchKernelGGL(sg_keyquery_bwd_kernel, dim3(N), dim3(256), 0, st, h, wk, wq, dkey, dquery, dh, dwk, dwq, B, N);
+  hipLaunchKernelGGL(sg_keyquery_bwd_kernel, dim3(N), dim3(256), 0, st, h, wk, wq, dkey, dqpart, nchunk, dh, dwk, dwq, B, N);
   SG_TRY(hipGetLastError());
   return 0;
 }
@@ -606,9 +572,7 @@ extern "C" int stemgnn_cheb_fwd(float* mul_L, int N, void* stream) {
   float* L = mul_L + nn;
   ChebFwdOp op2{L, L, mul_L + 2 * nn, N, 0};
   // small N: the products are a chain of dependent load -> LDS -> MFMA rounds; BK = 128 halves the number of rounds
-  // (STEMGNN_CHEB_BK=64 restores the round-1 tiles)
-  static const bool bk128 = !(getenv("STEMGNN_CHEB_BK") && atoi(getenv("STEMGNN_CHEB_BK")) == 64);
-  if (bk128 && N <= 512) {
+  if (N <= 512) {
     SG_TRY((sg_launch_gemm<ChebFwdOp, 32, 32, true, false, false, 128, true>(op2, N, N, 1, st)));
     ChebFwdOp op3b{L, mul_L + 2 * nn, mul_L + 3 * nn, N, 1};
     SG_TRY((sg_launch_gemm<ChebFwdOp, 32, 32, true, false, false, 128, true>(op3b, N, N, 1, st)));
@@ -628,8 +592,7 @@ extern "C" int stemgnn_cheb_bwd(const float* mul_L, const float* dmul_L, float* 
   float* dLp = scratch;
   float* dT2p = scratch + nn;
   ChebBwd1Op op1{mul_L + nn, mul_L + 2 * nn, dmul_L + nn, dmul_L + 2 * nn, dmul_L + 3 * nn, dLp, dT2p, N};
-  static const bool bk128 = !(getenv("STEMGNN_CHEB_BK") && atoi(getenv("STEMGNN_CHEB_BK")) == 64);
-  if (bk128 && N <= 512) {
+  if (N <= 512) {
     SG_TRY((sg_launch_gemm<ChebBwd1Op, 32, 32, true, true, false, 128, true>(op1, N, N, 2, st)));
     ChebBwd2Op op2b{mul_L + nn, dT2p, dLp, dL, N};
     SG_TRY((sg_launch_gemm<ChebBwd2Op, 32, 32, true, true, false, 128, true>(op2b, N, N, 1, st)));

@@ -39,9 +39,6 @@ struct G2Args {
 #define G2_DBG(g, bit) 0
 #endif
 
-#ifndef G2_VARIANT
-#define G2_VARIANT 0      // K-loop experiments of tools/probe/g2_probe (bit 0: fragment reads hoisted, bit 1: loads two stages ahead)
-#endif
 constexpr int G2_BM = 128, G2_BN = 128, G2_BK = 16, G2_LD = 132;
 
 // D layout of v_mfma_f32_32x32x2_f32: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
@@ -186,54 +183,16 @@ __global__ __launch_bounds__(256) void sg_gemm2(const G2Args g, const Epi epi) {
   }
   __syncthreads();
   int buf = 0;
-#if (G2_VARIANT & 2)
-  // probe variant (tools/probe/g2_probe -DG2_VARIANT=2): global loads TWO stages ahead through a second register set, so
-  // the wait ahead of the ds_write is for loads issued a whole stage earlier
-  float4 ra2[LA::NT], rb2[LB::NT];
-  if (K0 + BK < K1) {
-    LA::load(A, lda, m0, M, K0 + BK, K1, -1, tid, ra);
-    LB::load(Bp, ldb, n0, N, K0 + BK, K1, g.b_ones_col, tid, rb);
-  }
-#endif
   for (int kb = K0; kb < K1; kb += BK) {
     const bool more = kb + BK < K1;
-#if (G2_VARIANT & 2)
-    if (kb + 2 * BK < K1) {
-      LA::load(A, lda, m0, M, kb + 2 * BK, K1, -1, tid, ra2);
-      LB::load(Bp, ldb, n0, N, kb + 2 * BK, K1, g.b_ones_col, tid, rb2);
-    }
-#else
     if (more && !G2_DBG(g, 4)) {
       LA::load(A, lda, m0, M, kb + BK, K1, -1, tid, ra);
       LB::load(Bp, ldb, n0, N, kb + BK, K1, g.b_ones_col, tid, rb);
     }
-#endif
     const float* As = lds + buf * STAGE;
     const float* Bs = As + BK * LDA;
     const int fi = lane & 31, fk = lane >> 5;
-#if (G2_VARIANT & 1)
-    {   // probe variant (-DG2_VARIANT=1): every fragment of the stage into registers first, then the MFMAs back to back
-      float af[BK / 2][NI], bf0[BK / 2], bf1[BK / 2];
-#pragma unroll
-      for (int ks = 0; ks < BK; ks += 2) {
-#pragma unroll
-        for (int i = 0; i < NI; ++i) af[ks >> 1][i] = As[(ks + fk) * LDA + wm * (BM / 2) + i * 32 + fi];
-        bf0[ks >> 1] = Bs[(ks + fk) * G2_LD + wn * 64 + fi];
-        bf1[ks >> 1] = Bs[(ks + fk) * G2_LD + wn * 64 + 32 + fi];
-      }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int ks = 0; ks < BK; ks += 2)
-#pragma unroll
-        for (int i = 0; i < NI; ++i) {
-          acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[ks >> 1][i], bf0[ks >> 1], acc[i][0], 0, 0, 0);
-          acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[ks >> 1][i], bf1[ks >> 1], acc[i][1], 0, 0, 0);
-        }
-    }
-    if (false)
-#else
     if (!G2_DBG(g, 2))
-#endif
 #pragma unroll
     for (int ks = 0; ks < BK; ks += 2) {
       float a[NI];
@@ -253,12 +212,6 @@ __global__ __launch_bounds__(256) void sg_gemm2(const G2Args g, const Epi epi) {
     }
     __syncthreads();
     buf ^= 1;
-#if (G2_VARIANT & 2)
-#pragma unroll
-    for (int t = 0; t < LA::NT; ++t) ra[t] = ra2[t];
-#pragma unroll
-    for (int t = 0; t < LB::NT; ++t) rb[t] = rb2[t];
-#endif
     if constexpr (TL) {
       if (++tl_count == G2_FLUSH) {
         tl_count = 0;

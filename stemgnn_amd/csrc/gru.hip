@@ -523,90 +523,6 @@ __device__ __forceinline__ float gru_poll_lane(const gru_u64* g, unsigned tag, b
   return v;
 }
 
-// forward.  LDS: part[2][3*P][64]
-// OW = owner slices per wave: 3*P/OW waves per workgroup (OW = 2 lets P = 6 / 8 clusters -- hidden sizes up to 512 --
-// stay inside the 1024-thread limit; each wave then polls and multiplies two slices per step).
-template <int P, int KU, int OW>
-__global__ __launch_bounds__(3 * (P / OW) * 64) void gru_fwd_cluster2_kernel(const float* __restrict__ gi, const float* __restrict__ w_hh,
-                                                                      const float* __restrict__ b_hh, int B, int S, int Hd,
-                                                                      gru_u64* __restrict__ xbuf, int* __restrict__ status,
-                                                                      float* __restrict__ h_all, float* __restrict__ reserve,
-                                                                      gru_u64* __restrict__ xid, int allow_fast) {
-  static_assert(P % OW == 0, "owners per wave");
-  __shared__ float part[2][3 * P][64];
-  __shared__ __attribute__((aligned(16))) float lrow[3 * P][64];   // per-wave broadcast rows (GruBcast)
-  __shared__ int s_fast;
-  int b, p;
-  gru_cluster_ids(B, P, b, p);
-  if (b >= B) return;
-  const bool fast = P > 1 && gru_same_xcd(xid + (size_t)b * P, p, P, allow_fast, status, &s_fast, threadIdx.x);
-  const int U = (Hd + P - 1) / P;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = gru_uniform(tid >> 6);
-  const int g = wave / (P / OW), q0 = (wave - g * (P / OW)) * OW;       // gate, first owner of this wave's k-slices
-  const int u0 = p * U, un = max(0, min(Hd, u0 + U) - u0);
-  const int H3 = 3 * Hd;
-  gru_f2 wr[OW][32];
-  int k0[OW], kn[OW];
-#pragma unroll
-  for (int o = 0; o < OW; ++o) {
-    // owner of this wave's o-th k-slice, rotated by p: wave 0's first slice is the workgroup's OWN units, whose
-    // values it already holds in registers (lane = unit) -- the wave that runs the gate phase and its global
-    // prefetches never has to poll (its poll would queue behind those prefetch loads: vmcnt retires in order)
-    k0[o] = ((q0 + o + p) % P) * U;
-    kn[o] = max(0, min(Hd, k0[o] + U) - k0[o]);
-    const bool lane_ok = lane < un;
-    const float* wrow = w_hh + ((size_t)g * Hd + (lane_ok ? u0 + lane : 0)) * Hd + (kn[o] > 0 ? k0[o] : 0);
-#pragma unroll
-    for (int kk = 0; kk < KU; ++kk) {
-      const float v = wrow[kk < kn[o] ? kk : 0];
-      wr[o][kk >> 1][kk & 1] = (lane_ok && kk < kn[o]) ? v : 0.f;
-    }
-  }
-  const int gu = u0 + (tid < un ? tid : 0);            // gate-phase unit of this thread (wave 0 only)
-  const float bh0 = b_hh[gu], bh1 = b_hh[Hd + gu], bh2 = b_hh[2 * Hd + gu];
-  float hown = 0.f;                                     // h_{s-1} of this thread's unit
-
-  for (int s = 0; s < S; ++s) {
-    const size_t row = (size_t)s * B + b;
-    const float* gip = gi + row * H3;
-    const float gp0 = gip[gu], gp1 = gip[Hd + gu], gp2 = gip[2 * Hd + gu];     // prefetch for the gate phase
-#pragma unroll
-    for (int o = 0; o < OW; ++o) {
-      float hv = 0.f;
-      if (wave == 0 && o == 0) hv = hown;                 // own slice: h_{s-1} of unit `lane` is this lane's register
-      else if (s > 0) hv = gru_poll_lane(xbuf + ((size_t)(s & 1) * B + b) * Hd + k0[o] + (lane < kn[o] ? lane : 0),
-                                         (unsigned)s, lane < kn[o], status);
-      part[s & 1][g * P + q0 + o][lane] = gru_matvec<KU, GRU_NR2(P, OW)>(wr[o], hv, lrow[wave * OW + o], lane);
-    }
-    gru_lds_barrier();
-    if (tid < un) {
-      float g0 = bh0, g1 = bh1, g2 = bh2;
-#pragma unroll
-      for (int qq = 0; qq < P; ++qq) {
-        g0 += part[s & 1][0 * P + qq][tid];
-        g1 += part[s & 1][1 * P + qq][tid];
-        g2 += part[s & 1][2 * P + qq][tid];
-      }
-#ifdef GRU_FAST_GATES      // v_exp / v_rcp forms (A/B builds only; measured in profiles/r02_gru_exchange.md)
-      const float r = __frcp_rn(1.f + __expf(-(gp0 + g0)));
-      const float z = __frcp_rn(1.f + __expf(-(gp1 + g1)));
-      const float n = 1.f - 2.f * __frcp_rn(1.f + __expf(2.f * (gp2 + r * g2)));
-#else
-      const float r = gru_sigmoid(gp0 + g0);
-      const float z = gru_sigmoid(gp1 + g1);
-      const float n = tanhf(gp2 + r * g2);
-#endif
-      const float hn = (1.f - z) * n + z * hown;
-      hown = hn;
-      if (s + 1 < S) gru_publish_x(xbuf + ((size_t)((s + 1) & 1) * B + b) * Hd + gu, (unsigned)(s + 1), hn, fast);
-      float* rs = reserve + row * 4 * Hd;
-      rs[gu] = r; rs[Hd + gu] = z; rs[2 * Hd + gu] = n; rs[3 * Hd + gu] = g2;
-      h_all[row * Hd + gu] = hn;
-    }
-  }
-}
-
 // -DGRU_PROF builds (tools/gpu_job_r2m.sh): cycle counters of the phases of one recurrence step, summed over the steps
 // and printed by workgroup 0 (lane 0 of wave 0 = the gate-phase wave, lane 0 of wave 1 = a polling wave)
 #ifdef GRU_PROF
@@ -645,99 +561,6 @@ __device__ __forceinline__ void gru_matvec3(const gru_f2 (&w0)[32], const gru_f2
   o1 = (a1.x + b1.x) + (a1.y + b1.y);
   o2 = (a2.x + b2.x) + (a2.y + b2.y);
 }
-template <int P, int KU>
-__global__ __launch_bounds__(P * 64) void gru_fwd_cluster3_kernel(const float* __restrict__ gi, const float* __restrict__ w_hh,
-                                                                  const float* __restrict__ b_hh, int B, int S, int Hd,
-                                                                  gru_u64* __restrict__ xbuf, int* __restrict__ status,
-                                                                  float* __restrict__ h_all, float* __restrict__ reserve,
-                                                                  gru_u64* __restrict__ xid, int allow_fast) {
-  __shared__ float part[2][3 * P][64];
-  __shared__ __attribute__((aligned(16))) float lrow[P][64];       // per-wave broadcast rows (GruBcast)
-  __shared__ int s_fast;
-  int b, p;
-  gru_cluster_ids(B, P, b, p);
-  if (b >= B) return;
-  const bool fast = P > 1 && gru_same_xcd(xid + (size_t)b * P, p, P, allow_fast, status, &s_fast, threadIdx.x);
-  const int U = (Hd + P - 1) / P;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int q = gru_uniform(tid >> 6);                  // wave = owner slot, rotated by p: wave 0 multiplies the OWN units
-  const int u0 = p * U, un = max(0, min(Hd, u0 + U) - u0);
-  const int H3 = 3 * Hd;
-  const int k0 = ((q + p) % P) * U, kn = max(0, min(Hd, k0 + U) - k0);
-  gru_f2 wr[3][32];
-  {
-    const bool lane_ok = lane < un;
-#pragma unroll
-    for (int g = 0; g < 3; ++g) {
-      const float* wrow = w_hh + ((size_t)g * Hd + (lane_ok ? u0 + lane : 0)) * Hd + (kn > 0 ? k0 : 0);
-#pragma unroll
-      for (int kk = 0; kk < KU; ++kk) {
-        const float v = wrow[kk < kn ? kk : 0];
-        wr[g][kk >> 1][kk & 1] = (lane_ok && kk < kn) ? v : 0.f;
-      }
-    }
-  }
-  const int gu = u0 + (tid < un ? tid : 0);
-  const float bh0 = b_hh[gu], bh1 = b_hh[Hd + gu], bh2 = b_hh[2 * Hd + gu];
-  float hown = 0.f;
-
-#ifdef GRU_PROF
-  long long c_poll = 0, c_mv = 0, c_bar = 0, c_gate = 0;
-#endif
-  for (int s = 0; s < S; ++s) {
-    const size_t row = (size_t)s * B + b;
-    const float* gip = gi + row * H3;
-    const float gp0 = gip[gu], gp1 = gip[Hd + gu], gp2 = gip[2 * Hd + gu];     // prefetch for the gate phase
-    GRU_T(t0);
-    {
-      float hv = 0.f;
-      if (q == 0) hv = hown;
-      else if (s > 0) hv = gru_poll_lane(xbuf + ((size_t)(s & 1) * B + b) * Hd + k0 + (lane < kn ? lane : 0), (unsigned)s,
-                                         lane < kn, status);
-      GRU_T(t1);                                          // (the poll has returned: its value was compared)
-      GRU_ACC(c_poll, t1, t0);
-      float o0, o1, o2;
-      gru_matvec3<KU, GRU_NR3(KU)>(wr[0], wr[1], wr[2], hv, lrow[q], lane, o0, o1, o2);
-      part[s & 1][0 * P + q][lane] = o0;
-      part[s & 1][1 * P + q][lane] = o1;
-      part[s & 1][2 * P + q][lane] = o2;
-#ifdef GRU_PROF
-      GRU_T(t2);
-      GRU_ACC(c_mv, t2, t1);
-#endif
-    }
-    GRU_T(t3);
-    gru_lds_barrier();
-    GRU_T(t4);
-    GRU_ACC(c_bar, t4, t3);
-    if (tid < un) {
-      float g0 = bh0, g1 = bh1, g2 = bh2;
-#pragma unroll
-      for (int qq = 0; qq < P; ++qq) {
-        g0 += part[s & 1][0 * P + qq][tid];
-        g1 += part[s & 1][1 * P + qq][tid];
-        g2 += part[s & 1][2 * P + qq][tid];
-      }
-      const float r = gru_sigmoid(gp0 + g0);
-      const float z = gru_sigmoid(gp1 + g1);
-      const float n = tanhf(gp2 + r * g2);
-      const float hn = (1.f - z) * n + z * hown;
-      hown = hn;
-      if (s + 1 < S) gru_publish_x(xbuf + ((size_t)((s + 1) & 1) * B + b) * Hd + gu, (unsigned)(s + 1), hn, fast);
-      GRU_T(t5);
-      GRU_ACC(c_gate, t5, t4);
-      float* rs = reserve + row * 4 * Hd;
-      rs[gu] = r; rs[Hd + gu] = z; rs[2 * Hd + gu] = n; rs[3 * Hd + gu] = g2;
-      h_all[row * Hd + gu] = hn;
-    }
-  }
-#ifdef GRU_PROF
-  if (blockIdx.x == 0 && lane == 0)
-    printf("gru fwd3 wave %d: per step cycles: poll/own %lld  matvec %lld  barrier wait %lld  gate phase %lld  (S=%d)\n", q,
-           c_poll / S, c_mv / S, c_bar / S, c_gate / S, S);
-#endif
-}
-
 // backward.  LDS: part[2][3*P][64].  Wave (g, q): reduction slice j = g*Hd + units of owner q.
 template <int P, int KU, int OW>
 __global__ __launch_bounds__(3 * (P / OW) * 64) void gru_bwd_cluster2_kernel(const float* __restrict__ dout, const float* __restrict__ w_hh,
@@ -944,15 +767,8 @@ __global__ void gru_reduce_grad_kernel(const GruReduceJobs J) {
 
 // =================================================================================================
 #include <stdlib.h>
-// split-K slabs of the weight-gradient GEMMs (fixed-order reduce afterwards); STEMGNN_GRU_NSPLIT in [8, 64] for A/B runs
-static int gru_nsplit() {
-  static const int v = [] {
-    const char* e = getenv("STEMGNN_GRU_NSPLIT");
-    const int n = e ? atoi(e) : 32;
-    return n < 8 ? 8 : (n > 64 ? 64 : n);
-  }();
-  return v;
-}
+// split-K slabs of the weight-gradient GEMMs (fixed-order reduce afterwards; 16 / 24 / 48 / 64 measured slower)
+static int gru_nsplit() { return 32; }
 #define GRU_NSPLIT gru_nsplit()
 // slabs of the dW_ih | db_ih reduction: one per split of the GEMM, or one per batch row when the wave-specialised
 // backward accumulates them itself (gru_cluster4.h)
@@ -1002,19 +818,15 @@ static int gru_pick_P2(int B, int Hd) {
 // The backward recurrence is latency-bound and occupies one workgroup on B*P of the 256 CUs.  It reserves (almost)
 // the whole LDS of its CU so that no LDS-using kernel of another stream (the spectral blocks' weight-gradient
 // GEMMs, which ops.py overlaps with it) can become co-resident: those land on the idle CUs instead of filling the
-// memory queues of the CUs whose poll latency sets the step time.  STEMGNN_GRU_LDS_HOG=0 disables it.
+// memory queues of the CUs whose poll latency sets the step time.
 template <int P>
 static size_t gru_lds_hog(const void* fn) {
-  static const bool on = !(getenv("STEMGNN_GRU_LDS_HOG") && atoi(getenv("STEMGNN_GRU_LDS_HOG")) == 0);
-  if (!on) return 0;
   const size_t bytes = (size_t)156 * 1024 - sizeof(float) * 3 * 3 * P * 64;      // static: part[2][3P][64] + lrow[3P][64]
   (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
   return bytes;
 }
 template <int P>
 static size_t gru_lds_hog4(const void* fn) {             // the same for the wave-specialised backward (its static LDS is larger)
-  static const bool on = !(getenv("STEMGNN_GRU_LDS_HOG") && atoi(getenv("STEMGNN_GRU_LDS_HOG")) == 0);
-  if (!on) return 0;
   const size_t bytes = (size_t)156 * 1024 - sizeof(float) * gru4_static_lds_floats(P, 6, 4);
   (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
   return bytes;
@@ -1037,62 +849,6 @@ static int gru_pick_wide(int B, int Hd, int P2, GruWide* g) {
   if (P2 > 0 && mode != 1) return 0;                 // the per-row clusters are faster where they fit
   (void)B;
   return gru_wide_plan(Hd, gru_resident_limit(), g);
-}
-
-// Input projection gi[i][j] = b_ih[j] + sum_k x[b][k][s] w_ih[j][k] (row i = s * B + b) for short windows, as a streaming
-// kernel: K = W <= 16 is far too short for a tiled GEMM (one k-tile, 64 x 64 output tiles: 17-20 us for 20 MB of
-// output at PEMS07) -- here a thread keeps the W weights of 4 adjacent outputs in registers, walks down RPB rows, reads
-// the row's W window values through wave-uniform loads and stores one float4 per row.  Blocks beyond the row blocks zero
-// the two ranges the recurrence needs cleared (slab 0 of h_ext, the exchange granules): one launch instead of
-// fill + GEMM + fill ahead of the recurrence.  Needs 3 Hd % 4 == 0 and 3 Hd / 4 <= 1024.
-constexpr int GRU_GI_RPB = 8, GRU_GI_RU = 4;      // rows per block / rows whose window loads are in flight together
-template <int WW>
-__global__ __launch_bounds__(1024) void gru_gi_kernel(const float* __restrict__ x, const float* __restrict__ w_ih,
-                                                      const float* __restrict__ b_ih, float* __restrict__ gi, int B, int S,
-                                                      int Hd, int W, int nrb, unsigned* __restrict__ za, size_t na,
-                                                      unsigned* __restrict__ zb, size_t nb) {
-  if ((int)blockIdx.x >= nrb) {
-    const size_t i0 = ((size_t)(blockIdx.x - nrb) * blockDim.x + threadIdx.x) * 4;
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const size_t i = i0 + u;
-      if (i < na) za[i] = 0u;
-      else if (i < na + nb) zb[i - na] = 0u;
-    }
-    return;
-  }
-  const int H3 = 3 * Hd, j = 4 * (int)threadIdx.x;
-  if (j >= H3) return;                                   // (no barriers below)
-  float w[4][WW];
-#pragma unroll
-  for (int c = 0; c < 4; ++c)
-#pragma unroll
-    for (int k = 0; k < WW; ++k) w[c][k] = k < W ? w_ih[(size_t)(j + c) * W + k] : 0.f;
-  const float4 bias = make_float4(b_ih[j], b_ih[j + 1], b_ih[j + 2], b_ih[j + 3]);   // (parameter views: any 4-byte alignment)
-  const int i0 = blockIdx.x * GRU_GI_RPB, i1 = min(S * B, i0 + GRU_GI_RPB);
-  // (a first version walked 32 rows one at a time: 36 us, a chain of dependent L2 round trips -- slower than the GEMM)
-  for (int ib = i0; ib < i1; ib += GRU_GI_RU) {
-    float xv[GRU_GI_RU][WW];
-#pragma unroll
-    for (int u = 0; u < GRU_GI_RU; ++u) {
-      const int i = min(ib + u, i1 - 1);
-      const int sq = i / B, b = i - sq * B;
-      const float* xp = x + (size_t)b * W * S + sq;
-#pragma unroll
-      for (int k = 0; k < WW; ++k) xv[u][k] = xp[(size_t)(k < W ? k : 0) * S];      // wave-uniform addresses
-    }
-#pragma unroll
-    for (int u = 0; u < GRU_GI_RU; ++u) {
-      float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-      for (int k = 0; k < WW; ++k) {
-        a.x = fmaf(xv[u][k], w[0][k], a.x); a.y = fmaf(xv[u][k], w[1][k], a.y);
-        a.z = fmaf(xv[u][k], w[2][k], a.z); a.w = fmaf(xv[u][k], w[3][k], a.w);
-      }
-      a.x += bias.x; a.y += bias.y; a.z += bias.z; a.w += bias.w;
-      if (ib + u < i1) *reinterpret_cast<float4*>(gi + (size_t)(ib + u) * H3 + j) = a;
-    }
-  }
 }
 
 // zero two word ranges in one launch (4 words per thread where aligned; ranges are 4-byte aligned)
@@ -1140,35 +896,19 @@ extern "C" int stemgnn_gru_fwd(const float* x, const float* w_ih, const float* w
   float* w_hhT = scratch;
   float* gi = scratch + (size_t)3 * Hd * Hd;
   gru_u64* xbuf2 = (gru_u64*)(scratch + ((((size_t)3 * Hd * Hd + (size_t)3 * S * B * Hd) + 1) & ~(size_t)1));
-  bool gi_done = false;
   if (!use_wide && P2 > 0) {
     // per-row clusters: slab 0 (h_{-1} = 0) and the exchange granules (tags := 0 every launch) are zeroed ahead of the
-    // recurrence without fill nodes of their own (each costs ~5 us of launch latency on the step's critical path): by one
-    // small kernel ahead of the projection GEMM, or (STEMGNN_GRU_GI_STREAM=1, measured not faster) by the streaming
-    // input-projection kernel itself
+    // recurrence by one small kernel ahead of the projection GEMM instead of fill nodes of their own (each costs ~5 us of
+    // launch latency on the step's critical path).  (A streaming input-projection kernel that also did the zeroing was
+    // measured not faster in round 3 -- 25 us against 20 + 5 -- and removed in round 4.)
     const size_t n0 = (size_t)B * Hd, n1 = ((size_t)2 * B * Hd + (size_t)8 * B) * 2;        // in 4-byte words
-    static const bool gi_stream = getenv("STEMGNN_GRU_GI_STREAM") && atoi(getenv("STEMGNN_GRU_GI_STREAM")) == 1;   // measured: 25 us vs 20 + 5 -> off
-    const int nthr = ((3 * Hd / 4 + 63) / 64) * 64;
-    if (gi_stream && (3 * Hd) % 4 == 0 && nthr <= 1024 && W <= 16 && (((uintptr_t)gi) & 15) == 0) {
-      const int nrb = (S * B + GRU_GI_RPB - 1) / GRU_GI_RPB;
-      const unsigned nzb = (unsigned)((n0 + n1 + (size_t)nthr * 4 - 1) / ((size_t)nthr * 4));
-      if (W <= 12)
-        hipLaunchKernelGGL(gru_gi_kernel<12>, dim3(nrb + nzb), dim3(nthr), 0, st, x, w_ih, b_ih, gi, B, S, Hd, W, nrb,
-                           reinterpret_cast<unsigned*>(h_ext), n0, reinterpret_cast<unsigned*>(xbuf2), n1);
-      else
-        hipLaunchKernelGGL(gru_gi_kernel<16>, dim3(nrb + nzb), dim3(nthr), 0, st, x, w_ih, b_ih, gi, B, S, Hd, W, nrb,
-                           reinterpret_cast<unsigned*>(h_ext), n0, reinterpret_cast<unsigned*>(xbuf2), n1);
-      SG_TRY(hipGetLastError());
-      gi_done = true;
-    } else {
-      hipLaunchKernelGGL(gru_zero2_kernel, dim3((unsigned)((n0 + n1 + 1023) / 1024)), dim3(256), 0, st,
-                         reinterpret_cast<unsigned*>(h_ext), n0, reinterpret_cast<unsigned*>(xbuf2), n1);
-      SG_TRY(hipGetLastError());
-    }
+    hipLaunchKernelGGL(gru_zero2_kernel, dim3((unsigned)((n0 + n1 + 1023) / 1024)), dim3(256), 0, st,
+                       reinterpret_cast<unsigned*>(h_ext), n0, reinterpret_cast<unsigned*>(xbuf2), n1);
+    SG_TRY(hipGetLastError());
   } else {
     SG_TRY(hipMemsetAsync(h_ext, 0, (size_t)B * Hd * sizeof(float), st));    // slab 0: h_{-1} = 0
   }
-  if (!gi_done) {
+  {
     GruGiOp op{x, w_ih, b_ih, gi, B, S, Hd, W};
     SG_TRY((sg_launch_gemm<GruGiOp, 64, 64, true, true, false>(op, S * B, 3 * Hd, 1, st)));
   }
@@ -1181,36 +921,16 @@ extern "C" int stemgnn_gru_fwd(const float* x, const float* w_ih, const float* w
     gru_u64* xbuf = xbuf2;                                                          // zeroed by gru_zero2_kernel above
     gru_u64* xid = xbuf + (size_t)2 * B * Hd;                                       // P XCC-id granules per batch row
     static const int allow_fast = !(getenv("STEMGNN_GRU_FAST_XCD") && atoi(getenv("STEMGNN_GRU_FAST_XCD")) == 0);
-    const dim3 grid(8 * ((B + 7) / 8) * P2);
-#define GRU_F2K(PP, KK, OO) hipLaunchKernelGGL((gru_fwd_cluster2_kernel<PP, KK, OO>), grid, dim3(3 * (PP / OO) * 64), 0, st, gi, \
-                                               w_hh, b_hh, B, S, Hd, xbuf, status, h_all, reserve, xid, allow_fast)
-#define GRU_F2(PP, OO) do { if (KU2 == 32) GRU_F2K(PP, 32, OO); else if (KU2 == 48) GRU_F2K(PP, 48, OO); \
-                            else if (KU2 == 58) GRU_F2K(PP, 58, OO); else GRU_F2K(PP, 64, OO); } while (0)
-    const int KU2 = gru_pick_KU(Hd, P2);
-    // one wave per owner slice with the three gates sharing every broadcast (P <= 5); STEMGNN_GRU_FWD3=0: one wave per
-    // (gate, owner) as in round 1
-    const char* e3 = getenv("STEMGNN_GRU_FWD3");        // read per launch (a hipGraph capture freezes the choice)
-    const int fwd3 = !(e3 && atoi(e3) == 0);
-#define GRU_F3K(PP, KK) hipLaunchKernelGGL((gru_fwd_cluster3_kernel<PP, KK>), grid, dim3(PP * 64), 0, st, gi, w_hh, b_hh, B, S, \
-                                           Hd, xbuf, status, h_all, reserve, xid, allow_fast)
-#define GRU_F3(PP) do { if (KU2 == 32) GRU_F3K(PP, 32); else if (KU2 == 48) GRU_F3K(PP, 48); \
-                        else if (KU2 == 58) GRU_F3K(PP, 58); else GRU_F3K(PP, 64); } while (0)
-    const char* e4 = getenv("STEMGNN_GRU_V4");           // wave-specialised kernels (gru_cluster4.h); 0: v2 / v3
-    const int v4 = !(e4 && atoi(e4) == 0);
-    // The v4 forward runs P + 2 waves per workgroup, so every P <= 8 fits; its cluster size may differ from the backward's
-    // (the backward shares the chip with the side-stream weight-gradient GEMMs, the forward has it to itself).
-    // Default: 7 workgroups per batch row when B * 7 of them are resident (224 of the 256 CUs at batch 32: the mat-vec
-    // slices shrink to 33 columns; measured 1.4985 -> 1.4850 ms per step at PEMS07, P = 5 / 6: 1.509 / 1.491), else the
-    // backward's P.  STEMGNN_GRU_FWD_P=n forces n (1, 2, 4 .. 8; needs ceil(Hd / n) <= 64, and <= 40 for n >= 7), =0 means
-    // "as the backward".
+    // Wave-specialised forward (gru_cluster4.h): P + 2 waves per workgroup, so every P <= 8 fits; its cluster size may
+    // differ from the backward's (the backward shares the chip with the side-stream weight-gradient GEMMs, the forward
+    // has it to itself).  Default: 7 workgroups per batch row when B * 7 of them are resident (224 of the 256 CUs at batch
+    // 32: the mat-vec slices shrink to 33 columns; measured 1.4985 -> 1.4850 ms per step at PEMS07, P = 5 / 6: 1.509 /
+    // 1.491), else the backward's P.
     int PF = P2;
     {
-      const char* ep = getenv("STEMGNN_GRU_FWD_P");
-      const int want = ep ? atoi(ep) : 7;
-      const int uw = want >= 1 ? (Hd + want - 1) / want : 0;
-      // 7 or 8 workgroups per row = 9 or 10 waves = three on one SIMD = 168 registers per lane: slices of <= 40 columns only
-      const bool regs_ok = want <= 6 || uw <= 40;
-      if (want >= 1 && want <= 8 && want != 3 && uw <= 64 && regs_ok && B * want <= gru_resident_limit()) PF = want;
+      const int want = 7, uw = (Hd + want - 1) / want;
+      // 7 workgroups per row = 9 waves = three on one SIMD = 168 registers per lane: slices of <= 40 columns only
+      if (uw <= 40 && B * want <= gru_resident_limit()) PF = want;
     }
     const int UF = (Hd + PF - 1) / PF;
     const int KF = UF <= 32 ? 32 : (UF <= 34 ? 34 : (UF <= 40 ? 40 : (UF <= 48 ? 48 : (UF <= 58 ? 58 : 64))));
@@ -1219,19 +939,10 @@ extern "C" int stemgnn_gru_fwd(const float* x, const float* w_ih, const float* w
                                            b_hh, B, S, Hd, xbuf, status, h_all, reserve, xid, allow_fast)
 #define GRU_F4(PP) do { if (KF == 32) GRU_F4K(PP, 32); else if (KF == 34) GRU_F4K(PP, 34); else if (KF == 40) GRU_F4K(PP, 40); \
                         else if (KF == 48) GRU_F4K(PP, 48); else if (KF == 58) GRU_F4K(PP, 58); else GRU_F4K(PP, 64); } while (0)
-    if (v4) {
-      if (PF == 1) GRU_F4(1); else if (PF == 2) GRU_F4(2); else if (PF == 4) GRU_F4(4); else if (PF == 5) GRU_F4(5);
-      else if (PF == 6) GRU_F4(6); else if (PF == 7) GRU_F4(7); else GRU_F4(8);
-    } else if (fwd3 && P2 <= 5) {
-      if (P2 == 1) GRU_F3(1); else if (P2 == 2) GRU_F3(2); else if (P2 == 4) GRU_F3(4); else GRU_F3(5);
-    } else if (P2 == 1) GRU_F2(1, 1); else if (P2 == 2) GRU_F2(2, 1); else if (P2 == 4) GRU_F2(4, 1);
-    else if (P2 == 5) GRU_F2(5, 1); else if (P2 == 6) GRU_F2(6, 2); else GRU_F2(8, 2);
+    if (PF == 1) GRU_F4(1); else if (PF == 2) GRU_F4(2); else if (PF == 4) GRU_F4(4); else if (PF == 5) GRU_F4(5);
+    else if (PF == 6) GRU_F4(6); else if (PF == 7) GRU_F4(7); else GRU_F4(8);
 #undef GRU_F4
 #undef GRU_F4K
-#undef GRU_F3
-#undef GRU_F3K
-#undef GRU_F2
-#undef GRU_F2K
     SG_TRY(hipGetLastError());
     return 0;
   }
@@ -1275,41 +986,16 @@ static int gru_wgrad_rows(const float* dgi, const float* dghn, const float* h_ex
     g.nsplit = nsplit; g.chunk = chunk; g.b_ones_col = Hd;
     e.part[0] = p_hh + (size_t)slab0 * 2 * Hd * (Hd + 1);
     e.part[1] = p_hh + (size_t)GRU_NSPLIT * 2 * Hd * (Hd + 1) + (size_t)slab0 * Hd * (Hd + 1);
-    static const bool bm64 = getenv("STEMGNN_GRU_WG_BM64") && atoi(getenv("STEMGNN_GRU_WG_BM64")) == 1;
-    if (bm64) SG_TRY((g2_launch<G2SlabEpi, false, false, 64>(g, e, 2, st_hh)));
-    else SG_TRY((g2_launch<G2SlabEpi, false, false>(g, e, 2, st_hh)));
+    SG_TRY((g2_launch<G2SlabEpi, false, false>(g, e, 2, st_hh)));
   }
   if (!do_ih) return 0;                                  // accumulated inside the recurrence (gru_cluster4.h)
   GruWihGradOp o2{dgi, x, p_ih + (size_t)slab0 * 3 * Hd * (W + 1), B, S, Hd, W, nsplit, chunk, row0, rows};
   SG_TRY((sg_launch_gemm<GruWihGradOp, 64, 32, false, false, false, 64>(o2, 3 * Hd, W + 1, nsplit, st_ih)));
   return 0;
 }
-// one wave that returns when `progress` has reached `want` (bounded): the stream it is launched on resumes then
-__global__ void gru_wait_progress_kernel(const unsigned* __restrict__ progress, unsigned want, int* __restrict__ status) {
-  if (threadIdx.x != 0) return;
-  unsigned spins = 0;
-  while (__hip_atomic_load(progress, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
-    __builtin_amdgcn_s_sleep(32);
-    if (++spins > (1u << 24)) { atomicExch(status, 3); break; }
-  }
-}
-// events for the fork / join between the recurrence stream and the weight-gradient side streams (created once per
-// process; record / wait are stream-ordered and capturable: inside a hipGraph capture they become dependency edges)
-static hipEvent_t* gru_events() {
-  static hipEvent_t ev[12];
-  static bool ready = false;
-  if (!ready) {
-    for (int i = 0; i < 12; ++i)
-      if (hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) != hipSuccess) return nullptr;
-    ready = true;
-  }
-  return ev;
-}
-
 extern "C" int stemgnn_gru_bwd(const float* dh_all, const float* x, const float* w_hh, const float* h_ext,
                                const float* reserve, int B, int S, int Hd, int W, float* scratch, float* dw_ih,
-                               float* dw_hh, float* db_ih, float* db_hh, int* status, void* stream, void* side_stream,
-                               void* side_stream2) {
+                               float* dw_hh, float* db_ih, float* db_hh, int* status, void* stream) {
   if (!dh_all || !x || !w_hh || !h_ext || !reserve || !scratch || !dw_ih || !dw_hh || !db_ih || !db_hh || !status ||
       B <= 0 || S <= 0 || Hd <= 0 || W <= 0)
     return SG_EINVAL;
@@ -1321,31 +1007,20 @@ extern "C" int stemgnn_gru_bwd(const float* dh_all, const float* x, const float*
   float* p_ih = p_hh + (size_t)GRU_NSPLIT * 3 * Hd * (Hd + 1);
   const int P2 = gru_pick_P2(B, Hd);
   const int P = P2 > 0 ? 0 : gru_pick_P(B, Hd);
-  bool segmented = false, fold_ih = false, hh_fused = false, cnt_zeroed = false;
+  bool fold_ih = false, hh_fused = false, cnt_zeroed = false;
   GruWide wide;
   if (gru_pick_wide(B, Hd, P2, &wide) > 0) {
     float* xb = scratch + ((((size_t)(p_ih - scratch) + (size_t)gru_ih_slabs(B) * 3 * Hd * (W + 1)) + 3) & ~(size_t)3);
     SG_TRY(gru_wide_bwd(dh_all, w_hh, h_all, reserve, B, S, Hd, wide, xb, status, dgi, dghn, st));
   } else if (P2 > 0) {
-    // Time segmentation (side streams given): the S steps run as T launches; as soon as a segment's gate gradients are
-    // complete its share of the dW_hh / dW_ih reductions starts on the side streams and overlaps the next segment's
-    // (latency-bound) recurrence, so only the last segment's share is left on the critical path after the recurrence.
-    hipStream_t s1 = (hipStream_t)side_stream, s2 = (hipStream_t)side_stream2;
-    int T = 1;
-    if (s1 && s2 && S >= 64) {
-      // measured on MI355X (profiles/r02_gru_segments.md): every extra launch of the recurrence costs more than the
-      // overlap returns -- the LDS-reserving cluster kernel has to wait for the side streams' GEMM workgroups to drain
-      // from its CUs (+15-20 us per boundary, +30 us per segment) -- so segmentation is OFF by default
-      static const int env_t = getenv("STEMGNN_GRU_SEGMENTS") ? atoi(getenv("STEMGNN_GRU_SEGMENTS")) : 1;
-      T = env_t == 2 || env_t == 4 || env_t == 8 ? env_t : 1;
-    }
-    hipEvent_t* ev = T > 1 ? gru_events() : nullptr;
-    if (T > 1 && !ev) T = 1;
+    // (Round 2 also built two overlap schedules for the weight-gradient tail -- time segments of the recurrence and a
+    // progress mark released by a spin kernel -- which were parity-tested, measured SLOWER inside the hipGraph step
+    // (profiles/r02_gru_segments.md) and removed in round 4; the recurrence runs as ONE launch over all S steps.)
     float* xtail = scratch + ((((size_t)(p_ih - scratch) + (size_t)gru_ih_slabs(B) * 3 * Hd * (W + 1)) + 3) & ~(size_t)3);   // 16-byte aligned: one fill kernel
     gru_u64* xbuf = (gru_u64*)xtail;
     float* carry = xtail + gru_xbuf_floats(B, Hd);
     unsigned* progress = (unsigned*)(carry + (size_t)B * Hd);
-    gru_u64* xid0 = xbuf + (size_t)2 * B * 3 * Hd;           // P XCC-id granules per batch row and per segment launch
+    gru_u64* xid0 = xbuf + (size_t)2 * B * 3 * Hd;           // P XCC-id granules per batch row
     // ONE fill node ahead of the recurrence covers the exchange granules (tags := 0 every launch) and, behind carry /
     // progress, the arrival counters of the fused dW_hh kernel, which otherwise costs a ~6 us fill node of its own on the
     // critical path between the recurrence and that kernel (every memset is a graph node with its own launch latency)
@@ -1353,47 +1028,22 @@ extern "C" int stemgnn_gru_bwd(const float* dh_all, const float* x, const float*
     SG_TRY(hipMemsetAsync(xbuf, 0, (fill_end - (size_t)(xtail - scratch)) * sizeof(float), st));
     cnt_zeroed = true;
     static const int allow_fast = !(getenv("STEMGNN_GRU_FAST_XCD") && atoi(getenv("STEMGNN_GRU_FAST_XCD")) == 0);
-    // Early weight gradients (single launch of the recurrence): when every workgroup has passed step s_mark the rows of
-    // the steps >= s_mark are final; a spin kernel on side stream 1 waits for that mark and the dW_hh / dW_ih reductions
-    // of those rows run there under the REST of the recurrence -- only the rows below the mark are left for afterwards.
-    // OFF by default (STEMGNN_GRU_MARK=<percent of the steps> switches it on): it needs the spin kernel to run
-    // CONCURRENTLY with the recurrence, and a hipGraph replay gives no such guarantee -- measured, the graph executor
-    // placed the spin kernel behind the recurrence, so the early rows ran last and the step got 3 % slower
-    // (profiles/r02_gru_segments.md).  Correct in eager and in graph mode (parity-tested), useful only in eager mode.
-    int s_mark = -1;
-    if (T == 1 && s1 && s2 && S >= 64) {
-      static const int env_m = getenv("STEMGNN_GRU_MARK") ? atoi(getenv("STEMGNN_GRU_MARK")) : 0;
-      if (env_m > 0 && env_m < 100) s_mark = (int)((long)S * env_m / 100);
-      if (s_mark < 1) s_mark = -1;
-    }
-    if (s_mark > 0 && !ev) ev = gru_events();
-    if (s_mark > 0 && !ev) s_mark = -1;
-    if (s_mark > 0) {
-      SG_TRY(hipMemsetAsync(progress, 0, 4 * sizeof(unsigned), st));
-      SG_TRY(hipEventRecord(ev[10], st));                       // fork: the side stream may start waiting for the mark
-      SG_TRY(hipStreamWaitEvent(s1, ev[10], 0));
-    }
     const dim3 grid(8 * ((B + 7) / 8) * P2);
     const int KU2 = gru_pick_KU(Hd, P2);
-    const int nsplit_seg = GRU_NSPLIT / T;
-    for (int seg = 0; seg < T; ++seg) {
-      // segment seg covers steps s_hi .. s_lo (descending in time: the backward pass starts at step S - 1)
-      const int s_hi = S - 1 - (int)((long)S * seg / T), s_lo = S - (int)((long)S * (seg + 1) / T);
+    {
+      const int s_hi = S - 1, s_lo = 0, s_mark = -1;       // the whole range in one launch, no progress mark
 #define GRU_B2K(PP, KK, OO) do { const size_t hog = gru_lds_hog<PP>((const void*)gru_bwd_cluster2_kernel<PP, KK, OO>); \
     hipLaunchKernelGGL((gru_bwd_cluster2_kernel<PP, KK, OO>), grid, dim3(3 * (PP / OO) * 64), hog, st, dh_all, w_hh, h_all, \
                        reserve, B, S, Hd, xbuf, status, dgi, dghn, s_hi, s_lo, carry, s_mark, progress, \
-                       xid0 + (size_t)seg * 8 * B, allow_fast); } while (0)
+                       xid0, allow_fast); } while (0)
 #define GRU_B2(PP, OO) do { if (KU2 == 32) GRU_B2K(PP, 32, OO); else if (KU2 == 48) GRU_B2K(PP, 48, OO); \
                             else if (KU2 == 58) GRU_B2K(PP, 58, OO); else GRU_B2K(PP, 64, OO); } while (0)
-      const char* e4 = getenv("STEMGNN_GRU_V4");
-      // P = 6 (hidden 321..384: PEMS03) runs the wave-specialised backward with two owner slices per mat-vec wave
-      // (STEMGNN_GRU_V4_P6=0: the round-1 layout); P = 5 and P = 8 keep the round-1 layout (17 waves / register budget)
-      static const bool v4_p6 = !(getenv("STEMGNN_GRU_V4_P6") && atoi(getenv("STEMGNN_GRU_V4_P6")) == 0);
-      const bool v4 = !(e4 && atoi(e4) == 0) && (P2 <= 4 || (P2 == 6 && v4_p6)) && T == 1 && s_mark < 0;
+      // P <= 4 and P = 6 (hidden 321..384: PEMS03, two owner slices per mat-vec wave) run the wave-specialised backward
+      // (gru_cluster4.h); P = 5 and P = 8 keep the round-1 layout (17 waves / register budget)
+      const bool v4 = P2 <= 4 || P2 == 6;
       // dW_ih | db_ih accumulated by the chore wave while the gate gradients pass through it: one slab per batch row
-      // instead of the split-K GEMM behind the recurrence (STEMGNN_GRU_FOLD_IH=0: keep the GEMM)
-      const char* ef = getenv("STEMGNN_GRU_FOLD_IH");
-      fold_ih = v4 && W <= GRU4_WMAX && !(ef && atoi(ef) == 0);
+      // instead of the split-K GEMM behind the recurrence
+      fold_ih = v4 && W <= GRU4_WMAX;
       float* ih_slab = fold_ih ? p_ih : nullptr;
 #define GRU_B4K(PP, KK) do { const size_t hog = gru_lds_hog4<PP>((const void*)gru_bwd_cluster4_kernel<PP, KK>); \
     hipLaunchKernelGGL((gru_bwd_cluster4_kernel<PP, KK>), grid, dim3((3 * PP + 2) * 64), hog, st, dh_all, w_hh, h_all, reserve, B, S, \
@@ -1407,43 +1057,14 @@ extern "C" int stemgnn_gru_bwd(const float* dh_all, const float* x, const float*
         if (KU2 <= 58) GRU_B46K(58); else GRU_B46K(64);
       } else if (v4) {
         if (P2 == 1) GRU_B4(1); else if (P2 == 2) GRU_B4(2); else GRU_B4(4);
-      } else if (P2 == 1) GRU_B2(1, 1); else if (P2 == 2) GRU_B2(2, 1); else if (P2 == 4) GRU_B2(4, 1);
-      else if (P2 == 5) GRU_B2(5, 1); else if (P2 == 6) GRU_B2(6, 2); else GRU_B2(8, 2);
+      } else if (P2 == 5) GRU_B2(5, 1); else GRU_B2(8, 2);
 #undef GRU_B46K
 #undef GRU_B4
 #undef GRU_B4K
 #undef GRU_B2
 #undef GRU_B2K
       SG_TRY(hipGetLastError());
-      if (T > 1) {                                   // this segment's rows are final: reduce them on the side streams
-        SG_TRY(hipEventRecord(ev[seg], st));
-        SG_TRY(hipStreamWaitEvent(s1, ev[seg], 0));
-        SG_TRY(hipStreamWaitEvent(s2, ev[seg], 0));
-        const int rc = gru_wgrad_rows(dgi, dghn, h_ext, x, p_hh, p_ih, B, S, Hd, W, s_lo * B, (s_hi - s_lo + 1) * B,
-                                      seg * nsplit_seg, nsplit_seg, s1, s2);
-        if (rc) return rc;
-      }
     }
-    if (s_mark > 0) {
-      int n_early = (int)((long)GRU_NSPLIT * (S - s_mark) / S);
-      if (n_early < 1) n_early = 1;
-      if (n_early > GRU_NSPLIT - 1) n_early = GRU_NSPLIT - 1;
-      hipLaunchKernelGGL(gru_wait_progress_kernel, dim3(1), dim3(64), 0, s1, progress, (unsigned)(B * P2), status);
-      SG_TRY(hipGetLastError());
-      SG_TRY(hipEventRecord(ev[11], s1));
-      SG_TRY(hipStreamWaitEvent(s2, ev[11], 0));
-      int rc = gru_wgrad_rows(dgi, dghn, h_ext, x, p_hh, p_ih, B, S, Hd, W, s_mark * B, (S - s_mark) * B, 0, n_early, s1, s2);
-      if (rc) return rc;
-      rc = gru_wgrad_rows(dgi, dghn, h_ext, x, p_hh, p_ih, B, S, Hd, W, 0, s_mark * B, n_early, GRU_NSPLIT - n_early, st, st);
-      if (rc) return rc;
-    }
-    if (T > 1 || s_mark > 0) {                       // join both side streams before the fixed-order reduce
-      SG_TRY(hipEventRecord(ev[8], s1));
-      SG_TRY(hipEventRecord(ev[9], s2));
-      SG_TRY(hipStreamWaitEvent(st, ev[8], 0));
-      SG_TRY(hipStreamWaitEvent(st, ev[9], 0));
-    }
-    segmented = T > 1 || s_mark > 0;
   } else if (P > 0) {
     const GruCluster c = gru_cluster_geom(Hd, P);
     gru_u64* xbuf = (gru_u64*)(scratch + ((((size_t)(p_ih - scratch) + (size_t)gru_ih_slabs(B) * 3 * Hd * (W + 1)) + 1) & ~(size_t)1));
@@ -1461,20 +1082,11 @@ extern "C" int stemgnn_gru_bwd(const float* dh_all, const float* x, const float*
     hipLaunchKernelGGL(gru_bwd_kernel, dim3(B), dim3(1024), lds, st, dh_all, w_hh, h_all, reserve, B, S, Hd, dgi, dghn);
     SG_TRY(hipGetLastError());
   }
-  if (!segmented) {
-    // the two reductions are independent: with a side stream the small dW_ih product runs beside the dW_hh GEMM
-    hipStream_t s2 = (hipStream_t)side_stream2;
-    hipEvent_t* ev = s2 ? gru_events() : nullptr;
-    static const bool tail_par = getenv("STEMGNN_GRU_TAIL_PAR") && atoi(getenv("STEMGNN_GRU_TAIL_PAR")) == 1;   // measured: no gain
-    if (ev && tail_par) {
-      SG_TRY(hipEventRecord(ev[10], st));
-      SG_TRY(hipStreamWaitEvent(s2, ev[10], 0));
-    }
+  {
     // dW_hh | db_hh on the fused weight-gradient kernel (csrc/wgrad.h: direct-to-LDS ring, in-kernel fixed-order split
     // reduction, results written straight into dw_hh / db_hh; the slab region doubles as its partial-tile workspace) when
-    // the 16-byte rules hold (Hd % 4 == 0); otherwise (and with STEMGNN_GRU_WG_FUSED=0) 32 slabs + the reduce below
-    static const bool wg_on = !(getenv("STEMGNN_GRU_WG_FUSED") && atoi(getenv("STEMGNN_GRU_WG_FUSED")) == 0);
-    if (wg_on) {
+    // the 16-byte rules hold (Hd % 4 == 0); otherwise 32 slabs + the reduce below
+    {
       WgGemm q[2];
       q[0].A = dgi;  q[0].lda = 3 * Hd; q[0].Mi = 2 * Hd; q[0].out = dw_hh; q[0].out_bias = db_hh;
       q[1].A = dghn; q[1].lda = Hd;     q[1].Mi = Hd;     q[1].out = dw_hh + (size_t)2 * Hd * Hd; q[1].out_bias = db_hh + 2 * Hd;
@@ -1494,13 +1106,9 @@ extern "C" int stemgnn_gru_bwd(const float* dh_all, const float* x, const float*
         hh_fused = true;
       }
     }
-    const int rc = gru_wgrad_rows(dgi, dghn, h_ext, x, p_hh, p_ih, B, S, Hd, W, 0, S * B, 0, GRU_NSPLIT, st,
-                                  ev && tail_par ? s2 : st, !fold_ih, !hh_fused);
+    const int rc = gru_wgrad_rows(dgi, dghn, h_ext, x, p_hh, p_ih, B, S, Hd, W, 0, S * B, 0, GRU_NSPLIT, st, st, !fold_ih,
+                                  !hh_fused);
     if (rc) return rc;
-    if (ev && tail_par) {
-      SG_TRY(hipEventRecord(ev[11], s2));
-      SG_TRY(hipStreamWaitEvent(st, ev[11], 0));
-    }
   }
   {
     const size_t n0 = (size_t)2 * Hd * (Hd + 1);

@@ -11,6 +11,7 @@
 #include <math.h>
 
 #include "../../include/stemgnn_hip.h"
+#include "devattr.h"
 #include "layout.h"
 
 #define SG_TRY(e)                                \
@@ -71,6 +72,7 @@ extern "C" int stemgnn_make_tables_host(int W, int multi, float* t) {
 
 // ---- sizes ------------------------------------------------------------------------------------------------
 extern "C" const char* stemgnn_version(void) { return "stemgnn_hip 0.1 gfx950"; }
+extern "C" int stemgnn_num_cus(void) { return sg_num_cus(); }
 extern "C" size_t stemgnn_table_floats(int W, int multi) { return sg_table_layout(sg_dims(1, 1, W, multi)).total; }
 extern "C" size_t stemgnn_packed_floats(int W, int multi) { return sg_packed_layout(sg_dims(1, 1, W, multi)).total; }
 extern "C" size_t stemgnn_saved_floats(int B, int N, int W, int multi) { return sg_saved_layout(sg_dims(B, N, W, multi)).total; }

@@ -9,6 +9,7 @@
 #include <stdint.h>
 
 #include "../../include/stemgnn_hip.h"
+#include "devattr.h"
 
 #define SG_TRY(e)                                \
   do {                                           \
@@ -164,11 +165,8 @@ extern "C" int stemgnn_fc_tail_fwd(const float* fsum, const float* w0, const flo
   if (!fsum || !w0 || !b0 || !w2 || !b2 || !forecast || B <= 0 || N <= 0 || !stemgnn_fc_tail_supported(W, H))
     return SG_EINVAL;
   const size_t lds = fc_tail_fwd_lds(W, H);
-  static bool attr_done = false;
-  if (!attr_done && lds > 64 * 1024) {
-    SG_TRY(hipFuncSetAttribute((const void*)sg_fc_tail_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-    attr_done = true;
-  }
+  static SgDynLds lds_guard;
+  SG_TRY(sg_ensure_dyn_lds((const void*)sg_fc_tail_fwd_kernel, lds, lds_guard));
   hipLaunchKernelGGL(sg_fc_tail_fwd_kernel, dim3((B * N + TAIL_RB - 1) / TAIL_RB), dim3(256), lds, (hipStream_t)stream, fsum,
                      w0, b0, w2, b2, B, N, W, H, forecast);
   SG_TRY(hipGetLastError());
@@ -186,11 +184,8 @@ extern "C" int stemgnn_fc_tail_bwd(const float* dforecast, const float* fsum, co
   const int nblocks = (B * N + TAIL_RB - 1) / TAIL_RB;
   const size_t lds = fc_tail_bwd_lds(W, H);
   if (!stemgnn_fc_tail_supported(W, H)) return SG_EINVAL;
-  static bool attr_done = false;
-  if (!attr_done && lds > 64 * 1024) {
-    SG_TRY(hipFuncSetAttribute((const void*)sg_fc_tail_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-    attr_done = true;
-  }
+  static SgDynLds lds_guard;
+  SG_TRY(sg_ensure_dyn_lds((const void*)sg_fc_tail_bwd_kernel, lds, lds_guard));
   hipLaunchKernelGGL(sg_fc_tail_bwd_kernel, dim3(nblocks), dim3(256), lds, st, dforecast, fsum, w0, b0, w2, B, N, W, H, dfsum,
                      scratch);
   SG_TRY(hipGetLastError());
@@ -333,11 +328,8 @@ extern "C" int stemgnn_fc_tail_train(const float* fsum, const float* target, con
   const int nacc = W * W + W + H * W + H;
   const int nblocks = (B * N + TAIL_RB - 1) / TAIL_RB;
   const size_t lds = fc_tail_train_lds(W, H);
-  static bool attr_done = false;
-  if (!attr_done && lds > 64 * 1024) {
-    SG_TRY(hipFuncSetAttribute((const void*)sg_fc_tail_train_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-    attr_done = true;
-  }
+  static SgDynLds lds_guard;
+  SG_TRY(sg_ensure_dyn_lds((const void*)sg_fc_tail_train_kernel, lds, lds_guard));
   hipLaunchKernelGGL(sg_fc_tail_train_kernel, dim3(nblocks), dim3(256), lds, st, fsum, target, w0, b0, w2, b2, B, N, W, H,
                      forecast, dfsum, scratch);
   SG_TRY(hipGetLastError());

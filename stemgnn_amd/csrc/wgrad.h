@@ -29,6 +29,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "devattr.h"
 #include "gemm2.h"
 
 constexpr int WG_MAXG = 12;       // products per launch
@@ -399,17 +400,8 @@ __global__ __launch_bounds__(256, (STAGES * BK * 1024 <= 80 * 1024 ? 2 : 1)) voi
 struct WgPlan {
   int bk, stages, per_cu;   // kernel variant + target workgroups per CU
 };
-static inline WgPlan wg_plan_from_env() {
-  // STEMGNN_WG_CFG = "<BK>,<STAGES>,<workgroups per CU>"   (instantiated: 16,6 | 16,4 | 16,3 | 32,3)
-  WgPlan p{16, 6, 1};
-  if (const char* e = getenv("STEMGNN_WG_CFG")) {
-    int a = 0, b = 0, c = 0;
-    if (sscanf(e, "%d,%d,%d", &a, &b, &c) == 3 && c >= 1 && c <= 4) {
-      if ((a == 16 && (b == 6 || b == 4 || b == 3)) || (a == 32 && b == 3)) p = WgPlan{a, b, c};
-    }
-  }
-  return p;
-}
+// BK = 16, 6 ring stages, one workgroup per CU: the measured-best of {16,6 | 16,4 | 16,3 | 32,3} x {1, 2 per CU} (round 3)
+static inline WgPlan wg_plan() { return WgPlan{16, 6, 1}; }
 
 static inline bool wg_operand_ok(const void* p, int ld) { return (((uintptr_t)p) & 15) == 0 && (ld & 3) == 0; }
 
@@ -424,7 +416,7 @@ static inline bool wg_gemm_ok(const WgGemm& q) {
 // number of splits for `ntiles` output tiles and a K range of `K` rows (pure function: the workspace is sized by it)
 static inline int wg_splits(int ntiles, int K, int bk, int per_cu, int smax, int cu_percent = 100) {
   const int KT = (K + bk - 1) / bk;
-  const int slots = 256 * per_cu * (cu_percent < 10 ? 10 : (cu_percent > 100 ? 100 : cu_percent)) / 100;
+  const int slots = sg_num_cus() * per_cu * (cu_percent < 10 ? 10 : (cu_percent > 100 ? 100 : cu_percent)) / 100;
   int S = slots / (ntiles > 0 ? ntiles : 1);      // never more workgroups than slots: one straggler round doubles the time
   if (S < 1) S = 1;
   if (S == 1 && ntiles > 0 && ntiles < slots) {
@@ -465,7 +457,7 @@ static inline int wg_tile_index(WgGemm* q, int n) {
 static inline hipError_t wg_launch(WgGemm* q, int n, int K, float* ws, unsigned* cnt, int smax_ws, hipStream_t st,
                                    bool zero_counters = true, int cu_percent = 100) {
   if (n <= 0 || n > WG_MAXG || K <= 0) return hipErrorInvalidValue;
-  const WgPlan p = wg_plan_from_env();
+  const WgPlan p = wg_plan();
   WgArgs a;
   int tmax = 0;
   const int ntiles = wg_tile_index(q, n);
@@ -509,10 +501,7 @@ static inline hipError_t wg_launch(WgGemm* q, int n, int K, float* ws, unsigned*
   int maxload = 0;
   for (int c = 0; c < 8; ++c) maxload = load[c] > maxload ? load[c] : maxload;
   dim3 grid(a.use_tab ? 8 * maxload : 8 * ((groups + 7) / 8) * tmax);
-  if (p.bk == 16 && p.stages == 6) hipLaunchKernelGGL((sg_wgrad_kernel<16, 6>), grid, dim3(256), 0, st, a);
-  else if (p.bk == 16 && p.stages == 4) hipLaunchKernelGGL((sg_wgrad_kernel<16, 4>), grid, dim3(256), 0, st, a);
-  else if (p.bk == 16 && p.stages == 3) hipLaunchKernelGGL((sg_wgrad_kernel<16, 3>), grid, dim3(256), 0, st, a);
-  else hipLaunchKernelGGL((sg_wgrad_kernel<32, 3>), grid, dim3(256), 0, st, a);
+  hipLaunchKernelGGL((sg_wgrad_kernel<16, 6>), grid, dim3(256), 0, st, a);
   return hipGetLastError();
 }
 

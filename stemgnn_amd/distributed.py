@@ -4,7 +4,10 @@ distributed code at all).
 One process per GPU (torch.distributed, backend "nccl" == RCCL over xGMI on ROCm).  The path shards over
 the batch with no data-path collective ("replicas with a local graph"): every rank runs the
 reference math on its own batch shard; the only exchange is ONE flat fp32 all-reduce of the gradients
-per optimizer step (4.9 MB at PEMS07 -- latency-bound on xGMI, so a single bucket, no overlap machinery).
+per optimizer step (4.9 MB at PEMS07 -- latency-bound on xGMI).  Round 4: inside the captured step the flat buffer is
+reduced as TWO contiguous ranges -- the spectral blocks' + fc gradients (4.2 MB, complete when block 1's un-packing has run)
+on the side branch under the GRU backward recurrence, the GRU / attention gradients (0.67 MB) behind the GRU weight
+gradients -- so only the small one is exposed (engine.TrainStep).
 """
 import torch
 import torch.distributed as dist
@@ -48,6 +51,26 @@ class FlatGradBucket:
             join_side_streams(self.flat.device)      # weight gradients may still be in flight on the side stream
         if dist.is_available() and dist.is_initialized() and (force or dist.get_world_size(group) > 1):
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
+            return dist.get_world_size(group)
+        return 1
+
+    def offset_of(self, param):
+        """Offset (in elements) of `param`'s gradient view inside the flat buffer."""
+        off = 0
+        for p in self.params:
+            if p is param:
+                return off
+            off += p.numel()
+        raise ValueError("parameter is not in this bucket")
+
+    def all_reduce_range(self, lo, hi, group=None, force=False):
+        """SUM of flat[lo:hi] over the ranks on the CURRENT stream (no side-stream join: the caller orders it behind the
+        kernels that produce that range -- ops.SpectralHotPath.backward calls it on the side stream right behind block 1's
+        un-packing).  Same one-rank `force` semantics as all_reduce_sum."""
+        if hi <= lo:
+            return 1
+        if dist.is_available() and dist.is_initialized() and (force or dist.get_world_size(group) > 1):
+            dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=group)
             return dist.get_world_size(group)
         return 1
 

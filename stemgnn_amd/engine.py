@@ -50,12 +50,14 @@ class TrainStep:
                  exact=False, group=None, collective=None, one_graph=None):
         """collective: run the data-parallel step structure (gradient all-reduce between backward and optimizer); default
         world > 1, True forces it for a one-rank group (RCCL readiness on a 1-GPU box).  one_graph: capture the
-        all-reduce INSIDE the step's hipGraph (one replay per step) instead of graph / eager collective / graph; default
-        from STEMGNN_DDP_ONE_GRAPH (off: RCCL capture has only ever run with one rank here); a failed
-        capture falls back to the two-graph form."""
+        all-reduce INSIDE the step's hipGraph (one replay per step) instead of graph / eager collective / graph.  Default
+        since round 4: ON (STEMGNN_DDP_ONE_GRAPH=0 forces the two-graph form) -- the capture attempt itself is the start-up
+        probe: every rank reports whether its capture succeeded, the MIN over the ranks decides, and a failed capture falls
+        back to the two-graph form on ALL ranks together.  In the one-graph form the flat gradient buffer is reduced in two
+        ranges: blocks + fc on the side branch under the GRU recurrence, GRU / attention behind the GRU weight gradients."""
         self.model, self.opt = model, optimizer
         self.collective = (world > 1) if collective is None else bool(collective)
-        self.one_graph = (os.environ.get("STEMGNN_DDP_ONE_GRAPH", "0") == "1") if one_graph is None else bool(one_graph)
+        self.one_graph = (os.environ.get("STEMGNN_DDP_ONE_GRAPH", "1") == "1") if one_graph is None else bool(one_graph)
         self.B, self.W, self.H, self.N = int(batch_size), int(window_size), int(horizon), int(units)
         self.world = world
         dev = next(model.parameters()).device
@@ -73,7 +75,7 @@ class TrainStep:
         self.loss = torch.zeros((), device=dev)
         self.loss_sum = torch.zeros((), device=dev, dtype=torch.float64)
         self._one = torch.ones((), device=dev)
-        self.fuse_tail = hasattr(model, "loss") and os.environ.get("STEMGNN_FUSE_TAIL", "1") == "1"
+        self.fuse_tail = hasattr(model, "loss")     # fc tail + MSE + both backwards as one node (2 launches instead of 5)
         self.want_graph = bool(graph) and self.fused
         self.group = group
         if self.fused:
@@ -92,23 +94,29 @@ class TrainStep:
         self.mode = "eager"
         self._replay = None
         self._armed = False
+        # two-range gradient all-reduce (one-graph / eager collective form with the fused optimizer and the side stream): the
+        # tail range [split, numel) = both StockBlocks + fc is complete when block 1's un-packing has run and is reduced THERE
+        # (ops.HotPathState.block_grads_hook, side stream, under the GRU backward recurrence); _sync reduces the head range
+        # [0, split) = weight_key / weight_query / GRU behind the GRU weight gradients
+        self._split = None
+        if self.collective and self.fused and self.one_graph and self.state.overlap and hasattr(model, "stock_block"):
+            self._split = self.bucket.offset_of(next(model.stock_block[0].parameters()))
+            self.state.block_grads_hook = self._reduce_tail_range
 
     # -- the step body, on whatever tensors it is handed ------------------------------------------------------
     def _fwd_bwd(self, hi, x, y):
         # The side stream's work of the forward (weight packing, dropout key) only reads parameters: it forks from the
         # stream position BEFORE the step's first kernel (an event recorded here), not from behind the window gather --
         # inside a hipGraph a node whose successors sit on two queues releases them ~10 us late.  The work itself is queued
-        # after the gather so that the gather stays the first node the graph launches ("2"; "1": queued ahead of the
-        # gather, measured: the gather then starts 10 us late; "0": forked inside Model.hot_path, behind the gather).
-        early = os.environ.get("STEMGNN_EARLY_FORK", "2") if self.state.overlap and hasattr(self.model, "prefetch_side") else "0"
-        if early == "1":
-            self.model.prefetch_side(self.device)
-        elif early == "2":
+        # after the gather so that the gather stays the first node the graph launches (queued ahead of the gather, the
+        # gather starts 10 us late -- measured in round 3).
+        early = self.state.overlap and hasattr(self.model, "prefetch_side")
+        if early:
             self.state.fork_event = torch.cuda.Event()
             self.state.fork_event.record()
         if self.series is not None:
             ops.window_gather(self.series, hi, self.W, self.H, x, y)
-        if early == "2":
+        if early:
             self.model.prefetch_side(self.device)
         if not self.fuse_zero:
             if self.bucket is not None:
@@ -136,9 +144,25 @@ class TrainStep:
         finally:
             self.opt.grad_scale = prev
 
+    def _reduce_tail_range(self):
+        self.bucket.all_reduce_range(self._split, self.bucket.numel, self.group, force=True)
+
+    def _all_ranks_ok(self, ok):
+        """MIN over the ranks of a local success flag: every rank takes the same path after a capture attempt (a rank
+        falling back alone would issue a different sequence of collectives than its peers)."""
+        import torch.distributed as dist
+        if not (self.collective and dist.is_available() and dist.is_initialized()):
+            return ok
+        t = torch.tensor([1.0 if ok else 0.0], device=self.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group)
+        return bool(t.item() > 0.5)
+
     def _sync(self):
         if self.collective:
-            if self.fused:
+            if self.fused and self._split is not None:
+                ops.join_side_streams(self.device)      # orders the tail range's all-reduce (side stream) ahead of this one
+                self.bucket.all_reduce_range(0, self._split, self.group, force=True)
+            elif self.fused:
                 self.bucket.all_reduce_sum(self.group, force=True)
             else:
                 self.bucket.all_reduce_mean(self.group)
@@ -156,6 +180,10 @@ class TrainStep:
             snap = self._snapshot()
             rep = capture(whole, on_fail=self.state.reset)
             self._restore(snap)
+            if not self._all_ranks_ok(rep is not None):
+                rep = None
+            if rep is None and self._split is not None:     # two-graph / eager form: one all-reduce between the graphs
+                self._split, self.state.block_grads_hook = None, None
             if rep is not None:
                 self._replay = rep
                 self.mode = "hipgraph(whole step incl. rccl all-reduce)" if self.collective else "hipgraph(whole step)"
@@ -173,7 +201,7 @@ class TrainStep:
             ra = capture(part_a, on_fail=self.state.reset)
             rb = capture(part_b, on_fail=self.state.reset) if ra is not None else None
             self._restore(snap)
-            if ra is not None and rb is not None:
+            if self._all_ranks_ok(ra is not None and rb is not None):
                 def rep():
                     ra(); self._sync(); rb()
                 self._replay, self.mode = rep, "hipgraph(fwd+bwd) + rccl all-reduce + hipgraph(optimizer)"

@@ -13,7 +13,7 @@ import torch
 
 from . import _lib
 
-_NSPLIT = int(os.environ.get("STEMGNN_NSPLIT", "32"))     # split-M factor of the weight-gradient GEMMs
+_NSPLIT = 32      # split-M factor of the slab weight-gradient GEMMs (heads' BS product; GLU only on the fallback path)
 _side_streams = {}
 
 
@@ -48,11 +48,13 @@ class HotPathState:
         self.fork_event = None       # optional event the next prepack_blocks forks the side stream from
         self.pending = None          # (side stream, keep-alive objects) of weight-gradient work not yet joined
         self.exact_group = None      # data-parallel "exact mode" (SURVEY 8e-ii): (process group, world size) or None
+        self.block_grads_hook = None # callable run on the side stream right behind block 1's un-packing (overlap mode): the
+                                     # step driver's all-reduce of the block / fc gradient range (engine.TrainStep)
         _states.add(self)
 
     def set(self, direct=True, overlap=False):
         self.direct = bool(direct)
-        self.overlap = bool(direct) and bool(overlap) and os.environ.get("STEMGNN_OVERLAP_WGRAD", "1") == "1"
+        self.overlap = bool(direct) and bool(overlap)
         return self
 
     def join(self):
@@ -110,24 +112,23 @@ def set_direct_grad(model, flag=True, overlap=False):
     return model.hot_state.set(flag, overlap)
 
 
-_NCHUNK = int(os.environ.get("STEMGNN_ATTN_CHUNKS", "16"))  # row chunks of the attention backward
-# share of the CUs (percent) the fused weight-gradient launches fill in side-stream mode: [0] the first launch on the side
-# stream (beside GEMM / Chebyshev kernels of the main stream), [1] the second (under the GRU recurrence: half of the CUs)
-_WG_CU = (int(os.environ.get("STEMGNN_WG_CU0", "100")), int(os.environ.get("STEMGNN_WG_CU1", "0")))
+_NCHUNK = 16      # row chunks of the attention backward
 
 
 def _wg_cu(which, B, N):
-    """CU share (percent) of the side stream's first / second fused weight-gradient launch.  The second one runs under the
-    GRU backward recurrence, which pins stemgnn_gru_bwd_cus(B, N) CUs for its whole run: unless STEMGNN_WG_CU1 says
-    otherwise it is sized for what is left (50 % at PEMS07 where 4 workgroups serve a batch row, 25 % at N = 358 with 6; hidden sizes of the wide cluster keep 50)."""
-    if which == 0 or _WG_CU[1] > 0:
-        return _WG_CU[which]
+    """CU share (percent) of the side stream's first / second fused weight-gradient launch.  The first runs beside the
+    Chebyshev / attention backward chain and is sized for the whole chip (80 / 65 % measured 0 / +18 us per step); the second
+    runs under the GRU backward recurrence, which pins stemgnn_gru_bwd_cus(B, N) CUs for its whole run, and is sized for
+    what is left (50 % at PEMS07 where 4 workgroups serve a batch row, 25 % at N = 358 with 6; hidden sizes of the wide
+    cluster keep 50)."""
+    if which == 0:
+        return 100
     if N > 512:          # wide cluster (hidden > 512): the weight-gradient work there exceeds what the idle CUs could do in
         return 50        # the recurrence's time -- the round-2/3 setting (half of the chip, sharing CUs with the cluster) stays
-    busy = _lib.load().stemgnn_gru_bwd_cus(B, N)
-    return max(10, min(100, (256 - busy) * 100 // 256))
-_WG_SCHED = os.environ.get("STEMGNN_WG_SCHED", "late")
-_WG_FORK = os.environ.get("STEMGNN_WG_FORK", "dgrad")
+    lib = _lib.load()
+    cus = lib.stemgnn_num_cus()
+    busy = lib.stemgnn_gru_bwd_cus(B, N)
+    return max(10, min(100, (cus - busy) * 100 // cus))
 
 
 def _stream():
@@ -206,11 +207,20 @@ def gru_status_exists(device):
     return str(device) in _gru_status
 
 
-def check_eigh_status():
-    """Host sync + raise if a grid-barrier wait of the direct eigensolver timed out (STEMGNN_SPECTRAL=eig only)."""
-    rc = _lib.load().stemgnn_eigh_status()
+def check_eigh_status(device=None):
+    """Host sync + raise if the direct eigensolver flagged a run on `device` (STEMGNN_SPECTRAL=eig only).  The library
+    keeps one status word per device and clears it when it is read, so an event is reported once."""
+    dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+    with torch.cuda.device(dev):
+        rc = _lib.load().stemgnn_eigh_status()
+    if rc == 2:
+        raise _lib.StemGNNHipError(f"eigensolver status 2 on {dev}: a grid-barrier wait of the tridiagonalisation timed "
+                                   "out (a workgroup of its cluster was not resident)")
+    if rc == 3:
+        raise _lib.StemGNNHipError(f"eigensolver status 3 on {dev}: the re-solve of an eigenvalue cluster broke down "
+                                   "(no independent start vector left)")
     if rc != 0:
-        raise _lib.StemGNNHipError(f"eigensolver status {rc}: a workgroup of the tridiagonalisation cluster was not resident")
+        raise _lib.StemGNNHipError(f"eigensolver status {rc} on {dev}")
 
 
 def check_gru_status(device):
@@ -268,13 +278,10 @@ class GruFront(torch.autograd.Function):
             dw_ih, dw_hh = torch.empty_like(w_ih), torch.empty_like(w_hh)
             db_ih = torch.empty(3 * Hd, device=dev, dtype=f32)
             db_hh = torch.empty(3 * Hd, device=dev, dtype=f32)
-        # the two side-stream handles are only used by the opt-in schedules (STEMGNN_GRU_SEGMENTS / _MARK / _TAIL_PAR, all
-        # off by default: measured slower inside the hipGraph step); the default path runs on the current stream alone
-        sides = (_side_stream(dev).cuda_stream, _side_stream(dev, 1).cuda_stream) if ctx.state.overlap else (None, None)
         _lib.check(lib.stemgnn_gru_bwd(dh_all.data_ptr(), x.data_ptr(), w_hh.data_ptr(), h_ext.data_ptr(),
                                        reserve.data_ptr(), B, S, Hd, W, scratch.data_ptr(), dw_ih.data_ptr(),
                                        dw_hh.data_ptr(), db_ih.data_ptr(), db_hh.data_ptr(),
-                                       gru_status(dev).data_ptr(), _stream(), *sides), "gru_bwd")
+                                       gru_status(dev).data_ptr(), _stream()), "gru_bwd")
         ctx.state.join()                # the spectral blocks' weight gradients (side stream) overlapped this recurrence
         if direct:
             return None, None, None, None, None, None
@@ -345,7 +352,12 @@ class FcTailMse(torch.autograd.Function):
         dev, f32 = fsum.device, torch.float32
         prm = (w0, b0, w2, b2)
         w0c, b0c, w2c, b2c = (t.contiguous() for t in prm)
-        direct = ctx.state.direct and all(p.grad is not None and p.grad.is_contiguous() for p in prm)
+        # direct writes into p.grad only for a call that WILL be back-propagated with an upstream gradient of 1
+        # (unit_grad: the step driver's promise): a logging call under no_grad, or a scaled loss, must not clobber the
+        # flat gradient bucket -- those use temporaries that backward scales and returns
+        wanted = any(ctx.needs_input_grad[i] for i in (0, 2, 3, 4, 5))
+        direct = ctx.state.direct and bool(unit_grad) and wanted and \
+            all(p.grad is not None and p.grad.is_contiguous() for p in prm)
         grads = [p.grad for p in prm] if direct else [torch.empty_like(p) for p in prm]
         dfsum = torch.empty_like(fsum)
         loss = loss_out if loss_out is not None else torch.empty((), device=dev, dtype=f32)
@@ -371,8 +383,6 @@ class FcTailMse(torch.autograd.Function):
             dfsum = dfsum * grad_loss
             if grads is not None:
                 grads = [g * grad_loss for g in grads]
-            elif ctx.direct:                      # gradients already sit in p.grad for an upstream gradient of 1
-                raise _lib.StemGNNHipError("FcTailMse in direct-gradient mode needs unit_grad=True (loss.backward())")
         if grads is None:
             return dfsum, None, None, None, None, None, None, None, None, None
         return dfsum, None, grads[0], grads[1], grads[2], grads[3], None, None, None, None
@@ -505,8 +515,8 @@ class StockBlockFn(torch.autograd.Function):
         if use_bc and ctx.needs_input_grad[0]:
             # short-cut input of the backcast head (:71-72): backcast = sigmoid(BC(ig) - BS(x)) also depends on x directly.
             # Model.forward never needs this term (x is data); only a stand-alone block with a differentiable input does.
-            dpb = dbackcast * backcast * (1.0 - backcast)
-            dX = dX - torch.matmul(dpb, params[7])
+            _lib.check(lib.stemgnn_shortcut_dx(scratch.data_ptr(), params[7].data_ptr(), dX.data_ptr(), B, N, W, multi, st),
+                       "shortcut_dx")
         return (dX, dmul_L, None, None, *grads)
 
 
@@ -607,7 +617,7 @@ class SpectralHotPath(torch.autograd.Function):
             U = torch.empty(N, N, device=dev, dtype=f32)
             escr = torch.empty(lib.stemgnn_eigh_scratch_floats(N), device=dev, dtype=f32)
             _lib.check(lib.stemgnn_eigh_fwd(mul_L.data_ptr(), lam.data_ptr(), U.data_ptr(), escr.data_ptr(), N,
-                                            int(os.environ.get("STEMGNN_EIG_SWEEPS", "0")), st), "eigh_fwd")
+                                            0, st), "eigh_fwd")
         else:
             _lib.check(lib.stemgnn_cheb_fwd(mul_L.data_ptr(), N, st), "cheb_fwd")
 
@@ -696,9 +706,8 @@ class SpectralHotPath(torch.autograd.Function):
         # downstream in the backward pass.  overlap: both blocks' weight gradients go to the side stream, block 0's
         # first (it overlaps the cheb / attention chain), then block 1's, which then runs under the GRU recurrence
         # (that kernel is latency-bound on half of the CUs and reserves its CUs' LDS, so the GEMMs land on the idle
-        # CUs); block 1 therefore keeps its own scratch / partial buffers until the join.  STEMGNN_DEFER_B1=0 keeps
-        # block 1's weight gradients in order on the main stream with one shared scratch (less memory).
-        defer_b1 = overlap and os.environ.get("STEMGNN_DEFER_B1", "1") == "1"
+        # CUs); block 1 therefore keeps its own scratch / partial buffers until the join.
+        defer_b1 = overlap
         scratch0 = torch.empty(n_scratch, device=dev, dtype=f32)
         gradpart0 = torch.empty(n_gradpart, device=dev, dtype=f32)
         bufs = {0: (scratch0, gradpart0), 1: (scratch0, gradpart0)}
@@ -742,12 +751,11 @@ class SpectralHotPath(torch.autograd.Function):
 
             return heads, glu, wgrad, unpack
 
-        # side-stream schedule (STEMGNN_WG_SCHED): "late" (default): both launches behind block 0's data-gradient chain --
-        # block 0's beside the Chebyshev / attention backward chain, block 1's (sized for half of the CUs) under the GRU
-        # recurrence.  "early" forks block 1's right behind its own chain, beside block 0's MFMA-bound data-gradient
-        # kernels: measured 170 us SLOWER per step (two GEMM streams on one chip are zero-sum, profiles/r03_wgrad.md).
-        early = overlap and defer_b1 and _WG_SCHED == "early"
-        late_fork = None
+        # side-stream schedule: both weight-gradient launches fork right behind block 0's data-gradient chain -- block 0's
+        # runs beside the Chebyshev / attention backward chain, block 1's (sized for the CUs the GRU leaves free) under the
+        # GRU recurrence.  Measured alternatives (round 3, removed in round 4): forking block 1's right behind its own chain,
+        # beside block 0's MFMA-bound data-gradient kernels, +170 us per step (two GEMM streams on one chip are zero-sum);
+        # forking only behind the Chebyshev backward +32 us; block 0's GFT backward ahead of the fork +9 us.
         for s in (1, 0):
             scratch = bufs[s][0]
             dG = scratch[off_dG:]
@@ -755,58 +763,30 @@ class SpectralHotPath(torch.autograd.Function):
             heads, glu, wgrad, unpack = stage_fns(s)
             heads(st)
             glu(st)
-
-            def gft():
-                _lib.check(lib.stemgnn_gft_bwd(
-                    mul_L.data_ptr(), X.data_ptr(), sb, sn, stt, dG.data_ptr(),
-                    dbackcast.data_ptr() if s == 1 else None, dmul_L.data_ptr(), int(s == 0), B, N, W, st), "gft_bwd")
-            # STEMGNN_GFT_FIRST=1: block 0's GFT backward goes out BEFORE the fork instead of behind it.  Behind the fork it
-            # runs beside the chip-filling weight-gradient launch (70 us instead of 18 in the r03 step timeline), but moving
-            # it only moves the contention to the Chebyshev / attention kernels that follow: A/B on one box 1.380 / 1.382 ms
-            # per step with it, 1.370 / 1.373 without -> off
-            gft_first = overlap and s == 0 and not early and os.environ.get("STEMGNN_GFT_FIRST", "0") == "1"
-            if gft_first:
-                gft()
-            if overlap and (s == 0 or defer_b1):
-                if early:
-                    side.wait_stream(main)                   # fork behind THIS block's data-gradient chain
+            if overlap:
+                if s == 0:
+                    side.wait_stream(main)               # fork: every data-gradient chain is queued
                     with torch.cuda.stream(side):
-                        wgrad(side.cuda_stream, _wg_cu(1 - s, B, N))   # [0]: launch beside the GEMM chain, [1]: under the GRU
-                        unpack(side.cuda_stream)
-                    if s == 0:
-                        keep.append(bufs)                    # alive until the join
-                elif s == 0:
-                    def launch_side(heads=heads, glu=glu, wgrad=wgrad, unpack=unpack):
-                        side.wait_stream(main)               # fork: every data-gradient chain is queued
-                        with torch.cuda.stream(side):
-                            sst = side.cuda_stream
-                            for ss in ((0, 1) if defer_b1 else (0,)):
-                                _h, _g, w2, u2 = (heads, glu, wgrad, unpack) if ss == 0 else stage_fns(1)
-                                w2(sst, _wg_cu(ss, B, N))
-                                u2(sst)
-                        keep.append(bufs)                    # alive until the join
-                    # STEMGNN_WG_FORK: where the side stream forks.  "dgrad" (default): right behind block 0's
-                    # data-gradient chain.  "cheb": behind the GFT / Chebyshev backward products, which run 125 us instead
-                    # of 45 beside the chip-filling weight-gradient launch -- but the side chain's apparent slack under the
-                    # GRU recurrence is not there: measured 1.399 / 1.398 ms per step against 1.367 / 1.368 (A/B on one
-                    # box), the later start of the second launch costs more than the uncontended kernels return
-                    if _WG_FORK == "cheb":
-                        late_fork = launch_side
-                    else:
-                        launch_side()
+                        sst = side.cuda_stream
+                        for ss in (0, 1):
+                            _h, _g, w2, u2 = (heads, glu, wgrad, unpack) if ss == 0 else stage_fns(1)
+                            w2(sst, _wg_cu(ss, B, N))
+                            u2(sst)
+                        if state.block_grads_hook is not None:
+                            state.block_grads_hook()     # data-parallel: reduce the finished range under the GRU recurrence
+                    keep.append(bufs)                    # alive until the join
             else:
                 wgrad(st, 100)
                 unpack(st)
-            if not gft_first:
-                gft()
+            _lib.check(lib.stemgnn_gft_bwd(
+                mul_L.data_ptr(), X.data_ptr(), sb, sn, stt, dG.data_ptr(),
+                dbackcast.data_ptr() if s == 1 else None, dmul_L.data_ptr(), int(s == 0), B, N, W, st), "gft_bwd")
         if overlap:
             state.pending = (side, (keep, packed, saved, split, backcast, dfsum, dbackcast))
         dL = torch.empty(N, N, device=dev, dtype=f32)
         cheb_scratch = torch.empty(2 * N * N, device=dev, dtype=f32)
         _lib.check(lib.stemgnn_cheb_bwd(mul_L.data_ptr(), dmul_L.data_ptr(), dL.data_ptr(), cheb_scratch.data_ptr(),
                                         N, st), "cheb_bwd")
-        if late_fork is not None:
-            late_fork()
         dh = torch.empty_like(h)
         kq_direct = state.direct and wk.grad is not None and wq.grad is not None
         dwk = wk.grad if kq_direct else torch.empty_like(wk)

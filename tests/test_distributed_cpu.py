@@ -62,6 +62,41 @@ def test_flat_bucket_allreduce_equals_single_process():
     assert torch.allclose(f0, ref, atol=1e-6)
 
 
+def _range_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(3)
+    net = torch.nn.Sequential(torch.nn.Linear(4, 6), torch.nn.Linear(6, 5), torch.nn.Linear(5, 2))
+    one, two = FlatGradBucket(net.parameters()), None
+    torch.manual_seed(50 + rank)
+    g = torch.randn(one.numel)
+    one.flat.copy_(g)
+    one.all_reduce_sum()
+    whole = one.flat.clone()
+    two = FlatGradBucket(net.parameters())
+    two.flat.copy_(g)
+    split = two.offset_of(net[1].weight)                 # head = first layer, tail = the rest (engine.TrainStep's split)
+    assert split == 4 * 6 + 6
+    two.all_reduce_range(split, two.numel)              # tail range first (the side branch), then the head range
+    two.all_reduce_range(0, split)
+    out[rank] = (whole, two.flat.clone(), two.all_reduce_range(5, 5))
+    dist.destroy_process_group()
+
+
+def test_two_range_allreduce_equals_one_flat_allreduce():
+    """engine.TrainStep reduces the flat gradient buffer as two contiguous ranges (blocks + fc on the side branch, GRU /
+    attention behind the GRU weight gradients): together they are exactly the single flat all-reduce."""
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_range_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    for r in range(world):
+        whole, ranged, empty = out[r]
+        assert torch.equal(whole, ranged)
+        assert empty == 1                                # an empty range issues no collective
+    assert torch.equal(out[0][0], out[1][0])
+
+
 @pytest.mark.parametrize("B,world", [(32, 8), (7, 2), (5, 4), (3, 4)])
 def test_shard_batch_partitions(B, world):
     spans = [shard_batch(B, r, world) for r in range(world)]

@@ -40,8 +40,7 @@ def test_gru_fwd_bwd_vs_torch_cpu(B, S, W, cluster, monkeypatch):
 def test_gru_six_workgroup_cluster_backward_vs_torch_cpu(B, S, W, monkeypatch):
     """Hidden sizes 321..384 (PEMS03's N = 358): six workgroups per batch row, the wave-specialised backward with two owner
     slices per mat-vec wave (round 3), against torch's CPU GRU and for launch-to-launch bit reproducibility (W = 20 exceeds
-    the in-recurrence dW_ih accumulation and takes the GEMM path; the round-1 layout of the same cluster,
-    STEMGNN_GRU_V4_P6=0, is read once per process and is covered by the cluster="2" cases of the test above before round 3)."""
+    the in-recurrence dW_ih accumulation and takes the GEMM path)."""
     from stemgnn_amd.ops import GruFront, check_gru_status
 
     torch.manual_seed(S + B)
@@ -66,98 +65,6 @@ def test_gru_six_workgroup_cluster_backward_vs_torch_cpu(B, S, W, monkeypatch):
     torch.cuda.synchronize()
     for a, p in zip(g1, params):
         assert torch.equal(a, p.grad)
-
-
-@pytest.mark.parametrize("B,S,W", [(32, 228, 12), (5, 33, 7), (3, 140, 12), (2, 300, 4), (4, 307, 12)])
-def test_gru_forward_wave_per_owner_is_bit_identical(B, S, W, monkeypatch):
-    """The round-2 forward (one wave per owner slice, three gates per broadcast) sums every gate in the order of the
-    round-1 kernel (one wave per gate and owner, STEMGNN_GRU_FWD3=0): same bits."""
-    from stemgnn_amd.ops import GruFront, check_gru_status
-
-    torch.manual_seed(S + 3 * B)
-    gru = torch.nn.GRU(W, S)
-    x = torch.randn(B, W, S).cuda()
-    params = [p.detach().clone().cuda() for p in (gru.weight_ih_l0, gru.weight_hh_l0, gru.bias_ih_l0, gru.bias_hh_l0)]
-    outs = []
-    for flag in ("1", "0"):
-        monkeypatch.setenv("STEMGNN_GRU_FWD3", flag)
-        outs.append(GruFront.apply(x, *params).clone())
-    torch.cuda.synchronize()
-    check_gru_status(torch.device("cuda:0"))
-    assert torch.equal(outs[0], outs[1])
-
-
-@pytest.mark.parametrize("B,S,W", [(32, 228, 12), (5, 33, 7), (3, 140, 12), (2, 64, 5), (1, 100, 3), (7, 250, 12), (2, 1, 4), (2, 2, 4)])
-def test_gru_wave_specialised_kernels_are_bit_identical(B, S, W, monkeypatch):
-    """gru_cluster4.h (a dedicated gate wave, the chores done by the polling waves) against the round-1 layout
-    (STEMGNN_GRU_V4=0, STEMGNN_GRU_FWD3=0): same mat-vec chains, same order of the partial sums -> the same bits in
-    the hidden states; the gradients agree to rounding."""
-    from stemgnn_amd.ops import GruFront, check_gru_status
-
-    torch.manual_seed(S + 5 * B)
-    gru = torch.nn.GRU(W, S)
-    x = torch.randn(B, W, S).cuda()
-    dh = torch.randn(S, B, S).cuda()
-    ref = (gru.weight_ih_l0, gru.weight_hh_l0, gru.bias_ih_l0, gru.bias_hh_l0)
-    runs = []
-    for v4 in ("1", "0"):
-        monkeypatch.setenv("STEMGNN_GRU_V4", v4)
-        monkeypatch.setenv("STEMGNN_GRU_FWD3", v4)
-        monkeypatch.setenv("STEMGNN_GRU_FWD_P", "0")          # the backward's cluster size (the default forward is wider)
-        params = [p.detach().clone().cuda().requires_grad_(True) for p in ref]
-        h = GruFront.apply(x, *params)
-        h.backward(dh)
-        torch.cuda.synchronize()
-        runs.append([h.detach().clone()] + [p.grad.clone() for p in params])
-    check_gru_status(torch.device("cuda:0"))
-    assert torch.equal(runs[0][0], runs[1][0])                    # hidden states: the same bits
-    for a, c in zip(runs[0][1:], runs[1][1:]):                    # gradients: rounding only (fma contraction differs)
-        assert relerr(a, c) < 2e-6
-
-
-@pytest.mark.parametrize("mode", ["mark", "segments"])
-@pytest.mark.parametrize("B,S,W", [(32, 228, 12), (9, 358, 12), (3, 140, 12), (2, 64, 5)])
-def test_gru_backward_time_segments_vs_torch_cpu(B, S, W, mode):
-    """Overlap mode (side streams given) of the GRU backward, both schedules against torch's CPU GRU + bitwise
-    reproducibility:
-      mark      STEMGNN_GRU_MARK=30: one launch; when every workgroup has passed the progress mark (30 % of the steps) a
-                spin kernel releases the dW_hh / dW_ih reductions of the finished rows on the side streams, under the
-                rest of the recurrence;
-      segments  STEMGNN_GRU_SEGMENTS=4: four launches with the recurrent dh carried through global memory.
-    Both are off by default (measured slower inside the hipGraph train step, profiles/r02_gru_segments.md); the library
-    reads the switches once per process, so each case re-runs itself in a child process with its switch set."""
-    from stemgnn_amd import ops
-    from stemgnn_amd.ops import GruFront, check_gru_status
-
-    torch.manual_seed(S + B)
-    gru = torch.nn.GRU(W, S)
-    x = torch.randn(B, W, S)
-    dh = torch.randn(S, B, S)
-    out, _ = gru(x.permute(2, 0, 1).contiguous())
-    out.backward(dh)
-    ref = (gru.weight_ih_l0, gru.weight_hh_l0, gru.bias_ih_l0, gru.bias_hh_l0)
-    import subprocess, sys
-    switch = {"segments": ("STEMGNN_GRU_SEGMENTS", "4"), "mark": ("STEMGNN_GRU_MARK", "30")}[mode]
-    if os.environ.get(switch[0]) != switch[1]:
-        env = dict(os.environ, **{switch[0]: switch[1]})
-        r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", f"{__file__}::test_gru_backward_time_segments_vs_torch_cpu[{B}-{S}-{W}-{mode}]"],
-                           env=env, capture_output=True, text=True, timeout=600)
-        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-        return
-    state = ops.HotPathState()
-    state.overlap = True                                   # side streams on: segmentation active (S >= 64)
-    runs = []
-    for _ in range(2):
-        params = [p.detach().clone().cuda().requires_grad_(True) for p in ref]
-        h = GruFront.apply(x.cuda(), *params, state)
-        h.backward(dh.cuda())
-        torch.cuda.synchronize()
-        runs.append([p.grad.clone() for p in params])
-    check_gru_status(torch.device("cuda:0"))
-    assert relerr(h, out.detach()) < TOL
-    for mine, again, r in zip(runs[0], runs[1], ref):
-        assert relerr(mine, r.grad) < TOL
-        assert torch.equal(mine, again)
 
 
 @pytest.mark.parametrize("B,S,W,force", [(8, 1024, 12, False), (16, 2048, 48, False), (5, 100, 7, True), (3, 228, 12, True),

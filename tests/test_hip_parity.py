@@ -386,8 +386,9 @@ def test_large_config_shapes(N, W, multi, H, B):
 
 @pytest.mark.parametrize("shape", [(32, 228, 12, 5), (3, 20, 12, 5), (2, 9, 4, 2)])
 def test_fused_three_layer_glu_forward_matches_layerwise(shape, monkeypatch):
-    """STEMGNN_GLU3=1 (opt-in fused three-layer kernel, activations resident in LDS) against the default three
-    per-layer GEMM launches on the same packed weights and GFT output: every saved out / gate tensor agrees."""
+    """The fused three-layer GLU forward (csrc/glu_fused.h: activations of a row block resident in LDS, weight stream on a
+    direct-to-LDS ring; the default where its shape rules hold) against the three per-layer GEMM launches
+    (STEMGNN_GLU_FUSED=0) on the same packed weights and GFT output: every saved out / gate tensor agrees."""
     from stemgnn_amd import _lib, ops
     from stemgnn_amd.base_model import StockBlockLayer
     B, N, W, multi = shape
@@ -403,13 +404,13 @@ def test_fused_three_layer_glu_forward_matches_layerwise(shape, monkeypatch):
     G = torch.randn(B * N * 3 * W, device=dev)
     outs = []
     for flag in ("0", "1"):
-        monkeypatch.setenv("STEMGNN_GLU3", flag)
+        monkeypatch.setenv("STEMGNN_GLU_FUSED", flag)
         sv = torch.zeros(n_saved, device=dev)
         sv[: G.numel()] = G
         _lib.check(lib.stemgnn_spectral_glu_fwd(pk.data_ptr(), sv.data_ptr(), B, N, W, multi, st), "glu_fwd")
         torch.cuda.synchronize()
         outs.append(sv.clone())
-    monkeypatch.delenv("STEMGNN_GLU3")
+    monkeypatch.delenv("STEMGNN_GLU_FUSED")
     ref, got = outs
     assert float(ref[G.numel():].abs().max()) > 0
     assert relerr(got, ref) < 1e-6

@@ -2,16 +2,38 @@
 import json
 import sys
 
+
+def rows(v):
+    return v if isinstance(v, list) else [v] if v else []
+
+
 try:
     d = json.loads([ln for ln in open(sys.argv[1]) if ln.startswith("{")][-1])
     print("ms/step %.4f  value %.0f  %s" % (d["ms_per_step"], d["value"], d["config"]["launch"]))
     for k, v in d.get("roofline_families", {}).items():
-        print("  %-10s %6.1f us/launch  frac %.3f (executed %.3f)  mfma_util %s" % (
-            k, v["avg_launch_us"], v["frac"], v["frac_executed"], v.get("mfma_util")))
-    for o in d.get("other_configs", []):
-        print("  ", o["config"][:30], "%.3f ms" % o["ms_per_step"] if "ms_per_step" in o else o.get("error"))
-    for v in d.get("dtype_variants", []):
-        print("  ", v["dtype"], "%.4f ms" % v["ms_per_step"] if "ms_per_step" in v else v.get("error"))
+        print("  %-10s %6.1f us/launch x%d  frac %.3f (executed %.3f)" % (
+            k, v["avg_launch_us"], v["launches_per_step"], v["frac"], v["frac_executed"]))
+    g = d.get("gru")
+    if g:
+        print("  gru fwd %.0f us  bwd+wgrad %.0f us  share %.2f" % (g["fwd_us"], g["bwd_incl_weight_grads_us"], g.get("share_of_step", 0)))
+    for o in rows(d.get("other_configs")):
+        if "ms_per_step" not in o:
+            print("  ", o.get("config", "?")[:30], o.get("error"))
+            continue
+        extra = ""
+        if "gru" in o:
+            extra = "  gru %.2f/%.2f us/step" % (o["gru"]["fwd_us_per_recurrence_step"], o["gru"]["bwd_us_per_recurrence_step"])
+        if "roofline_families" in o:
+            extra += "  glu " + "/".join("%.2f" % v["frac"] for v in o["roofline_families"].values())
+        cpu = o.get("cpu_baseline", {})
+        if "ms_per_step" in cpu:
+            extra += "  cpu %.0f ms" % cpu["ms_per_step"]
+        print("  ", o["config"][:30], "%.3f ms" % o["ms_per_step"], extra)
+    for v in rows(d.get("dtype_variants")):
+        print("  ", v.get("dtype"), "%.4f ms" % v["ms_per_step"] if "ms_per_step" in v else v.get("error"))
+    for v in rows(d.get("spectral_variants")):
+        print("  eig", v.get("config", "?")[:30], ("%.3f ms/step, eigh %.0f us" % (v["ms_per_step"], v["eigh_us"]))
+              if "ms_per_step" in v else v.get("error"))
     c = d.get("cpu_baseline")
     if c:
         print("  cpu %s: %.1f ms/step on %d threads" % (c["kind"], c["ms_per_step"], c["cores"]))

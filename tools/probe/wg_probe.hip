@@ -1,7 +1,7 @@
 // Stand-alone timing probe of the fused weight-gradient kernel (csrc/wgrad.h) -- no torch, HIP events around back-to-back
 // launches (GPU-bound: no memset node, counters are left dirty, results are not checked here; parity is the test-suite's job).
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -DSG_WG_DEBUG -I stemgnn_amd/csrc tools/probe/wg_probe.hip -o gpurun_out/wg_probe
-//   ./wg_probe [M=7296] [iters=20]        env: STEMGNN_WG_CFG, STEMGNN_WG_DEBUG
+//   ./wg_probe [M=7296] [iters=20]        env: STEMGNN_WG_DEBUG
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
