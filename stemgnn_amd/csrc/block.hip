@@ -17,6 +17,7 @@
 #include "reduce.h"
 #include "wgrad.h"
 #include "heads.h"
+#include "glu_fused.h"
 
 #define SG_TRY(e)                                \
   do {                                           \
@@ -502,6 +503,39 @@ extern "C" int stemgnn_spectral_glu_fwd(const float* packed, float* saved, int B
   const SgPackedLayout P = sg_packed_layout(d);
   const SgSavedLayout S = sg_saved_layout(d);
   hipStream_t st = (hipStream_t)stream;
+  // One launch for the three layers (csrc/glu_fused.h: activations of a 64-row block resident in LDS, weights on a
+  // direct-to-LDS ring) where the padded channel count is <= 256; STEMGNN_GLU_FUSED=0 keeps the three per-layer launches
+  // (read per call, so a test can compare the two on the same buffers).
+  const GfGeom gg = gf_geom(d);
+  const char* ef = getenv("STEMGNN_GLU_FUSED");
+  if (gg.ok && !(ef && atoi(ef) == 0) && (((uintptr_t)packed) & 15) == 0) {
+    GfArgs a;
+    a.G = saved + S.G; a.KG = d.KG; a.KP0 = gg.kp[0]; a.KA = gg.KA; a.M = d.M; a.ns = gg.ns;
+    a.nrb = (d.M + GF_BM - 1) / GF_BM;
+    for (int l = 0; l < 3; ++l) {
+      a.nst[l] = gg.nst[l];
+      for (int r = 0; r < 2; ++r) {
+        a.bias[r][l] = packed + P.b[r][l];
+        a.out[r][l] = saved + S.out[r][l];
+        a.gate[r][l] = saved + S.gate[r][l];
+        a.cp[r][l] = sg_glu_cp(d, l, r);
+      }
+    }
+    for (int r = 0; r < 2; ++r) a.wf[r] = packed + P.wfused[r];
+    const dim3 grid(8 * ((a.nrb + 3) / 4));
+    static SgDynLds guard[3];
+#define GF_LAUNCH(H01, H2, GI)                                                                              \
+    do {                                                                                                    \
+      SG_TRY(sg_ensure_dyn_lds((const void*)sg_glu_fused_fwd_kernel<H01, H2>, gg.lds_bytes, guard[GI]));     \
+      hipLaunchKernelGGL((sg_glu_fused_fwd_kernel<H01, H2>), grid, dim3(256), gg.lds_bytes, st, a);          \
+    } while (0)
+    if (gg.hp[0] == 1) GF_LAUNCH(1, 1, 0);
+    else if (gg.hp[2] == 1) GF_LAUNCH(2, 1, 1);
+    else GF_LAUNCH(2, 2, 2);
+#undef GF_LAUNCH
+    SG_TRY(hipGetLastError());
+    return 0;
+  }
   for (int l = 0; l < 3; ++l) {
     G2Args g;
     GluFwdEpi e;

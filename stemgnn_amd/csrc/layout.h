@@ -60,10 +60,57 @@ SG_HD int sg_l2_orig_channel(const SgDims& d, int r, int c) {
   return kq * d.Wm + f;
 }
 
+// ---- fused three-layer GLU forward (csrc/glu_fused.h): geometry shared by layout, pack kernel, launcher ------------------
+constexpr int GF_BM = 64;            // series rows per workgroup
+constexpr int GF_LDA = 66;           // row stride of the K-major activation buffer (floats): conflict-free b64 writes
+constexpr int GF_STAGE = 4096;       // floats per ring stage (16 KB): 16 / HP weight rows x 256 HP columns
+constexpr int GF_STAGES = 5;
+// geometry of the fused kernel for a (W, multi) pair -- shared by the pack kernel, the launcher and the tests
+struct GfGeom {
+  int hp[3];        // channel groups of 32 per wave, per layer (layers 0 / 1: ceil(CP / 128); layer 2: ceil(max CP2 / 128))
+  int rs[3];        // weight rows per ring stage: 16 / hp
+  int kp[3];        // K padded to a multiple of rs
+  int nst[3];       // stages per layer
+  int ns;           // stages per branch
+  int KA;           // rows of the activation buffer
+  size_t lds_bytes;
+  bool ok;
+};
+SG_HD GfGeom gf_geom(const SgDims& d) {
+  GfGeom g;
+  const int cp2 = d.CP2[0] > d.CP2[1] ? d.CP2[0] : d.CP2[1];
+  g.hp[0] = g.hp[1] = (d.CP + 127) / 128;
+  g.hp[2] = (cp2 + 127) / 128;
+  g.ok = d.CP <= 256 && g.hp[2] <= g.hp[0];
+  g.ns = 0;
+  g.KA = 0;
+  for (int l = 0; l < 3; ++l) {
+    const int hp = g.hp[l] < 1 ? 1 : (g.hp[l] > 2 ? 2 : g.hp[l]);
+    g.rs[l] = 16 / hp;
+    const int K = l == 0 ? d.KG : d.CP;
+    g.kp[l] = (K + g.rs[l] - 1) / g.rs[l] * g.rs[l];
+    g.nst[l] = g.kp[l] / g.rs[l];
+    g.ns += g.nst[l];
+    if (g.kp[l] > g.KA) g.KA = g.kp[l];
+  }
+  g.KA = (g.KA + 1) & ~1;
+  g.lds_bytes = ((size_t)g.KA * GF_LDA + (size_t)GF_STAGES * GF_STAGE) * sizeof(float);
+  g.ok = g.ok && g.lds_bytes <= (size_t)160 * 1024;
+  return g;
+}
+// floats of the fused-order weight stream of one block (both branches)
+SG_HD size_t gf_stream_floats(const SgDims& d) {
+  const GfGeom g = gf_geom(d);
+  return g.ok ? (size_t)2 * g.ns * GF_STAGE : 0;
+}
+
+
 // ---- packed-weights buffer of one StockBlock (floats) -----------------------------------------
-// [r=0..1][l=0..2]: Wp (K_in x NP) then bias (NP)   ;  then Wfold (KF x WmP)
+// [r=0..1][l=0..2]: Wp (K_in x NP) then bias (NP)   ;  then Wfold (KF x WmP)  ;  then the fused-order GLU weight streams
 struct SgPackedLayout {
-  size_t w[2][3], b[2][3], wfold, total;
+  size_t w[2][3], b[2][3], wfold, total;   // total: end of the panels sg_pack_kernel writes
+  size_t wfused[2];                         // fused-order weight stream per branch (csrc/glu_fused.h), 16-byte aligned; 0 floats
+  size_t total_ext;                         // when the fused kernel does not apply.  total_ext: size of the whole buffer
 };
 SG_HD SgPackedLayout sg_packed_layout(const SgDims& d) {
   SgPackedLayout L;
@@ -75,6 +122,10 @@ SG_HD SgPackedLayout sg_packed_layout(const SgDims& d) {
     }
   L.wfold = off; off += (size_t)d.KF * d.WmP;
   L.total = off;
+  off = (off + 3) & ~(size_t)3;
+  const size_t per_branch = gf_stream_floats(d) / 2;
+  for (int r = 0; r < 2; ++r) { L.wfused[r] = off; off += per_branch; }
+  L.total_ext = off;
   return L;
 }
 

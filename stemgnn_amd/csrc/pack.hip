@@ -12,6 +12,7 @@
 
 #include "../../include/stemgnn_hip.h"
 #include "devattr.h"
+#include "glu_fused.h"
 #include "layout.h"
 
 #define SG_TRY(e)                                \
@@ -74,7 +75,7 @@ extern "C" int stemgnn_make_tables_host(int W, int multi, float* t) {
 extern "C" const char* stemgnn_version(void) { return "stemgnn_hip 0.1 gfx950"; }
 extern "C" int stemgnn_num_cus(void) { return sg_num_cus(); }
 extern "C" size_t stemgnn_table_floats(int W, int multi) { return sg_table_layout(sg_dims(1, 1, W, multi)).total; }
-extern "C" size_t stemgnn_packed_floats(int W, int multi) { return sg_packed_layout(sg_dims(1, 1, W, multi)).total; }
+extern "C" size_t stemgnn_packed_floats(int W, int multi) { return sg_packed_layout(sg_dims(1, 1, W, multi)).total_ext; }
 extern "C" size_t stemgnn_saved_floats(int B, int N, int W, int multi) { return sg_saved_layout(sg_dims(B, N, W, multi)).total; }
 extern "C" size_t stemgnn_scratch_floats(int B, int N, int W, int multi) { return sg_scratch_layout(sg_dims(B, N, W, multi)).total; }
 extern "C" size_t stemgnn_scratch_offset_dG(int B, int N, int W, int multi) { return sg_scratch_layout(sg_dims(B, N, W, multi)).dG; }
@@ -163,6 +164,25 @@ extern "C" int stemgnn_block_pack(const float* const* params_host, const float* 
   const unsigned blocks = (unsigned)((P.total + 255) / 256);
   hipLaunchKernelGGL(sg_pack_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, prm, tables, packed, d, P, T);
   SG_TRY(hipGetLastError());
+  // the same GLU weights once more as the stage stream of the fused three-layer forward (csrc/glu_fused.h), from the panels
+  // just written (stream order); 1.6 MB per block at W * multi = 60
+  const GfGeom gg = gf_geom(d);
+  if (gg.ok) {
+    GfPackArgs a;
+    a.g = gg;
+    for (int l = 0; l < 3; ++l) {
+      a.K[l] = sg_glu_kin(d, l);
+      for (int r = 0; r < 2; ++r) {
+        a.wp[r][l] = packed + P.w[r][l];
+        a.np[r][l] = sg_glu_np(d, l, r);
+        a.cp[r][l] = sg_glu_cp(d, l, r);
+      }
+    }
+    for (int r = 0; r < 2; ++r) a.wf[r] = packed + P.wfused[r];
+    const unsigned fb = (unsigned)(((size_t)gg.ns * GF_STAGE + 255) / 256);
+    hipLaunchKernelGGL(sg_pack_fused_kernel, dim3(fb, 2), dim3(256), 0, (hipStream_t)stream, a);
+    SG_TRY(hipGetLastError());
+  }
   return 0;
 }
 

@@ -58,6 +58,12 @@ class TrainStep:
         self.model, self.opt = model, optimizer
         self.collective = (world > 1) if collective is None else bool(collective)
         self.one_graph = (os.environ.get("STEMGNN_DDP_ONE_GRAPH", "1") == "1") if one_graph is None else bool(one_graph)
+        if self.collective and self.one_graph:
+            # only RCCL collectives can be captured into a hipGraph; a gloo group (CPU transport, tests) copies through the
+            # host, and a failed capture of that leaves a sticky HIP error behind -- never attempted
+            import torch.distributed as dist
+            ok = dist.is_available() and dist.is_initialized() and dist.get_backend(group) == "nccl"
+            self.one_graph = bool(ok)
         self.B, self.W, self.H, self.N = int(batch_size), int(window_size), int(horizon), int(units)
         self.world = world
         dev = next(model.parameters()).device
