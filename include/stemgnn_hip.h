@@ -162,6 +162,10 @@ int stemgnn_gru_bwd(const float* dh_all, const float* x, const float* w_hh, cons
  * (host array). */
 int stemgnn_block_pack(const float* const* params_host, const float* tables, float* packed,
                        int W, int multi, void* stream);
+/* The GLU weights of `packed` once more as the stage stream of the fused three-layer forward (csrc/glu_fused.h), written
+ * behind the panels inside the same buffer; stemgnn_block_pack calls it (exported for callers that fill the panels
+ * themselves).  No-op for (W, multi) the fused kernel does not cover (padded channel count 4 W multi > 256). */
+int stemgnn_glu_fused_repack(float* packed, int W, int multi, void* stream);
 /* adjoint of the above: scatter the weight gradients (slab 0 of every gradpart region, left complete by
  * stemgnn_block_wgrad or by the parts & 2 calls of stemgnn_igft_heads_bwd / stemgnn_spectral_glu_bwd) into the parameter
  * gradients grads_host[SG_BLOCK_NPARAMS] (entries may be NULL to skip).  nsplit = the value gradpart was sized with. */

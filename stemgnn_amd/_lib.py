@@ -45,6 +45,7 @@ SIGNATURES = {
     "stemgnn_glu_combine_fwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, _P]),
     "stemgnn_glu_combine_bwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, _P]),
     "stemgnn_colsum": (c_int, [_P, c_int, c_int, _P, _P]),
+    "stemgnn_glu_fused_repack": (c_int, [_P, c_int, c_int, _P]),
     "stemgnn_shortcut_dx": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "stemgnn_gru_reserve_floats": (c_size_t, [c_int, c_int, c_int]),
     "stemgnn_gru_fwd_scratch_floats": (c_size_t, [c_int, c_int, c_int]),

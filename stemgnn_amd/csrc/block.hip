@@ -721,6 +721,37 @@ extern "C" int stemgnn_spectral_glu_bwd(const float* packed, const float* saved,
       }
     fused = fused && wg_tiles_fit(wq, 6);
   }
+  // data-gradient chain: ONE launch for layer 2 -> 1 -> 0's d(pre-activation) (csrc/glu_fused.h, operand resident in LDS,
+  // weights on the direct-to-LDS ring) where the padded channel count is <= 256; STEMGNN_GLU_FUSED=0 keeps the two
+  // per-layer launches and the GluDgrad0Op product.
+  const GdGeom gdg = gd_geom(d);
+  const char* efd = getenv("STEMGNN_GLU_FUSED");
+  const bool fused_dgrad = (parts & 1) && gdg.ok && !(efd && atoi(efd) == 0) && (((uintptr_t)packed) & 15) == 0 &&
+                           (((uintptr_t)scratch) & 15) == 0;
+  if (fused_dgrad) {
+    GdArgs a;
+    a.CP = d.CP; a.KG = d.KG; a.M = d.M; a.KA = gdg.KA; a.nrb = (d.M + GF_BM - 1) / GF_BM;
+    for (int p = 0; p < 2; ++p) { a.nstB[p] = gdg.nstB[p]; a.nstC[p] = gdg.nstC[p]; }
+    for (int r = 0; r < 2; ++r) {
+      a.dact2[r] = scratch + C.dact[r][2]; a.np2[r] = sg_glu_np(d, 2, r);
+      a.wd[r] = packed + P.wdgrad[r];
+      a.out1[r] = saved + S.out[r][1]; a.gate1[r] = saved + S.gate[r][1];
+      a.out0[r] = saved + S.out[r][0]; a.gate0[r] = saved + S.gate[r][0];
+      a.dact1[r] = scratch + C.dact[r][1]; a.dact0[r] = scratch + C.dact[r][0];
+      a.dG[r] = scratch + C.dG + (size_t)r * d.M * d.KG;
+      a.nstA[r] = gdg.nstA[r]; a.ns[r] = gdg.ns[r];
+    }
+    const dim3 grid(8 * ((a.nrb + 3) / 4));
+    static SgDynLds guard[2];
+    if (gdg.nt == 2) {
+      SG_TRY(sg_ensure_dyn_lds((const void*)sg_glu_fused_dgrad_kernel<2>, gdg.lds_bytes, guard[1]));
+      hipLaunchKernelGGL((sg_glu_fused_dgrad_kernel<2>), grid, dim3(256), gdg.lds_bytes, st, a);
+    } else {
+      SG_TRY(sg_ensure_dyn_lds((const void*)sg_glu_fused_dgrad_kernel<1>, gdg.lds_bytes, guard[0]));
+      hipLaunchKernelGGL((sg_glu_fused_dgrad_kernel<1>), grid, dim3(256), gdg.lds_bytes, st, a);
+    }
+    SG_TRY(hipGetLastError());
+  }
   for (int l = 2; l >= 0; --l) {
     // d(pre-activation) of layer l lives in dact[r][l] as [M x NP(l,r)] (pair order); it was written by
     // igft_heads_bwd (l = 2) or by the data-gradient epilogue of layer l+1
@@ -740,6 +771,7 @@ extern "C" int stemgnn_spectral_glu_bwd(const float* packed, const float* saved,
       SG_TRY((g2_launch<GluWgradEpi, false, false>(g, e, 2, st)));
     }
     if (!(parts & 1)) continue;
+    if (fused_dgrad) continue;                   // the whole chain (incl. the layer-0 product -> dG) ran in the fused launch
     if (l > 0) {  // data gradient -> d(pre-activation) of layer l-1
       G2Args g;
       GluDpreEpi e;

@@ -359,34 +359,33 @@ __global__ __launch_bounds__(256) void sg_attention_bwd_kernel(
     out[j] = (smem[j] + smem[N + j]) + (smem[2 * N + j] + smem[3 * N + j]);
 }
 
+// dquery[b,j] = sum over the row chunks of the attention backward's partials, in chunk order (fixed association).  Its own
+// small launch: folding the sum into sg_keyquery_bwd_kernel (every one of its N workgroups re-reading all nchunk partial
+// rows) was measured in round 4 at 50.7 us for that kernel against 18.6 + 10.1 for the two launches (r04 step timeline);
+// folding it into the attention kernel as a last-arriver reduction was measured slower in round 3.
+__global__ void sg_dquery_reduce_kernel(const float* __restrict__ dqpart, float* __restrict__ dquery, int B, int N,
+                                        int nchunk) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (size_t)B * N) return;
+  const int b = (int)(idx / N), j = (int)(idx - (size_t)b * N);
+  float s = 0.f;
+  for (int c = 0; c < nchunk; ++c) s += dqpart[((size_t)b * nchunk + c) * N + j];
+  dquery[idx] = s;
+}
+
 // dh[s,b,i] = dkey[b,i] wk[s] + dquery[b,i] wq[s];  dwk[s] = sum_{b,i} dkey h ; dwq likewise.  One WG per s.
-// dquery[b,i] = sum_c dqpart[b][c][i] in chunk order c = 0..nchunk-1 (fixed association: every workgroup forms the same
-// bits); the nchunk partial rows are L2-resident (0.47 MB at PEMS07) and all loads of an element are issued before the sum.
 __global__ __launch_bounds__(256) void sg_keyquery_bwd_kernel(const float* __restrict__ h, const float* __restrict__ wk,
                                                               const float* __restrict__ wq, const float* __restrict__ dkey,
-                                                              const float* __restrict__ dqpart, int nchunk,
-                                                              float* __restrict__ dh, float* __restrict__ dwk,
-                                                              float* __restrict__ dwq, int B, int N) {
+                                                              const float* __restrict__ dquery, float* __restrict__ dh,
+                                                              float* __restrict__ dwk, float* __restrict__ dwq, int B, int N) {
   __shared__ float red[4][2];
   const int s = blockIdx.x;
   const size_t BN = (size_t)B * N;
   const float wks = wk[s], wqs = wq[s];
   float ak = 0.f, aq = 0.f;
   for (size_t e = threadIdx.x; e < BN; e += 256) {
-    const int b = (int)(e / N), i = (int)(e - (size_t)b * N);
-    const float* pp = dqpart + (size_t)b * nchunk * N + i;
-    const float dk = dkey[e];
+    const float dk = dkey[e], dqv = dquery[e];
     const float hv = h[(size_t)s * BN + e];
-    float dqv = 0.f;
-    int c = 0;
-    for (; c + 8 <= nchunk; c += 8) {
-      float v[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = pp[(size_t)(c + u) * N];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) dqv += v[u];
-    }
-    for (; c < nchunk; ++c) dqv += pp[(size_t)c * N];
     dh[(size_t)s * BN + e] = dk * wks + dqv * wqs;
     ak = fmaf(dk, hv, ak);
     aq = fmaf(dqv, hv, aq);
@@ -535,7 +534,8 @@ extern "C" int stemgnn_attn_laplacian_bwd(const float* dL, const float* h, const
   const float* deg = A + (size_t)N * N;
   float* dAB = scratch;
   float* dkey = dAB + (size_t)N * N;
-  float* dqpart = dkey + 2 * (size_t)B * N;      // (one [B,N] slot of the caller's layout is no longer used)
+  float* dquery = dkey + (size_t)B * N;
+  float* dqpart = dquery + (size_t)B * N;
   if (parts & 1) {      // Laplacian backward -> dA / B in scratch[0 .. N*N)  (a data-parallel caller may average it)
     hipLaunchKernelGGL(sg_laplacian_bwd_kernel, dim3((N + 3) / 4), dim3(256), 0, st, dL, A, deg, dAB, B, N,
                        (training && drop_p > 0.f) ? 1 : 0);
@@ -544,14 +544,16 @@ extern "C" int stemgnn_attn_laplacian_bwd(const float* dL, const float* h, const
   if (!(parts & 2)) return 0;
   const size_t lds = (size_t)(4 * N) * sizeof(float);
   if (lds > 150 * 1024) return SG_EINVAL;
-  // d(query): the attention kernel leaves one partial per row chunk; the key / query backward sums the nchunk partials of
-  // every element itself, in chunk order (round 4: the separate reduce launch sat on the backward's critical chain;
-  // folding it into the attention kernel as a last-arriver reduction was measured slower in round 3 -- the agent-scope
-  // fences of that hand-off flush the L2 under the concurrent weight-gradient kernel)
   hipLaunchKernelGGL(sg_attention_bwd_kernel, dim3(B, nchunk), dim3(256), lds, st, dAB, key, query, rowsum, alpha,
                      drop_p, training, seed, B, N, nchunk, dkey, dqpart);
   SG_TRY(hipGetLastError());
-  hipLaunchKernelGGL(sg_keyquery_bwd_kernel, dim3(N), dim3(256), 0, st, h, wk, wq, dkey, dqpart, nchunk, dh, dwk, dwq, B, N);
+  {
+    const size_t bn = (size_t)B * N;
+    hipLaunchKernelGGL(sg_dquery_reduce_kernel, dim3((unsigned)((bn + 255) / 256)), dim3(256), 0, st, dqpart, dquery, B,
+                       N, nchunk);
+    SG_TRY(hipGetLastError());
+  }
+  hipLaunchKernelGGL(sg_keyquery_bwd_kernel, dim3(N), dim3(256), 0, st, h, wk, wq, dkey, dquery, dh, dwk, dwq, B, N);
   SG_TRY(hipGetLastError());
   return 0;
 }

@@ -164,29 +164,50 @@ __device__ __forceinline__ void gf_layer(float* As, GfRing& rg, int& rbuf, int n
   }
   // ---- epilogue: bias, GLU gating, saved tensors, next layer's input ----------------------------------------------------
   if constexpr (!LAST) __builtin_amdgcn_s_barrier();     // every wave is done reading the activation buffer
+  const bool full = m0 + GF_BM <= M;                     // wave-uniform: only the last row block of a launch is ragged
 #pragma unroll
   for (int h = 0; h < HP; ++h) {
     const int c = wave * 32 * HP + h * 32 + fi;
     const bool live = c < cp;
-    float* po = outp + c;
-    float* pg = gatep + c;
+    float o[16][2], gs[16][2];
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) {
       const int rl = 2 * g2_row_of(reg, lane);
-      float o[2];
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const float u = acc[i][h][0][reg] + bl[h], v = acc[i][h][1][reg] + br[h];
-        const float gt = (GF_ABL & 8) ? v : gf_sigmoid(v);
-        o[i] = u * gt;
-        const int row = m0 + rl + i;
-        if (!(GF_ABL & 1) && live && row < M) {
-          po[(size_t)row * cp] = o[i];
-          pg[(size_t)row * cp] = gt;
-        }
+        gs[reg][i] = (GF_ABL & 8) ? v : gf_sigmoid(v);
+        o[reg][i] = u * gs[reg][i];
       }
       if constexpr (!LAST) {
-        if (c < KA) *reinterpret_cast<float2*>(As + c * GF_LDA + rl) = make_float2(o[0], o[1]);
+        if (c < KA) *reinterpret_cast<float2*>(As + c * GF_LDA + rl) = make_float2(o[reg][0], o[reg][1]);
+      }
+    }
+    // saved tensors: ONE lane predicate around the whole store loop (a per-store `row < M` test costs an exec-mask branch
+    // per store pair); the ragged last block takes the predicated form
+    float* po = outp + (size_t)m0 * cp + c;
+    float* pg = gatep + (size_t)m0 * cp + c;
+    if (!(GF_ABL & 1) && live) {
+      if (full) {
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg)
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            const size_t off = (size_t)(2 * g2_row_of(reg, lane) + i) * cp;
+            po[off] = o[reg][i];
+            pg[off] = gs[reg][i];
+          }
+      } else {
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg)
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            const int rl = 2 * g2_row_of(reg, lane) + i;
+            if (m0 + rl < M) {
+              po[(size_t)rl * cp] = o[reg][i];
+              pg[(size_t)rl * cp] = gs[reg][i];
+            }
+          }
       }
     }
   }
@@ -258,4 +279,374 @@ static __global__ __launch_bounds__(256, 1) void sg_glu_fused_fwd_kernel(const G
   gf_layer<HP01, false>(As, rg, rbuf, g.nst[1], lane, wave, bl[1], br[1], g.out[r][1], g.gate[r][1], g.cp[r][1], M, m0, g.KA);
   gf_layer<HP2, true>(As, rg, rbuf, g.nst[2], lane, wave, bl[2], br[2], g.out[r][2], g.gate[r][2], g.cp[r][2], M, m0, g.KA);
   gf_wait_vm<0>();                                         // the run-ahead DMA pieces must not outlive the workgroup's LDS
+}
+
+// =======================================================================================================================
+// Fused data-gradient chain of the GLU stack (autograd of models/base_model.py:52-54 with :12-13 through
+// models/handler.py:164), round 4: d(pre-activation) of layer 2 (from the heads' backward) -> layer 1 -> layer 0 in ONE
+// launch per block instead of three.  Mirror of the forward kernel:
+//   * a workgroup owns 64 series rows of one branch; the operand of the running product is resident in LDS, K-major: the
+//     d(pre-activation) rows of layer 2 are copied in from HBM, those of layer 1 are written there by the epilogue that
+//     forms them (and stored to HBM once, for the weight-gradient kernel) -- they are never read back;
+//   * a wave owns 32 NT channels of the layer whose d(out) is being formed, for all 64 rows: 2 x NT accumulator tiles; the
+//     second product accumulates into a second set while the first set is still being turned into its operand;
+//   * that operand (2 CP = 480 rows at PEMS07) does not fit the LDS beside the ring, so the reduction runs in NT phases of
+//     256 rows: phase p = the left / right values of every wave's p-th channel group.  The reduction order of a product is
+//     free -- the weight stream (sg_pack_dgrad_kernel) is laid out in exactly the order the phases produce the rows;
+//   * GLU backward in the epilogue: d = d(out)[row][c]; left = d * gate; right = d * out * (1 - gate), with
+//     the saved out / gate of the layer below loaded per lane (all loads of a tile in flight before the first use).
+//   * the layer-0 product (K = 2 CP -> the 3 W columns of dG) runs the same way behind it: its operand, the
+//     d(pre-activation) of layer 0, is stored once for the weight gradients and consumed from LDS; the four waves split the
+//     2 x 2 output tiles of the [64 x 64] result (one MFMA per k-step -- 7 us of a 60 us workgroup instead of a launch).
+// fp32 MFMA throughout; the first product sums its reduction in the per-layer kernels' order, the others in phase order
+// (fp32 re-association: parity bar, not bitwise).
+struct GdPackArgs {
+  const float* wp[2][3];        // pair panels [K_in][NP] of layers 1, 2 (index 0 unused)
+  float* wd[2];
+  int np[2][3];
+  int CP, KG;
+  GdGeom g;
+};
+static __global__ __launch_bounds__(256) void sg_pack_dgrad_kernel(const GdPackArgs a) {
+  const int r = blockIdx.y;
+  const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (size_t)a.g.ns[r] * GF_STAGE) return;
+  int s = (int)(e / GF_STAGE);
+  const int nt = a.g.nt, rs = a.g.rs, nc = 128 * nt;
+  const int wi = (int)(e % GF_STAGE);
+  const int sAB = a.g.nstA[r] + a.g.nstB[0] + a.g.nstB[1];
+  if (s >= sAB) {                                    // third product: layer 0, 64 rows x 64 columns per stage
+    s -= sAB;
+    int ph = 0;
+    if (s >= a.g.nstC[0]) { s -= a.g.nstC[0]; ph = 1; }
+    const int kk = wi >> 6, kin = wi & 63;           // column = input index of layer 0 (3 W of them)
+    const int k2 = s * 64 + kk;
+    const int t = k2 & 1, wf = k2 >> 1, w2 = wf >> 5, f2 = wf & 31;
+    const int c2 = w2 * 32 * nt + 32 * ph + f2;      // layer-0 channel whose left / right value the row holds
+    float v = 0.f;
+    if (w2 < 4 && c2 < a.CP && kin < a.KG) v = a.wp[r][0][(size_t)kin * a.np[r][0] + ((c2 >> 4) << 5) + (c2 & 15) + 16 * t];
+    a.wd[r][e] = v;
+    return;
+  }
+  const int kk = wi / nc, p = wi % nc;
+  int wave, fi, j;
+  if (nt == 2) { wave = p >> 6; fi = (p & 63) >> 1; j = p & 1; }
+  else { wave = p >> 5; fi = p & 31; j = 0; }
+  const int c = wave * 32 * nt + 32 * j + fi;        // output column of the product = input channel of the layer
+  float v = 0.f;
+  if (s < a.g.nstA[r]) {                             // first product: layer 2, reduction row = natural pair column
+    const int q = s * rs + kk;
+    if (q < a.np[r][2] && c < a.CP) v = a.wp[r][2][(size_t)c * a.np[r][2] + q];
+  } else {                                           // second product: layer 1, reduction rows in phase order
+    s -= a.g.nstA[r];
+    int ph = 0;
+    if (s >= a.g.nstB[0]) { s -= a.g.nstB[0]; ph = 1; }
+    const int k2 = s * rs + kk;                      // row of the phase: 2 (wave' 32 + lane') + t
+    const int t = k2 & 1, wf = k2 >> 1, w2 = wf >> 5, f2 = wf & 31;
+    const int c2 = w2 * 32 * nt + 32 * ph + f2;      // layer-1 channel whose left (t = 0) / right (t = 1) value the row holds
+    if (w2 < 4 && c2 < a.CP && c < a.CP) v = a.wp[r][1][(size_t)c * a.np[r][1] + ((c2 >> 4) << 5) + (c2 & 15) + 16 * t];
+  }
+  a.wd[r][e] = v;
+}
+
+struct GdArgs {
+  const float* dact2[2];        // [M][np2[r]]   d(pre-activation) of layer 2, pair order
+  const float* wd[2];           // weight stream (sg_pack_dgrad_kernel)
+  const float* out1[2];         // saved out / gate of layers 1 and 0, [M][CP]
+  const float* gate1[2];
+  const float* out0[2];
+  const float* gate0[2];
+  float* dact1[2];              // [M][2 CP]  d(pre-activation) of layers 1 and 0, pair order
+  float* dact0[2];
+  float* dG[2];                 // [M][KG]    layer-0 data gradient, one slab per branch (summed by the GFT backward)
+  int np2[2], nstA[2], ns[2];
+  int nstB[2], nstC[2];
+  int CP, KG, M, nrb, KA;
+};
+
+template <int NT>
+__device__ __forceinline__ void gd_stage(const float* __restrict__ Aq, const float* __restrict__ Bs, sg_f32x16 (&acc)[2][NT],
+                                         GfRing& rg) {
+  constexpr int NC = 128 * NT, RS = 32 / NT, STEPS = RS / 2;
+  constexpr int EVERY = STEPS / GF_NI;                 // one DMA piece every EVERY k-steps (2 or 4)
+  float2 fa[STEPS];
+  float fb[STEPS][2];
+  auto rd = [&](int st) {
+    fa[st] = *reinterpret_cast<const float2*>(Aq + 2 * st * GF_LDA);
+    if constexpr (NT == 2) {
+      const float2 b = *reinterpret_cast<const float2*>(Bs + 2 * st * NC);
+      fb[st][0] = b.x; fb[st][1] = b.y;
+    } else {
+      fb[st][0] = Bs[2 * st * NC]; fb[st][1] = 0.f;
+    }
+  };
+#pragma unroll
+  for (int st = 0; st < GF_PF && st < STEPS; ++st) rd(st);
+#pragma unroll
+  for (int st = 0; st < STEPS; ++st) {
+    const float a0 = fa[st].x, a1 = fa[st].y;
+    __builtin_amdgcn_sched_barrier(0);
+    if (!(GF_ABL & 2)) acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, fb[st][0], acc[0][0], 0, 0, 0);
+    if (st + GF_PF < STEPS) rd(st + GF_PF);
+    __builtin_amdgcn_sched_barrier(0);
+    if (!(GF_ABL & 2)) acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, fb[st][0], acc[1][0], 0, 0, 0);
+    if (!(GF_ABL & 4) && st % EVERY == 0 && st / EVERY < GF_NI) rg.issue(st / EVERY);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (NT == 2) {
+      if (!(GF_ABL & 2)) {
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, fb[st][1], acc[0][1], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, fb[st][1], acc[1][1], 0, 0, 0);
+      }
+    }
+  }
+}
+
+// third product (-> dG, 3 W <= 64 columns): the four waves split the 2 x 2 output tiles, one MFMA per k-step; a ring stage
+// holds 64 weight rows x 64 columns = 32 k-steps
+__device__ __forceinline__ void gd_stage_c(const float* __restrict__ Aq, const float* __restrict__ Bs, sg_f32x16& acc,
+                                           GfRing& rg) {
+  constexpr int STEPS = 32, EVERY = STEPS / GF_NI, PF = 4;
+  float fa[STEPS], fb[STEPS];
+#pragma unroll
+  for (int st = 0; st < PF; ++st) { fa[st] = Aq[2 * st * GF_LDA]; fb[st] = Bs[2 * st * 64]; }
+#pragma unroll
+  for (int st = 0; st < STEPS; ++st) {
+    __builtin_amdgcn_sched_barrier(0);
+    if (!(GF_ABL & 2)) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[st], fb[st], acc, 0, 0, 0);
+    if (st + PF < STEPS) { fa[st + PF] = Aq[2 * (st + PF) * GF_LDA]; fb[st + PF] = Bs[2 * (st + PF) * 64]; }
+    if (!(GF_ABL & 4) && st % EVERY == 0 && st / EVERY < GF_NI) rg.issue(st / EVERY);
+  }
+}
+__device__ __forceinline__ void gd_kloop_c(const float* As, GfRing& rg, int& rbuf, int nst, int lane, int wave, sg_f32x16& acc) {
+  const int fi = lane & 31, fk = lane >> 5, mi = wave >> 1, nj = wave & 1;
+  const float* Ap = As + fk * GF_LDA + 2 * fi + mi;          // row tile mi = block rows 2 r + mi (interleaved, as everywhere)
+  const int boff = fk * 64 + nj * 32 + fi;
+  for (int s = 0; s < nst; ++s) {
+    gf_wait_vm<(GF_STAGES - 2) * GF_NI>();
+    __builtin_amdgcn_s_barrier();
+    gd_stage_c(Ap + (size_t)s * 64 * GF_LDA, rg.ring + rbuf * GF_STAGE + boff, acc, rg);
+    rg.advance();
+    rbuf = rbuf + 1 == GF_STAGES ? 0 : rbuf + 1;
+  }
+}
+
+// Saved out / gate values one epilogue tile needs: 32 rows x 1 channel per lane and tensor.  They are requested in GD_NB
+// batches from inside the LAST GD_NB stages of the K loop that precedes the epilogue (gd_kloop), so their HBM latency hides
+// under MFMA work instead of standing in front of every epilogue (measured: ~3 us per tile, 4 tiles per workgroup).  A batch
+// must have landed by the next stage's counted wait (vmcnt retires in order), which a stage's 2048 MFMA cycles cover.
+constexpr int GD_NB = 8;              // batches (= stages) a tile's 64 loads are spread over
+struct GdSaved {
+  float y[16][2], g[16][2];
+};
+template <int NT, int J>
+__device__ __forceinline__ void gd_load_batch(GdSaved& sv, int b, const float* __restrict__ y, const float* __restrict__ gt,
+                                              int CP, int M, int m0, int lane, int wave) {
+  const int fi = lane & 31;
+  const int c = wave * 32 * NT + 32 * J + fi;
+  const bool live = c < CP;
+#pragma unroll
+  for (int reg = 0; reg < 16; ++reg) {
+    if (reg / (16 / GD_NB) != b) continue;           // (b is a compile-time constant at every call site)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int row = m0 + 2 * g2_row_of(reg, lane) + i;
+      const size_t o = (size_t)(row < M ? row : 0) * CP + (live ? c : 0);
+      sv.y[reg][i] = y[o];
+      sv.g[reg][i] = gt[o];
+    }
+  }
+}
+
+// K loop of one product (phase).  PJ >= 0: the saved out / gate values of column tile PJ (tensors y / gt) are requested from
+// inside the last GD_NB stages, one batch right behind each stage's barrier (P2 >= 0: a second tile into sv2 likewise).
+template <int NT, int PJ, int P2>
+__device__ __forceinline__ void gd_kloop(const float* As, GfRing& rg, int& rbuf, int nst, int lane, int wave,
+                                         sg_f32x16 (&acc)[2][NT], GdSaved& sv, GdSaved& sv2, const float* __restrict__ y,
+                                         const float* __restrict__ gt, int CP, int M, int m0) {
+  constexpr int NC = 128 * NT, RS = 32 / NT;
+  const int fi = lane & 31, fk = lane >> 5;
+  const float* Ap = As + fk * GF_LDA + 2 * fi;
+  const int boff = fk * NC + (NT == 2 ? wave * 64 + 2 * fi : wave * 32 + fi);
+  const int nhead = (PJ >= 0 && nst > GD_NB) ? nst - GD_NB : (PJ >= 0 ? 0 : nst);
+  int s = 0;
+  for (; s < nhead; ++s) {
+    gf_wait_vm<(GF_STAGES - 2) * GF_NI>();
+    __builtin_amdgcn_s_barrier();
+    gd_stage<NT>(Ap + (size_t)s * RS * GF_LDA, rg.ring + rbuf * GF_STAGE + boff, acc, rg);
+    rg.advance();
+    rbuf = rbuf + 1 == GF_STAGES ? 0 : rbuf + 1;
+  }
+  if constexpr (PJ >= 0) {
+    // tail: stage s of the last min(nst, GD_NB) carries batch (GD_NB - (nst - s)); batches a short loop has no stage
+    // for go out ahead of it
+    const int first = nst < GD_NB ? GD_NB - nst : 0;
+#pragma unroll
+    for (int b = 0; b < GD_NB; ++b) {
+      if (b >= first) {
+        gf_wait_vm<(GF_STAGES - 2) * GF_NI>();
+        __builtin_amdgcn_s_barrier();
+      }
+      gd_load_batch<NT, PJ>(sv, b, y, gt, CP, M, m0, lane, wave);
+      if constexpr (P2 >= 0) gd_load_batch<NT, P2>(sv2, b, y, gt, CP, M, m0, lane, wave);
+      if (b >= first) {
+        gd_stage<NT>(Ap + (size_t)s * RS * GF_LDA, rg.ring + rbuf * GF_STAGE + boff, acc, rg);
+        rg.advance();
+        rbuf = rbuf + 1 == GF_STAGES ? 0 : rbuf + 1;
+        ++s;
+      }
+    }
+  }
+}
+
+// GLU backward of column tile J of the accumulators: -> d(pre-activation) of the layer below in HBM (pair order) and, when
+// TO_LDS, into the operand buffer as rows 2 (wave 32 + lane) + t of the coming phase
+template <int NT, int J, bool TO_LDS>
+__device__ __forceinline__ void gd_epilogue(const sg_f32x16 (&acc)[2][NT], float* As, const GdSaved& sv,
+                                            float* __restrict__ dpre, int CP, int M, int m0, int lane, int wave) {
+  const int fi = lane & 31;
+  const int c = wave * 32 * NT + 32 * J + fi;
+  const bool live = c < CP;
+  const int q = ((c >> 4) << 5) + (c & 15);
+  const int k0 = 2 * (wave * 32 + fi);
+  float left[16][2], right[16][2];
+#pragma unroll
+  for (int reg = 0; reg < 16; ++reg) {
+    const int rl = 2 * g2_row_of(reg, lane);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const float d = acc[i][J][reg];
+      left[reg][i] = d * sv.g[reg][i];
+      right[reg][i] = d * sv.y[reg][i] * (1.f - sv.g[reg][i]);
+    }
+    if constexpr (TO_LDS) {
+      *reinterpret_cast<float2*>(As + k0 * GF_LDA + rl) = make_float2(left[reg][0], left[reg][1]);
+      *reinterpret_cast<float2*>(As + (k0 + 1) * GF_LDA + rl) = make_float2(right[reg][0], right[reg][1]);
+    }
+  }
+  // ONE lane predicate around the whole store loop: a per-store test puts every store pair into its own basic block, and
+  // hipcc then waits vmcnt(0) in each (the prefetched operands look pending at every join) -- the stores serialise
+  float* dp = dpre + (size_t)m0 * 2 * CP + q;
+  const bool full = m0 + GF_BM <= M;
+  if (!(GF_ABL & 1) && live) {
+    if (full) {
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const size_t off = (size_t)(2 * g2_row_of(reg, lane) + i) * 2 * CP;
+          dp[off] = left[reg][i];
+          dp[off + 16] = right[reg][i];
+        }
+    } else {
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int rl = 2 * g2_row_of(reg, lane) + i;
+          if (m0 + rl < M) {
+            dp[(size_t)rl * 2 * CP] = left[reg][i];
+            dp[(size_t)rl * 2 * CP + 16] = right[reg][i];
+          }
+        }
+    }
+  }
+}
+
+template <int NT>
+static __global__ __launch_bounds__(256, 1) void sg_glu_fused_dgrad_kernel(const GdArgs g) {
+  extern __shared__ __attribute__((aligned(16))) float gf_lds[];   // ONE array: As[KA][66] then the ring
+  float* As = gf_lds;
+  const int L = blockIdx.x, xcd = L & 7;
+  const int r = (xcd >> 2) & 1, rb = (L >> 3) * 4 + (xcd & 3);
+  if (rb >= g.nrb) return;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m0 = rb * GF_BM, M = g.M, CP = g.CP;
+  constexpr int RS = 32 / NT;
+
+  GfRing rg;
+  rg.ring = gf_lds + (size_t)g.KA * GF_LDA;
+  rg.wave = wave;
+  rg.src = g.wd[r] + (size_t)wave * GF_NI * 256 + lane * 4;
+  rg.next = 0; rg.last = g.ns[r] - 1; rg.wbuf = 0;
+#pragma unroll
+  for (int p = 0; p < GF_STAGES - 1; ++p) {
+#pragma unroll
+    for (int q = 0; q < GF_NI; ++q) rg.issue(q);
+    rg.advance();
+  }
+  {  // operand of the first product: the block's d(pre-activation) rows of layer 2, K-major; rows np2 .. nstA * RS - 1 zero
+    // a wave moves 16 rows x 4 k-quads per step, the quads 2 apart: the four ds_write_b32 of a lane's float4 then land in
+    // rows 8 apart = 16 banks apart per quad, 64 distinct banks per instruction (the row-per-wave mapping was 8-way
+    // conflicted); the other parity of the quads is the next step, so every 128-byte line is still used in full
+    const int np2 = g.np2[r], nq = np2 >> 2;
+    const float* src = g.dact2[r] + (size_t)m0 * np2;
+    const int rows = M - m0 < GF_BM ? M - m0 : GF_BM;
+    const int r16 = lane & 15, a4 = lane >> 4;
+    const int nkc = (nq + 7) >> 3;                      // chunks of 8 k-quads
+    for (int item = wave; item < 4 * nkc * 2; item += 4) {
+      const int par = item & 1, kc = (item >> 1) % nkc, rblk = (item >> 1) / nkc;
+      const int i = 16 * rblk + r16, kq = kc * 8 + 2 * a4 + par;
+      const bool ok = i < rows && kq < nq;
+      const float4 v = *reinterpret_cast<const float4*>(src + (ok ? (size_t)i * np2 + 4 * kq : 0));
+      if (kq < nq) {
+        float* d = As + (4 * kq) * GF_LDA + i;
+        d[0] = ok ? v.x : 0.f;
+        d[GF_LDA] = ok ? v.y : 0.f;
+        d[2 * GF_LDA] = ok ? v.z : 0.f;
+        d[3 * GF_LDA] = ok ? v.w : 0.f;
+      }
+    }
+    const int kend = g.nstA[r] * RS;
+    for (int idx = tid; idx < (kend - np2) * GF_BM; idx += 256) As[(np2 + idx / GF_BM) * GF_LDA + (idx % GF_BM)] = 0.f;
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  int rbuf = 0;
+  sg_f32x16 acc1[2][NT], acc0[2][NT];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) { acc1[i][j][e] = 0.f; acc0[i][j][e] = 0.f; }
+  GdSaved sva, svb;
+  gd_kloop<NT, 0, -1>(As, rg, rbuf, g.nstA[r], lane, wave, acc1, sva, svb, g.out1[r], g.gate1[r], CP, M, m0);   // d(out of layer 1)
+  __builtin_amdgcn_s_barrier();                                      // every wave is done reading the operand buffer
+  gd_epilogue<NT, 0, true>(acc1, As, sva, g.dact1[r], CP, M, m0, lane, wave);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  if constexpr (NT == 2) {
+    gd_kloop<NT, 1, -1>(As, rg, rbuf, g.nstB[0], lane, wave, acc0, sva, svb, g.out1[r], g.gate1[r], CP, M, m0);  // phase 0
+    __builtin_amdgcn_s_barrier();
+    gd_epilogue<NT, 1, true>(acc1, As, sva, g.dact1[r], CP, M, m0, lane, wave);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    gd_kloop<NT, 0, 1>(As, rg, rbuf, g.nstB[1], lane, wave, acc0, sva, svb, g.out0[r], g.gate0[r], CP, M, m0);   // phase 1
+  } else {
+    gd_kloop<NT, 0, -1>(As, rg, rbuf, g.nstB[0], lane, wave, acc0, sva, svb, g.out0[r], g.gate0[r], CP, M, m0);
+  }
+  // third product: d(pre-activation) of layer 0 (stored for the weight gradients, kept in LDS phase by phase) -> dG slab
+  sg_f32x16 accg;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) accg[e] = 0.f;
+  __builtin_amdgcn_s_barrier();
+  gd_epilogue<NT, 0, true>(acc0, As, sva, g.dact0[r], CP, M, m0, lane, wave);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  gd_kloop_c(As, rg, rbuf, g.nstC[0], lane, wave, accg);
+  if constexpr (NT == 2) {
+    __builtin_amdgcn_s_barrier();
+    gd_epilogue<NT, 1, true>(acc0, As, svb, g.dact0[r], CP, M, m0, lane, wave);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    gd_kloop_c(As, rg, rbuf, g.nstC[1], lane, wave, accg);
+  }
+  {
+    const int kin = (wave & 1) * 32 + (lane & 31), mi = wave >> 1;
+    float* pg = g.dG[r] + (size_t)m0 * g.KG + kin;
+    if (!(GF_ABL & 1) && kin < g.KG) {
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int rl = 2 * g2_row_of(reg, lane) + mi;
+        if (m0 + rl < M) pg[(size_t)rl * g.KG] = accg[reg];
+      }
+    }
+  }
+  gf_wait_vm<0>();
 }

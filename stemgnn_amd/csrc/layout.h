@@ -105,12 +105,56 @@ SG_HD size_t gf_stream_floats(const SgDims& d) {
 }
 
 
+// ---- fused GLU data-gradient chain (csrc/glu_fused.h, sg_glu_fused_dgrad_kernel): d(pre-activation) of layer 2 -> layer 1
+// -> layer 0 for a 64-row block with the running operand resident in LDS.  A wave owns 32 NT channels of the layer whose
+// d(out) is being formed (NT = MFMA column tiles per wave, 1 or 2).  A product's reduction index runs over the pair columns
+// of the layer above: in natural pair order for the first product (its operand arrives from HBM), in NT "phases" of 256
+// rows for the second (phase p = the left / right values of every wave's p-th channel group, written to LDS by the
+// epilogue that forms them: row 2 (wave 32 + lane) + t of the phase).
+struct GdGeom {
+  int nt;               // MFMA column tiles per wave
+  int rs;               // weight rows per 16 KB ring stage: 32 / nt
+  int nstA[2];          // stages of the first product (layer-2 weights), per branch: ceil(2 CP2[r] / rs)
+  int nstB[2];          // stages of each phase of the second product (layer-1 weights); unused phases have 0
+  int nstC[2];          // stages (64 weight rows each, 64 columns) of each phase of the third product (layer 0 -> dG)
+  int ns[2];            // stages per branch
+  int KA;               // rows of the LDS operand buffer
+  size_t lds_bytes;
+  bool ok;
+};
+SG_HD GdGeom gd_geom(const SgDims& d) {
+  GdGeom g;
+  g.nt = d.CP > 128 ? 2 : 1;
+  g.rs = 32 / g.nt;
+  g.ok = d.CP <= 256;
+  g.KA = 256;
+  for (int r = 0; r < 2; ++r) {
+    const int np2 = 2 * d.CP2[r];
+    g.nstA[r] = (np2 + g.rs - 1) / g.rs;
+    if (g.nstA[r] * g.rs > g.KA) g.KA = g.nstA[r] * g.rs;
+  }
+  for (int p = 0; p < 2; ++p) {
+    int live = 0;                                   // (wave, lane) pairs of phase p whose channel exists
+    for (int w = 0; w < 4; ++w)
+      for (int fi = 0; fi < 32; ++fi)
+        if (p < g.nt && w * 32 * g.nt + 32 * p + fi < d.CP) ++live;
+    g.nstB[p] = (2 * live + g.rs - 1) / g.rs;
+    g.nstC[p] = (2 * live + 63) / 64;
+  }
+  for (int r = 0; r < 2; ++r) g.ns[r] = g.nstA[r] + g.nstB[0] + g.nstB[1] + g.nstC[0] + g.nstC[1];
+  g.ok = g.ok && d.KG <= 64;                         // the third product's 64 output columns hold the 3 W columns of dG
+  g.lds_bytes = ((size_t)g.KA * GF_LDA + (size_t)GF_STAGES * GF_STAGE) * sizeof(float);
+  g.ok = g.ok && g.lds_bytes <= (size_t)160 * 1024;
+  return g;
+}
+
 // ---- packed-weights buffer of one StockBlock (floats) -----------------------------------------
 // [r=0..1][l=0..2]: Wp (K_in x NP) then bias (NP)   ;  then Wfold (KF x WmP)  ;  then the fused-order GLU weight streams
 struct SgPackedLayout {
   size_t w[2][3], b[2][3], wfold, total;   // total: end of the panels sg_pack_kernel writes
   size_t wfused[2];                         // fused-order weight stream per branch (csrc/glu_fused.h), 16-byte aligned; 0 floats
-  size_t total_ext;                         // when the fused kernel does not apply.  total_ext: size of the whole buffer
+  size_t wdgrad[2];                         // when the fused kernel does not apply; wdgrad: the data-gradient chain's stream
+  size_t total_ext;                         // total_ext: size of the whole buffer
 };
 SG_HD SgPackedLayout sg_packed_layout(const SgDims& d) {
   SgPackedLayout L;
@@ -125,6 +169,8 @@ SG_HD SgPackedLayout sg_packed_layout(const SgDims& d) {
   off = (off + 3) & ~(size_t)3;
   const size_t per_branch = gf_stream_floats(d) / 2;
   for (int r = 0; r < 2; ++r) { L.wfused[r] = off; off += per_branch; }
+  const GdGeom gd = gd_geom(d);
+  for (int r = 0; r < 2; ++r) { L.wdgrad[r] = off; off += gd.ok ? (size_t)gd.ns[r] * GF_STAGE : 0; }
   L.total_ext = off;
   return L;
 }

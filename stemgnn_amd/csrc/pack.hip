@@ -164,8 +164,16 @@ extern "C" int stemgnn_block_pack(const float* const* params_host, const float* 
   const unsigned blocks = (unsigned)((P.total + 255) / 256);
   hipLaunchKernelGGL(sg_pack_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, prm, tables, packed, d, P, T);
   SG_TRY(hipGetLastError());
-  // the same GLU weights once more as the stage stream of the fused three-layer forward (csrc/glu_fused.h), from the panels
-  // just written (stream order); 1.6 MB per block at W * multi = 60
+  return stemgnn_glu_fused_repack(packed, W, multi, stream);
+}
+
+// The GLU weights once more as the stage stream of the fused three-layer forward (csrc/glu_fused.h), produced from the pair
+// panels already in `packed` (stream order; 1.6 MB per block at W * multi = 60).  stemgnn_block_pack calls it; exported
+// for callers that fill the panels themselves (timing probes, stage tests).  No-op where the fused kernel does not apply.
+extern "C" int stemgnn_glu_fused_repack(float* packed, int W, int multi, void* stream) {
+  if (!packed || W <= 0 || multi <= 0) return SG_EINVAL;
+  const SgDims d = sg_dims(1, 1, W, multi);
+  const SgPackedLayout P = sg_packed_layout(d);
   const GfGeom gg = gf_geom(d);
   if (gg.ok) {
     GfPackArgs a;
@@ -181,6 +189,22 @@ extern "C" int stemgnn_block_pack(const float* const* params_host, const float* 
     for (int r = 0; r < 2; ++r) a.wf[r] = packed + P.wfused[r];
     const unsigned fb = (unsigned)(((size_t)gg.ns * GF_STAGE + 255) / 256);
     hipLaunchKernelGGL(sg_pack_fused_kernel, dim3(fb, 2), dim3(256), 0, (hipStream_t)stream, a);
+    SG_TRY(hipGetLastError());
+  }
+  const GdGeom gd = gd_geom(d);          // ... and as the stream of the fused data-gradient chain (transposed products)
+  if (gd.ok) {
+    GdPackArgs a;
+    a.g = gd;
+    a.CP = d.CP; a.KG = d.KG;
+    for (int l = 0; l < 3; ++l)
+      for (int r = 0; r < 2; ++r) {
+        a.wp[r][l] = packed + P.w[r][l];
+        a.np[r][l] = sg_glu_np(d, l, r);
+      }
+    for (int r = 0; r < 2; ++r) a.wd[r] = packed + P.wdgrad[r];
+    const int nsmax = gd.ns[0] > gd.ns[1] ? gd.ns[0] : gd.ns[1];
+    const unsigned fb = (unsigned)(((size_t)nsmax * GF_STAGE + 255) / 256);
+    hipLaunchKernelGGL(sg_pack_dgrad_kernel, dim3(fb, 2), dim3(256), 0, (hipStream_t)stream, a);
     SG_TRY(hipGetLastError());
   }
   return 0;
