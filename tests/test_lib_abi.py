@@ -42,7 +42,11 @@ def test_version_and_sizes(lib):
     assert b"gfx950" in lib.stemgnn_version()
     # PEMS07 shape: W=12, multi=5 -> GLU panels 36x480, 240x480, 240x480, 240x256 ... (layout.h)
     n = lib.stemgnn_packed_floats(12, 5)
-    expect = 2 * (36 * 480 + 480 + 240 * 480 + 480) + (240 * 256 + 256) * 2 + 256 * 64
+    panels = 2 * (36 * 480 + 480 + 240 * 480 + 480) + (240 * 256 + 256) * 2 + 256 * 64
+    # + the same weights as the 16 KB-stage streams of the fused kernels (csrc/glu_fused.h), 4096 floats per stage:
+    # forward: per branch 5 (K 36 -> 40, 8 rows) + 30 (K 240, 8 rows) + 15 (K 240, 16 rows) stages;
+    # data-gradient chain: per branch 16 (256 rows / 16) + 16 + 14 (two phases of 256 / 224 live rows) + 4 + 4 (64-row stages)
+    expect = panels + 2 * (5 + 30 + 15) * 4096 + 2 * (16 + 16 + 14 + 4 + 4) * 4096
     assert n == expect
     assert lib.stemgnn_table_floats(12, 5) == 2 * 144 + 31 * 60 + 29 * 60
     assert lib.stemgnn_saved_floats(32, 228, 12, 5) == 7296 * (36 + 2 * 2 * (240 + 240 + 128) + 120)
