@@ -102,9 +102,19 @@ def time_gemm_families(cfg, iters=20):
                        "glu_bwd")
         return run
 
+    # round 4: one fused launch per block for the forward and for the data-gradient chain where the padded channel count
+    # 4 W multi is <= 256 (csrc/glu_fused.h); configs[4] (W = 48) keeps the per-layer launches
+    fused = (4 * W * multi + 15) // 16 * 16 <= 256 and os.environ.get("STEMGNN_GLU_FUSED", "1") != "0"
+    if fused:
+        fwd_desc = (fwd, 1, "sg_glu_fused_fwd_kernel (the three GLU layers of a block, both branches, in ONE launch: row block's "
+                            "activations resident in LDS, weights on a direct-to-LDS ring)")
+        dg_desc = (bwd(1), 1, "sg_glu_fused_dgrad_kernel (d(pre-activation) of layer 2 -> 1 -> 0 -> dG in ONE launch per block)")
+    else:
+        fwd_desc = (fwd, 3, "sg_gemm2<GluFwdEpi> (spectral GLU forward: 3 launches per block, both branches per launch)")
+        dg_desc = (bwd(1), 3, "sg_gemm2<GluDpreEpi> x2 + sg_gemm_f32<GluDgrad0Op> (GLU data gradients: 3 launches per block)")
     fams = {
-        "glu_fwd": (fwd, 3, "sg_gemm2<GluFwdEpi> (spectral GLU forward: 3 launches per block, both branches per launch)"),
-        "glu_dgrad": (bwd(1), 3, "sg_gemm2<GluDpreEpi> x2 + sg_gemm_f32<GluDgrad0Op> (GLU data gradients: 3 launches per block)"),
+        "glu_fwd": fwd_desc,
+        "glu_dgrad": dg_desc,
         "glu_wgrad": (bwd(2), 1, "sg_wgrad_kernel (all six GLU weight-gradient products of a block in ONE launch: direct-to-LDS "
                                  "ring, in-kernel fixed-order split reduction -- no reduce kernel)"),
     }

@@ -384,7 +384,7 @@ def test_large_config_shapes(N, W, multi, H, B):
     assert not bad, bad
 
 
-@pytest.mark.parametrize("shape", [(32, 228, 12, 5), (3, 20, 12, 5), (2, 9, 4, 2)])
+@pytest.mark.parametrize("shape", [(32, 228, 12, 5), (3, 20, 12, 5), (2, 9, 4, 2), (5, 33, 7, 3), (2, 70, 16, 4), (4, 100, 12, 1)])
 def test_fused_three_layer_glu_forward_matches_layerwise(shape, monkeypatch):
     """The fused three-layer GLU forward (csrc/glu_fused.h: activations of a row block resident in LDS, weight stream on a
     direct-to-LDS ring; the default where its shape rules hold) against the three per-layer GEMM launches
@@ -401,19 +401,31 @@ def test_fused_three_layer_glu_forward_matches_layerwise(shape, monkeypatch):
     st = torch.cuda.current_stream().cuda_stream
     _lib.check(lib.stemgnn_block_pack(_lib.ptr_array(blk.hip_params()), tables.data_ptr(), pk.data_ptr(), W, multi, st), "pack")
     n_saved = lib.stemgnn_saved_floats(B, N, W, multi)
+    n_scr = lib.stemgnn_scratch_floats(B, N, W, multi)
+    n_gp = lib.stemgnn_gradpart_floats(W, multi, 32)
     G = torch.randn(B * N * 3 * W, device=dev)
-    outs = []
+    scr0 = torch.randn(n_scr, device=dev) * 0.1            # carries the d(pre-activation) of layer 2, the chain's input
+    gp = torch.empty(n_gp, device=dev)
+    outs, scrs = [], []
     for flag in ("0", "1"):
         monkeypatch.setenv("STEMGNN_GLU_FUSED", flag)
         sv = torch.zeros(n_saved, device=dev)
         sv[: G.numel()] = G
         _lib.check(lib.stemgnn_spectral_glu_fwd(pk.data_ptr(), sv.data_ptr(), B, N, W, multi, st), "glu_fwd")
+        scr = scr0.clone()
+        # data-gradient chain (parts = 1): fused = one launch for layer 2 -> 1 -> 0 -> dG, else two launches + GluDgrad0Op
+        _lib.check(lib.stemgnn_spectral_glu_bwd(pk.data_ptr(), sv.data_ptr(), scr.data_ptr(), gp.data_ptr(), 32, 1, B, N, W,
+                                                multi, st), "glu_bwd")
         torch.cuda.synchronize()
         outs.append(sv.clone())
+        scrs.append(scr.clone())
     monkeypatch.delenv("STEMGNN_GLU_FUSED")
     ref, got = outs
     assert float(ref[G.numel():].abs().max()) > 0
-    assert relerr(got, ref) < 1e-6
+    assert torch.equal(got, ref)          # the forward sums every accumulator in the per-layer kernels' order: same bits
+    assert relerr(scrs[1], scrs[0]) < 1e-6 and not torch.equal(scrs[0], scr0)   # phase-ordered reduction: rounding only
+    off = lib.stemgnn_scratch_offset_dG(B, N, W, multi)
+    assert relerr(scrs[1][off:off + 2 * B * N * 3 * W], scrs[0][off:off + 2 * B * N * 3 * W]) < 1e-5
 
 
 @pytest.mark.parametrize("lead,cin,cout", [((7296,), 48, 240), ((3, 20), 36, 60), ((5,), 7, 9), ((2, 3, 4), 240, 240)])
