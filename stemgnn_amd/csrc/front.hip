@@ -250,6 +250,7 @@ __global__ __launch_bounds__(256) void sg_laplacian_fused_kernel(const float* __
 __global__ __launch_bounds__(256) void sg_laplacian_bwd_kernel(const float* __restrict__ dL, const float* __restrict__ A,
                                                                const float* __restrict__ deg, float* __restrict__ dAB,
                                                                int B, int N, int with_degree) {
+  __builtin_amdgcn_s_setprio(SG_CHAIN_PRIO);      // see gemm_core.h: these run beside the weight-gradient launch
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = blockIdx.x * 4 + wave;
   if (i >= N) return;
@@ -282,6 +283,7 @@ __global__ __launch_bounds__(256) void sg_attention_bwd_kernel(
     const float* __restrict__ dAB, const float* __restrict__ key, const float* __restrict__ query,
     const float* __restrict__ rowsum, float alpha, float drop_p, int training, const uint64_t* __restrict__ seedp,
     int B, int N, int nchunk, float* __restrict__ dkey, float* __restrict__ dqpart) {
+  __builtin_amdgcn_s_setprio(SG_CHAIN_PRIO);      // see gemm_core.h: these run beside the weight-gradient launch
   extern __shared__ __attribute__((aligned(16))) float smem[];
   __shared__ float wred[4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -365,6 +367,7 @@ __global__ __launch_bounds__(256) void sg_attention_bwd_kernel(
 // folding it into the attention kernel as a last-arriver reduction was measured slower in round 3.
 __global__ void sg_dquery_reduce_kernel(const float* __restrict__ dqpart, float* __restrict__ dquery, int B, int N,
                                         int nchunk) {
+  __builtin_amdgcn_s_setprio(SG_CHAIN_PRIO);      // see gemm_core.h: these run beside the weight-gradient launch
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (size_t)B * N) return;
   const int b = (int)(idx / N), j = (int)(idx - (size_t)b * N);
@@ -378,6 +381,7 @@ __global__ __launch_bounds__(256) void sg_keyquery_bwd_kernel(const float* __res
                                                               const float* __restrict__ wq, const float* __restrict__ dkey,
                                                               const float* __restrict__ dquery, float* __restrict__ dh,
                                                               float* __restrict__ dwk, float* __restrict__ dwq, int B, int N) {
+  __builtin_amdgcn_s_setprio(SG_CHAIN_PRIO);      // see gemm_core.h: these run beside the weight-gradient launch
   __shared__ float red[4][2];
   const int s = blockIdx.x;
   const size_t BN = (size_t)B * N;

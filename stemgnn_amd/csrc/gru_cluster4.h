@@ -49,7 +49,7 @@ __device__ __forceinline__ void gru4_after_publish(const gru_u64* g) {
 #define GRU_POLL_MODE 0
 #endif
 #ifndef GRU_POLL_PRE_F
-#define GRU_POLL_PRE_F 12
+#define GRU_POLL_PRE_F 10     // (12 with the libm gate math of rounds 2-3; retuned with GRU_FAST_GATES in round 4: 1.290 -> 1.277 ms per step)
 #endif
 #ifndef GRU_POLL_PRE_B
 #define GRU_POLL_PRE_B 9
@@ -57,6 +57,57 @@ __device__ __forceinline__ void gru4_after_publish(const gru_u64* g) {
 #ifndef GRU_POLL_LOOP_SLEEP
 #define GRU_POLL_LOOP_SLEEP 1
 #endif
+// ---- gate math of the forward's gate wave ---------------------------------------------------------------------------
+// The gate phase (LDS partial sums -> sigmoid, sigmoid, tanh -> granule store) sits on the critical path of every
+// recurrence step, and two thirds of its ~700 cycles were libm: expf, tanhf and two IEEE divisions are ~120 VALU
+// instructions on one wave.  GRU_FAST_GATES = 1 (round 4) evaluates the same functions on the hardware transcendental
+// units WITH their rounding errors compensated, so the results stay within ~2 ulp of the exact value (the plain
+// v_exp_f32 / v_rcp_f32 forms tried in round 2 carried |x| 2^-24 of argument-scaling error into the exponential and
+// moved a kink-sensitive gradient by 8e-4 at N = 358):
+//   e^x      = v_exp_f32(t) (1 + r ln 2),  t = fl(x log2e_hi),  r = (x log2e_hi - t) + x log2e_lo   (two fma recover r)
+//   1 / d    = y + y (1 - d y),            y = v_rcp_f32(d)                                         (one Newton step)
+//   tanh x   = x + x^3 P(x^2) for |x| < 0.625 (Cephes tanhf, degree 4 in x^2), else sign(x) (1 - 2 / (e^{2|x|} + 1))
+// GRU_FAST_GATES = 0 keeps expf / tanhf / IEEE division.
+#ifndef GRU_FAST_GATES
+#define GRU_FAST_GATES 1
+#endif
+__device__ __forceinline__ float gru4_exp(float x) {
+  const float L2E_HI = 1.44269502162933349609375f;      // float(log2 e)
+  const float L2E_LO = 1.925963033500011e-8f;           // log2 e - float(log2 e)
+  const float t = x * L2E_HI;
+  float r = __builtin_fmaf(x, L2E_HI, -t);
+  r = __builtin_fmaf(x, L2E_LO, r);
+  const float e = __builtin_amdgcn_exp2f(t);
+  return __builtin_fmaf(e, r * 0.693147182464599609375f, e);
+}
+__device__ __forceinline__ float gru4_rcp(float d) {
+  const float y = __builtin_amdgcn_rcpf(d);
+  return __builtin_fmaf(y, __builtin_fmaf(-d, y, 1.f), y);
+}
+__device__ __forceinline__ float gru4_sigmoid(float v) {
+#if GRU_FAST_GATES
+  const float vc = fminf(fmaxf(v, -87.f), 87.f);        // keeps 1 + e^{-v} finite for the Newton step; sigma saturates long before
+  return gru4_rcp(1.f + gru4_exp(-vc));
+#else
+  return gru_sigmoid(v);
+#endif
+}
+__device__ __forceinline__ float gru4_tanh(float x) {
+#if GRU_FAST_GATES
+  const float ax = fabsf(x), z = x * x;
+  float p = __builtin_fmaf(-5.70498872745e-3f, z, 2.06390887954e-2f);
+  p = __builtin_fmaf(p, z, -5.37397155531e-2f);
+  p = __builtin_fmaf(p, z, 1.33314422036e-1f);
+  p = __builtin_fmaf(p, z, -3.33332819422e-1f);
+  const float small = __builtin_fmaf(p * z, x, x);
+  const float e2 = gru4_exp(2.f * fminf(ax, 44.f));
+  const float big = __builtin_fmaf(-2.f, gru4_rcp(e2 + 1.f), 1.f);
+  return ax < 0.625f ? small : copysignf(big, x);
+#else
+  return tanhf(x);
+#endif
+}
+
 template <int PRE>
 __device__ __forceinline__ float gru4_poll(const gru_u64* g, unsigned tag, bool active, int* status) {
   if (PRE > 0) __builtin_amdgcn_s_sleep(PRE);
@@ -254,9 +305,9 @@ __global__ __launch_bounds__((P + 2) * 64) void gru_fwd_cluster4_kernel(const fl
         g2 += part[s & 1][2 * P + qq][lane];
       }
       const float gp0 = gin[s & 1][0][lane], gp1 = gin[s & 1][1][lane], gp2 = gin[s & 1][2][lane];
-      const float r = gru_sigmoid(gp0 + g0);
-      const float z = gru_sigmoid(gp1 + g1);
-      const float n = tanhf(gp2 + r * g2);
+      const float r = gru4_sigmoid(gp0 + g0);
+      const float z = gru4_sigmoid(gp1 + g1);
+      const float n = gru4_tanh(gp2 + r * g2);
       const float hn = (1.f - z) * n + z * hown;
       hown = hn;
       if (s + 1 < S && lane_ok) gru_publish_x(pub + ((s + 1) & 1) * par, (unsigned)(s + 1), hn, fast);
@@ -347,21 +398,17 @@ __global__ __launch_bounds__((3 * P / OW + 2) * 64) void gru_bwd_cluster4_kernel
       float pv;
       if constexpr (OW == 1) {
         const float dv = gru4_poll<GRU_POLL_PRE_B>(pollp[0] + (tag & 1) * par, tag, lane < kn[0], status);
-        GRU_T(t1);
-        GRU_ACC(c_a, t1, t0);
         pv = gru_matvec<KU, (KU <= 58 ? GRU_NR4 : (GRU_NR4 > 24 ? GRU_NR4 : 24))>(wr[0], dv, lrow[wave], lane);
       } else {
         float dv[2];
         gru4_poll2<GRU_POLL_PRE_B>(pollp[0] + (tag & 1) * par, pollp[1] + (tag & 1) * par, tag, lane < kn[0], lane < kn[1],
                                    status, dv);
-        GRU_T(t1);
-        GRU_ACC(c_a, t1, t0);
         pv = gru_matvec<KU, 64>(wr[0], dv[0], lrow[wave], lane);
         pv += gru_matvec<KU, 64>(wr[OW - 1], dv[1], lrow[wave], lane);
       }
       part[tag & 1][wave][lane] = pv;
       GRU_T(t2);
-      GRU_ACC(c_b, t2, t1);
+      GRU_ACC(c_b, t2, t0);                              // (poll + mat-vec together: the poll's end is inside the if constexpr)
       gru_lds_barrier();                                 // B_s
       GRU_T(t3);
       GRU_ACC(c_c, t3, t2);

@@ -106,15 +106,26 @@ __global__ __launch_bounds__(GW_NW * 64) void gru_fwd_wide_kernel(
       __builtin_amdgcn_make_buffer_rsrc(hx, 0, KG * 256 * 4, 0x00020000),
       __builtin_amdgcn_make_buffer_rsrc(hx + (size_t)KG * 256, 0, KG * 256 * 4, 0x00020000)};
 
+#ifdef GRU_PROF
+  long long c_flag = 0, c_mm = 0, c_sync1 = 0, c_gate = 0, c_drain = 0, c_sync2 = 0;
+#define GW_T(v) const long long v = (long long)__builtin_readcyclecounter()
+#define GW_ACC(a, t1, t0) a += (t1) - (t0)
+#else
+#define GW_T(v)
+#define GW_ACC(a, t1, t0)
+#endif
   for (int s = 0; s < S; ++s) {
     const size_t row = (size_t)s * B + gbb;
     const float* gip = gi + row * H3;
     const float gp0 = gip[gu], gp1 = gip[Hd + gu], gp2 = gip[2 * Hd + gu];     // prefetch for the gate phase
+    GW_T(t0);
     gw_f4 acc[MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) acc[m] = gw_f4{0.f, 0.f, 0.f, 0.f};
     if (s > 0 && G0 < G1) {
       gw_wait_flags(flags, pa, pb, (unsigned)s, lane, status);
+      GW_T(tf);
+      GW_ACC(c_flag, tf, t0);
       // chunks of GW_CH groups, double buffered: the loads of chunk c + 1 are in flight under the MFMAs of chunk c
       constexpr int GW_CH = MT * GW >= 48 ? 2 : 4;
       gw_f4 v[2][GW_CH];
@@ -140,7 +151,11 @@ __global__ __launch_bounds__(GW_NW * 64) void gru_fwd_wide_kernel(
     for (int m = 0; m < MT; ++m)
 #pragma unroll
       for (int e = 0; e < 4; ++e) part[wave][16 * m + 4 * ak + e][ai] = acc[m][e];
+    GW_T(t1);
     __syncthreads();
+    GW_T(t2);
+    GW_ACC(c_mm, t1, t0);
+    GW_ACC(c_sync1, t2, t1);
     float r = 0.f, z = 0.f, n = 0.f, g2 = 0.f, hn = 0.f;
     if (gate) {
       float g0 = bh0, g1 = bh1;
@@ -160,8 +175,14 @@ __global__ __launch_bounds__(GW_NW * 64) void gru_fwd_wide_kernel(
         __hip_atomic_store(hx + (size_t)((s + 1) & 1) * KG * 256 + gw_slot(gu, gb), hn, __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);
     }
+    GW_T(t3);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wave drains its write-through stores ...
+    GW_T(t4);
     __syncthreads();                                       // ... before the one flag store (also: `part` may be reused)
+    GW_T(t5);
+    GW_ACC(c_gate, t3, t2);
+    GW_ACC(c_drain, t4, t3);
+    GW_ACC(c_sync2, t5, t4);
     if (tid == 0 && s + 1 < S) __hip_atomic_store(flags + p, (unsigned)(s + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (gate) {                                            // saved tensors: off the critical path, after the flag
       float* rsv = reserve + row * 4 * Hd;
@@ -169,6 +190,11 @@ __global__ __launch_bounds__(GW_NW * 64) void gru_fwd_wide_kernel(
       h_all[row * Hd + gu] = hn;
     }
   }
+#ifdef GRU_PROF
+  if ((p == 0 || p == 100) && lane == 0 && (wave == 0 || wave == 5))
+    printf("gru wide fwd wg %d wave %d: per step cycles: flag wait %lld  (flag+load+mfma %lld)  sync1 %lld  gate %lld  drain %lld  sync2 %lld\n",
+           p, wave, c_flag / S, c_mm / S, c_sync1 / S, c_gate / S, c_drain / S, c_sync2 / S);
+#endif
 }
 
 // ---- backward --------------------------------------------------------------------------------------------------

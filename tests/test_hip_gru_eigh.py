@@ -291,6 +291,67 @@ def test_model_eig_route_train_mode_with_dropout(monkeypatch):
         assert relerr(res["eig"][2][k], g) < TOL, k
 
 
+@pytest.mark.parametrize("N,B", [(228, 8), (358, 4), (1024, 2)])
+def test_model_eig_route_at_real_sizes(N, B, monkeypatch):
+    """The eigen route INSIDE the model at the sizes of BASELINE configs[1], [2], [3] (only N = 60, the
+    one-workgroup register-resident kernel, was covered): N = 228 runs the register-resident tridiagonalisation, N = 358 and
+    1024 the multi-workgroup grid-barrier kernel.  T_k(L) = U p_k(Lambda) U^T is the same function of L as the two Chebyshev
+    products, so forecast, attention and every parameter gradient of the two routes must agree; the Chebyshev route is
+    pinned to the oracle at these shapes by test_hip_parity."""
+    from stemgnn_amd import Model, ops
+
+    W, multi, H = 12, 5, 3
+    sd = O.det_state_dict(N, W, multi, H, seed=11)
+    torch.manual_seed(N)
+    x, y = torch.randn(B, W, N).cuda(), torch.randn(B, H, N).cuda()
+    res = {}
+    for route in ("cheb", "eig"):
+        monkeypatch.setenv("STEMGNN_SPECTRAL", route)
+        model = Model(N, 2, W, multi, horizon=H, dropout_rate=0.0)
+        model.load_state_dict(sd)
+        model.cuda().train()
+        forecast, att = model(x)
+        torch.nn.functional.mse_loss(forecast, y).backward()
+        torch.cuda.synchronize()
+        res[route] = (forecast.detach(), att.detach(), {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None})
+    ops.check_eigh_status(torch.device("cuda:0"))
+    ops.check_gru_status(torch.device("cuda:0"))
+    assert relerr(res["eig"][0], res["cheb"][0]) < TOL and relerr(res["eig"][1], res["cheb"][1]) < TOL
+    for k, g in res["cheb"][2].items():
+        assert relerr(res["eig"][2][k], g) < TOL, (k, relerr(res["eig"][2][k], g))
+
+
+def test_eig_route_inside_the_hipgraph_train_step(monkeypatch):
+    """STEMGNN_SPECTRAL=eig through engine.TrainStep at the headline shape: the seven launches of the direct solver are
+    captured with the rest of the step (one hipGraph replay per batch) and the training losses track the Chebyshev
+    route's (same seeds, same dropout stream)."""
+    from stemgnn_amd import Model, ops
+    from stemgnn_amd.engine import TrainStep
+    from stemgnn_amd.optim import FusedRMSprop
+
+    N, W, multi, H, B, T = 228, 12, 5, 3, 32, 600
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(2)
+    series = torch.randn(T, N, generator=g).to(dev)
+    hi = (torch.randperm(T - W - H, generator=g)[: 6 * B] + W).view(6, B).to(dev)
+    losses, modes = {}, {}
+    for route in ("cheb", "eig"):
+        monkeypatch.setenv("STEMGNN_SPECTRAL", route)
+        torch.manual_seed(0)
+        model = Model(N, 2, W, multi, horizon=H).to(dev).train()
+        model.set_dropout_seed(77, 0)
+        opt = FusedRMSprop(model.parameters(), lr=1e-4, eps=1e-8)
+        step = TrainStep(model, opt, B, W, H, N, series=series)
+        out = []
+        for i in range(6):
+            step.run_indices(hi[i])
+            out.append(float(step.loss.item()))
+        losses[route], modes[route] = out, step.mode
+    ops.check_eigh_status(dev)
+    assert modes["eig"] == "hipgraph(whole step)", modes
+    assert all(abs(a - b) <= 2e-4 * abs(b) for a, b in zip(losses["eig"], losses["cheb"])), losses
+
+
 def test_miopen_gru_switch_gives_same_result(monkeypatch):
     from stemgnn_amd import Model
 
