@@ -57,56 +57,7 @@ __device__ __forceinline__ void gru4_after_publish(const gru_u64* g) {
 #ifndef GRU_POLL_LOOP_SLEEP
 #define GRU_POLL_LOOP_SLEEP 1
 #endif
-// ---- gate math of the forward's gate wave ---------------------------------------------------------------------------
-// The gate phase (LDS partial sums -> sigmoid, sigmoid, tanh -> granule store) sits on the critical path of every
-// recurrence step, and two thirds of its ~700 cycles were libm: expf, tanhf and two IEEE divisions are ~120 VALU
-// instructions on one wave.  GRU_FAST_GATES = 1 (round 4) evaluates the same functions on the hardware transcendental
-// units WITH their rounding errors compensated, so the results stay within ~2 ulp of the exact value (the plain
-// v_exp_f32 / v_rcp_f32 forms tried in round 2 carried |x| 2^-24 of argument-scaling error into the exponential and
-// moved a kink-sensitive gradient by 8e-4 at N = 358):
-//   e^x      = v_exp_f32(t) (1 + r ln 2),  t = fl(x log2e_hi),  r = (x log2e_hi - t) + x log2e_lo   (two fma recover r)
-//   1 / d    = y + y (1 - d y),            y = v_rcp_f32(d)                                         (one Newton step)
-//   tanh x   = x + x^3 P(x^2) for |x| < 0.625 (Cephes tanhf, degree 4 in x^2), else sign(x) (1 - 2 / (e^{2|x|} + 1))
-// GRU_FAST_GATES = 0 keeps expf / tanhf / IEEE division.
-#ifndef GRU_FAST_GATES
-#define GRU_FAST_GATES 1
-#endif
-__device__ __forceinline__ float gru4_exp(float x) {
-  const float L2E_HI = 1.44269502162933349609375f;      // float(log2 e)
-  const float L2E_LO = 1.925963033500011e-8f;           // log2 e - float(log2 e)
-  const float t = x * L2E_HI;
-  float r = __builtin_fmaf(x, L2E_HI, -t);
-  r = __builtin_fmaf(x, L2E_LO, r);
-  const float e = __builtin_amdgcn_exp2f(t);
-  return __builtin_fmaf(e, r * 0.693147182464599609375f, e);
-}
-__device__ __forceinline__ float gru4_rcp(float d) {
-  const float y = __builtin_amdgcn_rcpf(d);
-  return __builtin_fmaf(y, __builtin_fmaf(-d, y, 1.f), y);
-}
-__device__ __forceinline__ float gru4_sigmoid(float v) {
-#if GRU_FAST_GATES
-  const float vc = fminf(fmaxf(v, -87.f), 87.f);        // keeps 1 + e^{-v} finite for the Newton step; sigma saturates long before
-  return gru4_rcp(1.f + gru4_exp(-vc));
-#else
-  return gru_sigmoid(v);
-#endif
-}
-__device__ __forceinline__ float gru4_tanh(float x) {
-#if GRU_FAST_GATES
-  const float ax = fabsf(x), z = x * x;
-  float p = __builtin_fmaf(-5.70498872745e-3f, z, 2.06390887954e-2f);
-  p = __builtin_fmaf(p, z, -5.37397155531e-2f);
-  p = __builtin_fmaf(p, z, 1.33314422036e-1f);
-  p = __builtin_fmaf(p, z, -3.33332819422e-1f);
-  const float small = __builtin_fmaf(p * z, x, x);
-  const float e2 = gru4_exp(2.f * fminf(ax, 44.f));
-  const float big = __builtin_fmaf(-2.f, gru4_rcp(e2 + 1.f), 1.f);
-  return ax < 0.625f ? small : copysignf(big, x);
-#else
-  return tanhf(x);
-#endif
-}
+#include "gru_math.h"
 
 template <int PRE>
 __device__ __forceinline__ float gru4_poll(const gru_u64* g, unsigned tag, bool active, int* status) {

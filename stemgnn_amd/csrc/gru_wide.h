@@ -19,6 +19,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "gru_math.h"
+
 typedef float gw_f4 __attribute__((ext_vector_type(4)));
 typedef unsigned int gw_u4 __attribute__((ext_vector_type(4)));
 constexpr int GW_NW = 8;        // waves per workgroup (each takes a contiguous slice of the reduction)
@@ -119,9 +121,11 @@ __global__ __launch_bounds__(GW_NW * 64) void gru_fwd_wide_kernel(
     const float* gip = gi + row * H3;
     const float gp0 = gip[gu], gp1 = gip[Hd + gu], gp2 = gip[2 * Hd + gu];     // prefetch for the gate phase
     GW_T(t0);
-    gw_f4 acc[MT];
+    // two accumulators per M tile: v_mfma_f32_16x16x4_f32 has a ~40-cycle dependent latency; one chain of the slice's 4 GW
+    // instructions was 1300 cycles of every step at N = 1024 (round 4)
+    gw_f4 acc[MT][2];
 #pragma unroll
-    for (int m = 0; m < MT; ++m) acc[m] = gw_f4{0.f, 0.f, 0.f, 0.f};
+    for (int m = 0; m < MT; ++m) { acc[m][0] = gw_f4{0.f, 0.f, 0.f, 0.f}; acc[m][1] = gw_f4{0.f, 0.f, 0.f, 0.f}; }
     if (s > 0 && G0 < G1) {
       gw_wait_flags(flags, pa, pb, (unsigned)s, lane, status);
       GW_T(tf);
@@ -144,13 +148,15 @@ __global__ __launch_bounds__(GW_NW * 64) void gru_fwd_wide_kernel(
           for (int sl = 0; sl < 4; ++sl)
 #pragma unroll
             for (int m = 0; m < MT; ++m)     // groups beyond the slice carry zero weights: clamped loads are harmless
-              acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[m][4 * (c * GW_CH + g) + sl], v[c & 1][g][sl], acc[m], 0, 0, 0);
+              acc[m][sl & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[m][4 * (c * GW_CH + g) + sl], v[c & 1][g][sl], acc[m][sl & 1], 0, 0, 0);
       }
     }
 #pragma unroll
-    for (int m = 0; m < MT; ++m)
+    for (int m = 0; m < MT; ++m) {
+      const gw_f4 a = acc[m][0] + acc[m][1];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) part[wave][16 * m + 4 * ak + e][ai] = acc[m][e];
+      for (int e = 0; e < 4; ++e) part[wave][16 * m + 4 * ak + e][ai] = a[e];
+    }
     GW_T(t1);
     __syncthreads();
     GW_T(t2);
@@ -166,9 +172,9 @@ __global__ __launch_bounds__(GW_NW * 64) void gru_fwd_wide_kernel(
         g1 += part[w][U + gul][gb];
         g2 += part[w][2 * U + gul][gb];
       }
-      r = gw_sigmoid(gp0 + g0);
-      z = gw_sigmoid(gp1 + g1);
-      n = tanhf(gp2 + r * g2);
+      r = gru4_sigmoid(gp0 + g0);          // compensated hardware transcendentals (gru_math.h), as in the per-row clusters
+      z = gru4_sigmoid(gp1 + g1);
+      n = gru4_tanh(gp2 + r * g2);
       hn = (1.f - z) * n + z * hown;
       hown = hn;
       if (s + 1 < S)       // h_s into the parity step s + 1 reads
