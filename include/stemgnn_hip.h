@@ -69,7 +69,11 @@ int stemgnn_attn_laplacian_fwd(const float* h, const float* wk, const float* wq,
                                int parts, void* stream);
 /* dL [N,N] = gradient w.r.t. mul_L slot 1 (total).  Outputs dh [N,B,N], dwk [N], dwq [N].
  * scratch: stemgnn_attn_scratch_floats(B,N,nchunk).  parts bit 0: Laplacian backward -> dA / B in scratch[0 .. N*N)
- * (averaged over the ranks by an exact-mode data-parallel caller), bit 1: softmax / key / query backward; 3 = both. */
+ * (averaged over the ranks by an exact-mode data-parallel caller), bit 1: softmax / key / query backward; 3 = both.
+ * parts bit 2 (with bit 1): FACTORED output -- stop at dkey | dquery ([B,N] each, left in scratch behind the [N,N] dA:
+ * scratch + N*N and scratch + N*N + B*N); dh / dwk / dwq are not touched (may be NULL).  In the model
+ * dh[s][b][i] = dkey[b][i] wk[s] + dquery[b][i] wq[s] (models/base_model.py:154-155): stemgnn_gru_bwd_rank2 consumes the two
+ * factors directly, stemgnn_keyquery_wgrad forms dwk / dwq from them off the critical chain. */
 int stemgnn_attn_laplacian_bwd(const float* dL, const float* h, const float* wk, const float* wq,
                                float alpha, float drop_p, int training, const uint64_t* seed,
                                int B, int N, const float* saved, float* scratch, int nchunk,
@@ -154,6 +158,16 @@ int stemgnn_gru_fwd(const float* x, const float* w_ih, const float* w_hh, const 
 int stemgnn_gru_bwd(const float* dh_all, const float* x, const float* w_hh, const float* h_ext,
                     const float* reserve, int B, int S, int Hd, int W, float* scratch,
                     float* dw_ih, float* dw_hh, float* db_ih, float* db_hh, int* status, void* stream);
+
+/* dwk[s] = sum_{b,i} dkey[b,i] h[s,b,i] (dwq likewise) from the factors a parts | 4 call of stemgnn_attn_laplacian_bwd left
+ * in `attn_scratch`. */
+int stemgnn_keyquery_wgrad(const float* h, const float* attn_scratch, float* dwk, float* dwq, int B, int N, void* stream);
+/* stemgnn_gru_bwd with the output gradient given as the rank-2 form dh[s][b][i] = dkey[b][i] wk[s] + dquery[b][i] wq[s]
+ * (dkey, dquery [B,Hd]; wk, wq [S]); only where stemgnn_gru_bwd_rank2_ok(B, Hd) (the wave-specialised per-row clusters). */
+int stemgnn_gru_bwd_rank2_ok(int B, int Hd);
+int stemgnn_gru_bwd_rank2(const float* dkey, const float* dquery, const float* wk, const float* wq, const float* x,
+                          const float* w_hh, const float* h_ext, const float* reserve, int B, int S, int Hd, int W,
+                          float* scratch, float* dw_ih, float* dw_hh, float* db_ih, float* db_hh, int* status, void* stream);
 
 /* ---- weight packing (per StockBlock, once per optimizer step) -----------------------------------
  * Folds the length-W DFT (:49-51) into the first GLU layer, drops the dead C2R bins,

@@ -196,6 +196,7 @@ class Model(nn.Module):
         else:                                                      # persistent HIP recurrence (csrc/gru.hip)
             g = self.GRU
             h = GruFront.apply(x, g.weight_ih_l0, g.weight_hh_l0, g.bias_ih_l0, g.bias_hh_l0, hs)
+            hs.gru_front_live = True       # SpectralHotPath may hand GruFront.backward a factored gradient (ops.py)
         if use_drop and seed is None:
             seed = self._next_seed(x.device)
         params = blocks[0] + blocks[1]

@@ -508,10 +508,12 @@ extern "C" int stemgnn_spectral_glu_fwd(const float* packed, float* saved, int B
   // (read per call, so a test can compare the two on the same buffers).
   const GfGeom gg = gf_geom(d);
   const char* ef = getenv("STEMGNN_GLU_FUSED");
-  if (gg.ok && !(ef && atoi(ef) == 0) && (((uintptr_t)packed) & 15) == 0) {
+  const int fmode = ef ? atoi(ef) : 1;                  // 0 off, 1 auto, 2 / 3: force 64- / 96-row workgroups (tests)
+  if (gg.ok && fmode != 0 && (((uintptr_t)packed) & 15) == 0) {
+    const int mt = fmode == 3 && gg.ok3 ? 3 : (fmode == 2 ? 2 : gf_pick_mt(d.M, sg_num_cus(), gg.ok3));
     GfArgs a;
     a.G = saved + S.G; a.KG = d.KG; a.KP0 = gg.kp[0]; a.KA = gg.KA; a.M = d.M; a.ns = gg.ns;
-    a.nrb = (d.M + GF_BM - 1) / GF_BM;
+    a.nrb = (d.M + 32 * mt - 1) / (32 * mt);
     for (int l = 0; l < 3; ++l) {
       a.nst[l] = gg.nst[l];
       for (int r = 0; r < 2; ++r) {
@@ -523,15 +525,22 @@ extern "C" int stemgnn_spectral_glu_fwd(const float* packed, float* saved, int B
     }
     for (int r = 0; r < 2; ++r) a.wf[r] = packed + P.wfused[r];
     const dim3 grid(8 * ((a.nrb + 3) / 4));
-    static SgDynLds guard[3];
-#define GF_LAUNCH(H01, H2, GI)                                                                              \
+    const size_t lds = mt == 3 ? gg.lds_bytes3 : gg.lds_bytes;
+    static SgDynLds guard[6];
+#define GF_LAUNCH(MT_, H01, H2, GI)                                                                          \
     do {                                                                                                    \
-      SG_TRY(sg_ensure_dyn_lds((const void*)sg_glu_fused_fwd_kernel<H01, H2>, gg.lds_bytes, guard[GI]));     \
-      hipLaunchKernelGGL((sg_glu_fused_fwd_kernel<H01, H2>), grid, dim3(256), gg.lds_bytes, st, a);          \
+      SG_TRY(sg_ensure_dyn_lds((const void*)sg_glu_fused_fwd_kernel<MT_, H01, H2>, lds, guard[GI]));         \
+      hipLaunchKernelGGL((sg_glu_fused_fwd_kernel<MT_, H01, H2>), grid, dim3(256), lds, st, a);              \
     } while (0)
-    if (gg.hp[0] == 1) GF_LAUNCH(1, 1, 0);
-    else if (gg.hp[2] == 1) GF_LAUNCH(2, 1, 1);
-    else GF_LAUNCH(2, 2, 2);
+    if (mt == 3) {
+      if (gg.hp[0] == 1) GF_LAUNCH(3, 1, 1, 3);
+      else if (gg.hp[2] == 1) GF_LAUNCH(3, 2, 1, 4);
+      else GF_LAUNCH(3, 2, 2, 5);
+    } else {
+      if (gg.hp[0] == 1) GF_LAUNCH(2, 1, 1, 0);
+      else if (gg.hp[2] == 1) GF_LAUNCH(2, 2, 1, 1);
+      else GF_LAUNCH(2, 2, 2, 2);
+    }
 #undef GF_LAUNCH
     SG_TRY(hipGetLastError());
     return 0;
@@ -726,11 +735,13 @@ extern "C" int stemgnn_spectral_glu_bwd(const float* packed, const float* saved,
   // per-layer launches and the GluDgrad0Op product.
   const GdGeom gdg = gd_geom(d);
   const char* efd = getenv("STEMGNN_GLU_FUSED");
-  const bool fused_dgrad = (parts & 1) && gdg.ok && !(efd && atoi(efd) == 0) && (((uintptr_t)packed) & 15) == 0 &&
+  const int dmode = efd ? atoi(efd) : 1;                // 0 off, 1 auto, 2 / 3: force 64- / 96-row workgroups (tests)
+  const bool fused_dgrad = (parts & 1) && gdg.ok && dmode != 0 && (((uintptr_t)packed) & 15) == 0 &&
                            (((uintptr_t)scratch) & 15) == 0;
   if (fused_dgrad) {
+    const int mt = dmode == 3 && gdg.ok3 ? 3 : (dmode == 2 ? 2 : gf_pick_mt(d.M, sg_num_cus(), gdg.ok3));
     GdArgs a;
-    a.CP = d.CP; a.KG = d.KG; a.M = d.M; a.KA = gdg.KA; a.nrb = (d.M + GF_BM - 1) / GF_BM;
+    a.CP = d.CP; a.KG = d.KG; a.M = d.M; a.KA = gdg.KA; a.nrb = (d.M + 32 * mt - 1) / (32 * mt);
     for (int p = 0; p < 2; ++p) { a.nstB[p] = gdg.nstB[p]; a.nstC[p] = gdg.nstC[p]; }
     for (int r = 0; r < 2; ++r) {
       a.dact2[r] = scratch + C.dact[r][2]; a.np2[r] = sg_glu_np(d, 2, r);
@@ -742,14 +753,16 @@ extern "C" int stemgnn_spectral_glu_bwd(const float* packed, const float* saved,
       a.nstA[r] = gdg.nstA[r]; a.ns[r] = gdg.ns[r];
     }
     const dim3 grid(8 * ((a.nrb + 3) / 4));
-    static SgDynLds guard[2];
-    if (gdg.nt == 2) {
-      SG_TRY(sg_ensure_dyn_lds((const void*)sg_glu_fused_dgrad_kernel<2>, gdg.lds_bytes, guard[1]));
-      hipLaunchKernelGGL((sg_glu_fused_dgrad_kernel<2>), grid, dim3(256), gdg.lds_bytes, st, a);
-    } else {
-      SG_TRY(sg_ensure_dyn_lds((const void*)sg_glu_fused_dgrad_kernel<1>, gdg.lds_bytes, guard[0]));
-      hipLaunchKernelGGL((sg_glu_fused_dgrad_kernel<1>), grid, dim3(256), gdg.lds_bytes, st, a);
-    }
+    const size_t lds = mt == 3 ? gdg.lds_bytes3 : gdg.lds_bytes;
+    static SgDynLds guard[4];
+#define GD_LAUNCH(MT_, NT_, GI)                                                                            \
+    do {                                                                                                  \
+      SG_TRY(sg_ensure_dyn_lds((const void*)sg_glu_fused_dgrad_kernel<MT_, NT_>, lds, guard[GI]));         \
+      hipLaunchKernelGGL((sg_glu_fused_dgrad_kernel<MT_, NT_>), grid, dim3(256), lds, st, a);              \
+    } while (0)
+    if (mt == 3) { if (gdg.nt == 2) GD_LAUNCH(3, 2, 3); else GD_LAUNCH(3, 1, 2); }
+    else { if (gdg.nt == 2) GD_LAUNCH(2, 2, 1); else GD_LAUNCH(2, 1, 0); }
+#undef GD_LAUNCH
     SG_TRY(hipGetLastError());
   }
   for (int l = 2; l >= 0; --l) {

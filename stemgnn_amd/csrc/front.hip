@@ -405,6 +405,31 @@ __global__ __launch_bounds__(256) void sg_keyquery_bwd_kernel(const float* __res
   }
 }
 
+// dwk[s] = sum_{b,i} dkey[b,i] h[s,b,i], dwq likewise -- the parameter-gradient half of sg_keyquery_bwd_kernel, for callers
+// that hand the GRU backward dkey / dquery instead of the materialised dh (stemgnn_gru_bwd_rank2): off the critical chain
+__global__ __launch_bounds__(256) void sg_keyquery_wgrad_kernel(const float* __restrict__ h, const float* __restrict__ dkey,
+                                                                const float* __restrict__ dquery, float* __restrict__ dwk,
+                                                                float* __restrict__ dwq, int B, int N) {
+  __shared__ float red[4][2];
+  const int s = blockIdx.x;
+  const size_t BN = (size_t)B * N;
+  float ak = 0.f, aq = 0.f;
+  for (size_t e = threadIdx.x; e < BN; e += 256) {
+    const float hv = h[(size_t)s * BN + e];
+    ak = fmaf(dkey[e], hv, ak);
+    aq = fmaf(dquery[e], hv, aq);
+  }
+  ak = sg_wave_sum(ak);
+  aq = sg_wave_sum(aq);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) { red[wave][0] = ak; red[wave][1] = aq; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    dwk[s] = (red[0][0] + red[1][0]) + (red[2][0] + red[3][0]);
+    dwq[s] = (red[0][1] + red[1][1]) + (red[2][1] + red[3][1]);
+  }
+}
+
 __global__ void sg_dropout_mask_kernel(float drop_p, const uint64_t* __restrict__ seedp, size_t n, float* __restrict__ mask) {
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= n) return;
@@ -526,8 +551,9 @@ extern "C" int stemgnn_attn_laplacian_bwd(const float* dL, const float* h, const
                                           float alpha, float drop_p, int training, const uint64_t* seed, int B, int N,
                                           const float* saved, float* scratch, int nchunk, float* dh, float* dwk,
                                           float* dwq, int parts, void* stream) {
-  if (!dL || !h || !wk || !wq || !saved || !scratch || !dh || !dwk || !dwq || B <= 0 || N <= 0 || nchunk <= 0 ||
-      (parts & 3) == 0)
+  const bool factored = (parts & 4) != 0;       // stop at dkey / dquery: no dh, dwk, dwq (-> stemgnn_keyquery_wgrad)
+  if (!dL || !h || !wk || !wq || !saved || !scratch || ((parts & 2) && !factored && (!dh || !dwk || !dwq)) || B <= 0 ||
+      N <= 0 || nchunk <= 0 || (parts & 3) == 0)
     return SG_EINVAL;
   if (training && drop_p > 0.f && !seed) return SG_EINVAL;
   hipStream_t st = (hipStream_t)stream;
@@ -557,7 +583,18 @@ extern "C" int stemgnn_attn_laplacian_bwd(const float* dL, const float* h, const
                        N, nchunk);
     SG_TRY(hipGetLastError());
   }
+  if (factored) return 0;
   hipLaunchKernelGGL(sg_keyquery_bwd_kernel, dim3(N), dim3(256), 0, st, h, wk, wq, dkey, dquery, dh, dwk, dwq, B, N);
+  SG_TRY(hipGetLastError());
+  return 0;
+}
+
+extern "C" int stemgnn_keyquery_wgrad(const float* h, const float* attn_scratch, float* dwk, float* dwq, int B, int N,
+                                      void* stream) {
+  if (!h || !attn_scratch || !dwk || !dwq || B <= 0 || N <= 0) return SG_EINVAL;
+  const float* dkey = attn_scratch + (size_t)N * N;
+  hipLaunchKernelGGL(sg_keyquery_wgrad_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, h, dkey, dkey + (size_t)B * N, dwk,
+                     dwq, B, N);
   SG_TRY(hipGetLastError());
   return 0;
 }

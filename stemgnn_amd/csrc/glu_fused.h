@@ -24,6 +24,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "gemm2.h"
 #include "layout.h"
 
@@ -82,7 +84,7 @@ __device__ __forceinline__ void gf_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)
 struct GfRing {
   const float* src;
   float* ring;
-  int next, last, wbuf, wave;
+  int next, last, wbuf, wave, nstages;
   __device__ __forceinline__ void issue(int q) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + q * 256),
                                      (__attribute__((address_space(3))) void*)(ring + wbuf * GF_STAGE + (wave * GF_NI + q) * 256),
@@ -92,95 +94,112 @@ struct GfRing {
   __device__ __forceinline__ void advance() {
     if (next < last) src += GF_STAGE;
     ++next;
-    wbuf = wbuf + 1 == GF_STAGES ? 0 : wbuf + 1;
+    wbuf = wbuf + 1 == nstages ? 0 : wbuf + 1;
   }
 };
 
+// Row tiles of a workgroup (MT = 2: 64 rows, MT = 3: 96 rows -- the latter when 64-row blocks would need a second, mostly
+// empty round of workgroups, e.g. M = 11456 at PEMS03: 358 blocks on 256 CUs -> 240 blocks of 96).  Tiles 0 and 1 are
+// interleaved in block rows 0..63 (tile i, tile row r = block row 2 r + i: one 8-byte LDS read feeds both), tile 2 is block
+// rows 64..95.  LDS row stride of the K-major operand buffer: 32 MT + 2 floats (conflict-free 8-byte epilogue writes).
+template <int MT>
+struct GfTile {
+  static constexpr int BM = 32 * MT, LDA = 32 * MT + 2;
+  static constexpr int STAGES = MT == 3 ? 4 : 5;        // ring depth the LDS leaves room for (MT = 3: 94 KB of operand)
+  static __device__ __forceinline__ int row(int i, int reg, int lane) {
+    return i < 2 ? 2 * g2_row_of(reg, lane) + i : 64 + g2_row_of(reg, lane);
+  }
+};
 // One ring stage of MFMA work (16 / HP weight rows = 8 / HP k-steps) with the next ring stage's DMA pieces issued from
 // inside it.  The fragment reads go through __restrict__ pointers: that gives them alias-scope metadata, without which
 // hipcc's waitcnt pass assumes every LDS read may alias the LDS-DMA in flight and drains the ring (vmcnt(0)) per k-step.
-template <int HP>
-__device__ __forceinline__ void gf_stage(const float* __restrict__ Aq, const float* __restrict__ Bs,
-                                         sg_f32x16 (&acc)[2][HP][2], GfRing& rg) {
-  constexpr int NC = 256 * HP, RS = 16 / HP, STEPS = RS / 2;
+// Aq points at (row k0 + fk, column 2 fi) of the operand buffer; A2 at (row k0 + fk, column 64 + fi) (MT = 3 only).
+template <int MT, int HP>
+__device__ __forceinline__ void gf_stage(const float* __restrict__ Aq, const float* __restrict__ A2,
+                                         const float* __restrict__ Bs, sg_f32x16 (&acc)[MT][HP][2], GfRing& rg) {
+  constexpr int NC = 256 * HP, RS = 16 / HP, STEPS = RS / 2, LDA = GfTile<MT>::LDA;
   constexpr int EVERY = STEPS / GF_NI;                 // one DMA piece every EVERY k-steps (1 or 2)
   float2 fa[STEPS], fb[STEPS][HP];
-#pragma unroll
-  for (int st = 0; st < GF_PF && st < STEPS; ++st) {
-    fa[st] = *reinterpret_cast<const float2*>(Aq + 2 * st * GF_LDA);
+  float fc[STEPS];
+  auto rd = [&](int st) {
+    fa[st] = *reinterpret_cast<const float2*>(Aq + 2 * st * LDA);
+    if constexpr (MT == 3) fc[st] = A2[2 * st * LDA];
 #pragma unroll
     for (int h = 0; h < HP; ++h) fb[st][h] = *reinterpret_cast<const float2*>(Bs + 2 * st * NC + h * 64);
-  }
+  };
+#pragma unroll
+  for (int st = 0; st < GF_PF && st < STEPS; ++st) rd(st);
 #pragma unroll
   for (int st = 0; st < STEPS; ++st) {
-    const float a0 = fa[st].x, a1 = fa[st].y;
+    float a[3];
+    a[0] = fa[st].x; a[1] = fa[st].y; a[2] = MT == 3 ? fc[st] : 0.f;
     __builtin_amdgcn_sched_barrier(0);
-    if (!(GF_ABL & 2)) acc[0][0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, fb[st][0].x, acc[0][0][0], 0, 0, 0);
-    if (st + GF_PF < STEPS) {
-      fa[st + GF_PF] = *reinterpret_cast<const float2*>(Aq + 2 * (st + GF_PF) * GF_LDA);
-#pragma unroll
-      for (int h = 0; h < HP; ++h) fb[st + GF_PF][h] = *reinterpret_cast<const float2*>(Bs + 2 * (st + GF_PF) * NC + h * 64);
-    }
+    if (!(GF_ABL & 2)) acc[0][0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], fb[st][0].x, acc[0][0][0], 0, 0, 0);
+    if (st + GF_PF < STEPS) rd(st + GF_PF);
     __builtin_amdgcn_sched_barrier(0);
-    if (!(GF_ABL & 2)) acc[0][0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, fb[st][0].y, acc[0][0][1], 0, 0, 0);
+    if (!(GF_ABL & 2)) acc[0][0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], fb[st][0].y, acc[0][0][1], 0, 0, 0);
     if (!(GF_ABL & 4) && st % EVERY == 0 && st / EVERY < GF_NI) rg.issue(st / EVERY);
     __builtin_amdgcn_sched_barrier(0);
     if (!(GF_ABL & 2)) {
-      acc[1][0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, fb[st][0].x, acc[1][0][0], 0, 0, 0);
-      acc[1][0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, fb[st][0].y, acc[1][0][1], 0, 0, 0);
-      if constexpr (HP == 2) {
-        acc[0][1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, fb[st][1].x, acc[0][1][0], 0, 0, 0);
-        acc[0][1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, fb[st][1].y, acc[0][1][1], 0, 0, 0);
-        acc[1][1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, fb[st][1].x, acc[1][1][0], 0, 0, 0);
-        acc[1][1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, fb[st][1].y, acc[1][1][1], 0, 0, 0);
-      }
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int h = 0; h < HP; ++h) {
+          if (i == 0 && h == 0) continue;
+          acc[i][h][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], fb[st][h].x, acc[i][h][0], 0, 0, 0);
+          acc[i][h][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], fb[st][h].y, acc[i][h][1], 0, 0, 0);
+        }
     }
   }
 }
 
-template <int HP, bool LAST>
+template <int MT, int HP, bool LAST>
 __device__ __forceinline__ void gf_layer(float* As, GfRing& rg, int& rbuf, int nst, int lane, int wave,
                                          const float (&bl)[2], const float (&br)[2], float* __restrict__ outp,
                                          float* __restrict__ gatep, int cp, int M, int m0, int KA) {
-  constexpr int NC = 256 * HP, RS = 16 / HP;
+  using T = GfTile<MT>;
+  constexpr int NC = 256 * HP, RS = 16 / HP, LDA = T::LDA;
   const int fi = lane & 31, fk = lane >> 5;
-  sg_f32x16 acc[2][HP][2];
+  sg_f32x16 acc[MT][HP][2];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < MT; ++i)
 #pragma unroll
     for (int h = 0; h < HP; ++h)
 #pragma unroll
       for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[i][h][t][e] = 0.f;
-  const float* Ap = As + fk * GF_LDA + 2 * fi;
+  const float* Ap = As + fk * LDA + 2 * fi;
+  const float* Ap2 = As + fk * LDA + 64 + fi;
   const int boff = fk * NC + wave * (64 * HP) + 2 * fi;
   for (int s = 0; s < nst; ++s) {
-    gf_wait_vm<(GF_STAGES - 2) * GF_NI>();             // my pieces of this stage have landed
+    gf_wait_vm<(T::STAGES - 2) * GF_NI>();             // my pieces of this stage have landed
     __builtin_amdgcn_s_barrier();                      // everybody's have; the buffer read last stage is free
-    gf_stage<HP>(Ap + (size_t)s * RS * GF_LDA, rg.ring + rbuf * GF_STAGE + boff, acc, rg);
+    gf_stage<MT, HP>(Ap + (size_t)s * RS * LDA, Ap2 + (size_t)s * RS * LDA, rg.ring + rbuf * GF_STAGE + boff, acc, rg);
     rg.advance();
-    rbuf = rbuf + 1 == GF_STAGES ? 0 : rbuf + 1;
+    rbuf = rbuf + 1 == T::STAGES ? 0 : rbuf + 1;
   }
   // ---- epilogue: bias, GLU gating, saved tensors, next layer's input ----------------------------------------------------
   if constexpr (!LAST) __builtin_amdgcn_s_barrier();     // every wave is done reading the activation buffer
-  const bool full = m0 + GF_BM <= M;                     // wave-uniform: only the last row block of a launch is ragged
+  const bool full = m0 + T::BM <= M;                     // wave-uniform: only the last row block of a launch is ragged
 #pragma unroll
   for (int h = 0; h < HP; ++h) {
     const int c = wave * 32 * HP + h * 32 + fi;
     const bool live = c < cp;
-    float o[16][2], gs[16][2];
+    float o[16][MT], gs[16][MT];
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) {
-      const int rl = 2 * g2_row_of(reg, lane);
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
+      for (int i = 0; i < MT; ++i) {
         const float u = acc[i][h][0][reg] + bl[h], v = acc[i][h][1][reg] + br[h];
         gs[reg][i] = (GF_ABL & 8) ? v : gf_sigmoid(v);
         o[reg][i] = u * gs[reg][i];
       }
       if constexpr (!LAST) {
-        if (c < KA) *reinterpret_cast<float2*>(As + c * GF_LDA + rl) = make_float2(o[reg][0], o[reg][1]);
+        if (c < KA) {
+          *reinterpret_cast<float2*>(As + c * LDA + 2 * g2_row_of(reg, lane)) = make_float2(o[reg][0], o[reg][1]);
+          if constexpr (MT == 3) As[c * LDA + 64 + g2_row_of(reg, lane)] = o[reg][2];
+        }
       }
     }
     // saved tensors: ONE lane predicate around the whole store loop (a per-store `row < M` test costs an exec-mask branch
@@ -192,8 +211,8 @@ __device__ __forceinline__ void gf_layer(float* As, GfRing& rg, int& rbuf, int n
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg)
 #pragma unroll
-          for (int i = 0; i < 2; ++i) {
-            const size_t off = (size_t)(2 * g2_row_of(reg, lane) + i) * cp;
+          for (int i = 0; i < MT; ++i) {
+            const size_t off = (size_t)T::row(i, reg, lane) * cp;
             po[off] = o[reg][i];
             pg[off] = gs[reg][i];
           }
@@ -201,8 +220,8 @@ __device__ __forceinline__ void gf_layer(float* As, GfRing& rg, int& rbuf, int n
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg)
 #pragma unroll
-          for (int i = 0; i < 2; ++i) {
-            const int rl = 2 * g2_row_of(reg, lane) + i;
+          for (int i = 0; i < MT; ++i) {
+            const int rl = T::row(i, reg, lane);
             if (m0 + rl < M) {
               po[(size_t)rl * cp] = o[reg][i];
               pg[(size_t)rl * cp] = gs[reg][i];
@@ -213,13 +232,14 @@ __device__ __forceinline__ void gf_layer(float* As, GfRing& rg, int& rbuf, int n
   }
   if constexpr (!LAST) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // published by the next layer's first barrier
   if (GF_ABL & 1) {
-    if (acc[0][0][0][0] + acc[1][HP - 1][1][7] == 1.2345e-30f) As[0] = 1.f;   // keep the accumulators alive
+    if (acc[0][0][0][0] + acc[MT - 1][HP - 1][1][7] == 1.2345e-30f) As[0] = 1.f;   // keep the accumulators alive
   }
 }
 
-template <int HP01, int HP2>
+template <int MT, int HP01, int HP2>
 static __global__ __launch_bounds__(256, 1) void sg_glu_fused_fwd_kernel(const GfArgs g) {
-  extern __shared__ __attribute__((aligned(16))) float gf_lds[];   // ONE array: As[KA][66] then the ring
+  using T = GfTile<MT>;
+  extern __shared__ __attribute__((aligned(16))) float gf_lds[];   // ONE array: As[KA][LDA] then the ring
   float* As = gf_lds;
   const int L = blockIdx.x, xcd = L & 7;
   const int r = (xcd >> 2) & 1, rb = (L >> 3) * 4 + (xcd & 3);      // XCDs 0-3 stream branch 0's weights, 4-7 branch 1's
@@ -227,15 +247,16 @@ static __global__ __launch_bounds__(256, 1) void sg_glu_fused_fwd_kernel(const G
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fi = lane & 31;
-  const int m0 = rb * GF_BM, M = g.M;
+  const int m0 = rb * T::BM, M = g.M;
 
   GfRing rg;
-  rg.ring = gf_lds + (size_t)g.KA * GF_LDA;
+  rg.ring = gf_lds + (size_t)g.KA * T::LDA;
   rg.wave = wave;
+  rg.nstages = T::STAGES;
   rg.src = g.wf[r] + (size_t)wave * GF_NI * 256 + lane * 4;
   rg.next = 0; rg.last = g.ns - 1; rg.wbuf = 0;
 #pragma unroll
-  for (int p = 0; p < GF_STAGES - 1; ++p) {
+  for (int p = 0; p < T::STAGES - 1; ++p) {
 #pragma unroll
     for (int q = 0; q < GF_NI; ++q) rg.issue(q);
     rg.advance();
@@ -256,16 +277,18 @@ static __global__ __launch_bounds__(256, 1) void sg_glu_fused_fwd_kernel(const G
       br[l][h] = ok ? y : 0.f;
     }
   }
-  {  // layer-0 input: the 64 G rows of this block, K-major, rows KG .. KP0-1 zero (they meet zero weight rows)
+  {  // layer-0 input: the G rows of this block, K-major, rows KG .. KP0-1 zero (they meet zero weight rows).  Block row i of
+     // the buffer is series row m0 + i for tiles 0 / 1 interleaved (i < 64) and tile 2 (i >= 64) alike: the MFMA row <-> block
+     // row mapping lives in the fragment reads and the epilogue only
     const int KG = g.KG;
     const float* Gp = g.G + (size_t)m0 * KG;
-    const int nlive = (M - m0 < GF_BM ? M - m0 : GF_BM) * KG;
-    for (int idx = tid; idx < GF_BM * KG; idx += 256) {
+    const int nlive = (M - m0 < T::BM ? M - m0 : T::BM) * KG;
+    for (int idx = tid; idx < T::BM * KG; idx += 256) {
       const int i = idx / KG, k = idx - i * KG;
       const float v = Gp[idx < nlive ? idx : 0];
-      As[k * GF_LDA + i] = idx < nlive ? v : 0.f;
+      As[k * T::LDA + i] = idx < nlive ? v : 0.f;
     }
-    for (int idx = tid; idx < (g.KP0 - KG) * GF_BM; idx += 256) As[(KG + idx / GF_BM) * GF_LDA + (idx % GF_BM)] = 0.f;
+    for (int idx = tid; idx < (g.KP0 - KG) * T::BM; idx += 256) As[(KG + idx / T::BM) * T::LDA + (idx % T::BM)] = 0.f;
   }
   // materialise the biases HERE (the copy loop above has drained the loads anyway): left to the compiler their selects
   // sink to the first epilogue, where the wait for these ordinary loads would drain the ring
@@ -275,9 +298,9 @@ static __global__ __launch_bounds__(256, 1) void sg_glu_fused_fwd_kernel(const G
     for (int h = 0; h < 2; ++h) asm volatile("" : "+v"(bl[l][h]), "+v"(br[l][h]));
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // (the first stage's barrier publishes the buffer)
   int rbuf = 0;
-  gf_layer<HP01, false>(As, rg, rbuf, g.nst[0], lane, wave, bl[0], br[0], g.out[r][0], g.gate[r][0], g.cp[r][0], M, m0, g.KA);
-  gf_layer<HP01, false>(As, rg, rbuf, g.nst[1], lane, wave, bl[1], br[1], g.out[r][1], g.gate[r][1], g.cp[r][1], M, m0, g.KA);
-  gf_layer<HP2, true>(As, rg, rbuf, g.nst[2], lane, wave, bl[2], br[2], g.out[r][2], g.gate[r][2], g.cp[r][2], M, m0, g.KA);
+  gf_layer<MT, HP01, false>(As, rg, rbuf, g.nst[0], lane, wave, bl[0], br[0], g.out[r][0], g.gate[r][0], g.cp[r][0], M, m0, g.KA);
+  gf_layer<MT, HP01, false>(As, rg, rbuf, g.nst[1], lane, wave, bl[1], br[1], g.out[r][1], g.gate[r][1], g.cp[r][1], M, m0, g.KA);
+  gf_layer<MT, HP2, true>(As, rg, rbuf, g.nst[2], lane, wave, bl[2], br[2], g.out[r][2], g.gate[r][2], g.cp[r][2], M, m0, g.KA);
   gf_wait_vm<0>();                                         // the run-ahead DMA pieces must not outlive the workgroup's LDS
 }
 
@@ -364,15 +387,25 @@ struct GdArgs {
   int CP, KG, M, nrb, KA;
 };
 
-template <int NT>
-__device__ __forceinline__ void gd_stage(const float* __restrict__ Aq, const float* __restrict__ Bs, sg_f32x16 (&acc)[2][NT],
-                                         GfRing& rg) {
-  constexpr int NC = 128 * NT, RS = 32 / NT, STEPS = RS / 2;
+// row-tile geometry of the data-gradient kernel: as GfTile, but the 96-row form leaves room for 3 ring stages only (its
+// operand buffer is 256 x 98 floats = 100 KB)
+template <int MT>
+struct GdTile {
+  static constexpr int BM = 32 * MT, LDA = 32 * MT + 2;
+  static constexpr int STAGES = MT == 3 ? 3 : 5;
+};
+
+template <int MT, int NT>
+__device__ __forceinline__ void gd_stage(const float* __restrict__ Aq, const float* __restrict__ A2,
+                                         const float* __restrict__ Bs, sg_f32x16 (&acc)[MT][NT], GfRing& rg) {
+  constexpr int NC = 128 * NT, RS = 32 / NT, STEPS = RS / 2, LDA = GdTile<MT>::LDA;
   constexpr int EVERY = STEPS / GF_NI;                 // one DMA piece every EVERY k-steps (2 or 4)
   float2 fa[STEPS];
+  float fc[STEPS];
   float fb[STEPS][2];
   auto rd = [&](int st) {
-    fa[st] = *reinterpret_cast<const float2*>(Aq + 2 * st * GF_LDA);
+    fa[st] = *reinterpret_cast<const float2*>(Aq + 2 * st * LDA);
+    if constexpr (MT == 3) fc[st] = A2[2 * st * LDA];
     if constexpr (NT == 2) {
       const float2 b = *reinterpret_cast<const float2*>(Bs + 2 * st * NC);
       fb[st][0] = b.x; fb[st][1] = b.y;
@@ -384,97 +417,126 @@ __device__ __forceinline__ void gd_stage(const float* __restrict__ Aq, const flo
   for (int st = 0; st < GF_PF && st < STEPS; ++st) rd(st);
 #pragma unroll
   for (int st = 0; st < STEPS; ++st) {
-    const float a0 = fa[st].x, a1 = fa[st].y;
+    float a[3];
+    a[0] = fa[st].x; a[1] = fa[st].y; a[2] = MT == 3 ? fc[st] : 0.f;
     __builtin_amdgcn_sched_barrier(0);
-    if (!(GF_ABL & 2)) acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, fb[st][0], acc[0][0], 0, 0, 0);
+    if (!(GF_ABL & 2)) acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], fb[st][0], acc[0][0], 0, 0, 0);
     if (st + GF_PF < STEPS) rd(st + GF_PF);
     __builtin_amdgcn_sched_barrier(0);
-    if (!(GF_ABL & 2)) acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, fb[st][0], acc[1][0], 0, 0, 0);
+    if (!(GF_ABL & 2)) acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], fb[st][0], acc[1][0], 0, 0, 0);
     if (!(GF_ABL & 4) && st % EVERY == 0 && st / EVERY < GF_NI) rg.issue(st / EVERY);
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (NT == 2) {
-      if (!(GF_ABL & 2)) {
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, fb[st][1], acc[0][1], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, fb[st][1], acc[1][1], 0, 0, 0);
+    if (!(GF_ABL & 2)) {
+      if constexpr (MT == 3) acc[2][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2], fb[st][0], acc[2][0], 0, 0, 0);
+      if constexpr (NT == 2) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i) acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], fb[st][1], acc[i][1], 0, 0, 0);
       }
     }
   }
 }
 
-// third product (-> dG, 3 W <= 64 columns): the four waves split the 2 x 2 output tiles, one MFMA per k-step; a ring stage
-// holds 64 weight rows x 64 columns = 32 k-steps
-__device__ __forceinline__ void gd_stage_c(const float* __restrict__ Aq, const float* __restrict__ Bs, sg_f32x16& acc,
+// third product (-> dG, 3 W <= 64 columns): the four waves split the 2 x 2 output tiles of block rows 0..63, one MFMA per
+// k-step; with 96-row blocks waves 0 / 1 also take the two tiles of rows 64..95.  A ring stage holds 64 weight rows x 64
+// columns = 32 k-steps
+template <int MT>
+__device__ __forceinline__ void gd_stage_c(const float* __restrict__ Aq, const float* __restrict__ A2,
+                                           const float* __restrict__ Bs, sg_f32x16& acc, sg_f32x16& acc2, bool extra,
                                            GfRing& rg) {
-  constexpr int STEPS = 32, EVERY = STEPS / GF_NI, PF = 4;
-  float fa[STEPS], fb[STEPS];
+  constexpr int STEPS = 32, EVERY = STEPS / GF_NI, PF = 4, LDA = GdTile<MT>::LDA;
+  float fa[STEPS], fb[STEPS], fc[STEPS];
+  auto rd = [&](int st) {
+    fa[st] = Aq[2 * st * LDA];
+    fb[st] = Bs[2 * st * 64];
+    if constexpr (MT == 3) fc[st] = A2[2 * st * LDA];
+  };
 #pragma unroll
-  for (int st = 0; st < PF; ++st) { fa[st] = Aq[2 * st * GF_LDA]; fb[st] = Bs[2 * st * 64]; }
+  for (int st = 0; st < PF; ++st) rd(st);
 #pragma unroll
   for (int st = 0; st < STEPS; ++st) {
     __builtin_amdgcn_sched_barrier(0);
     if (!(GF_ABL & 2)) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[st], fb[st], acc, 0, 0, 0);
-    if (st + PF < STEPS) { fa[st + PF] = Aq[2 * (st + PF) * GF_LDA]; fb[st + PF] = Bs[2 * (st + PF) * 64]; }
+    if constexpr (MT == 3) {
+      if (extra && !(GF_ABL & 2)) acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(fc[st], fb[st], acc2, 0, 0, 0);   // wave-uniform
+    }
+    if (st + PF < STEPS) rd(st + PF);
     if (!(GF_ABL & 4) && st % EVERY == 0 && st / EVERY < GF_NI) rg.issue(st / EVERY);
   }
 }
-__device__ __forceinline__ void gd_kloop_c(const float* As, GfRing& rg, int& rbuf, int nst, int lane, int wave, sg_f32x16& acc) {
+template <int MT>
+__device__ __forceinline__ void gd_kloop_c(const float* As, GfRing& rg, int& rbuf, int nst, int lane, int wave, sg_f32x16& acc,
+                                           sg_f32x16& acc2) {
+  using T = GdTile<MT>;
   const int fi = lane & 31, fk = lane >> 5, mi = wave >> 1, nj = wave & 1;
-  const float* Ap = As + fk * GF_LDA + 2 * fi + mi;          // row tile mi = block rows 2 r + mi (interleaved, as everywhere)
+  const float* Ap = As + fk * T::LDA + 2 * fi + mi;          // row tile mi = block rows 2 r + mi (interleaved, as everywhere)
+  const float* Ap2 = As + fk * T::LDA + 64 + fi;             // row tile 2 = block rows 64 + r
   const int boff = fk * 64 + nj * 32 + fi;
   for (int s = 0; s < nst; ++s) {
-    gf_wait_vm<(GF_STAGES - 2) * GF_NI>();
+    gf_wait_vm<(T::STAGES - 2) * GF_NI>();
     __builtin_amdgcn_s_barrier();
-    gd_stage_c(Ap + (size_t)s * 64 * GF_LDA, rg.ring + rbuf * GF_STAGE + boff, acc, rg);
+    gd_stage_c<MT>(Ap + (size_t)s * 64 * T::LDA, Ap2 + (size_t)s * 64 * T::LDA, rg.ring + rbuf * GF_STAGE + boff, acc, acc2,
+                   mi == 0, rg);
     rg.advance();
-    rbuf = rbuf + 1 == GF_STAGES ? 0 : rbuf + 1;
+    rbuf = rbuf + 1 == T::STAGES ? 0 : rbuf + 1;
   }
 }
 
-// Saved out / gate values one epilogue tile needs: 32 rows x 1 channel per lane and tensor.  They are requested in GD_NB
+// Saved out / gate values one epilogue tile needs: 32 MT rows x 1 channel per lane and tensor.  They are requested in GD_NB
 // batches from inside the LAST GD_NB stages of the K loop that precedes the epilogue (gd_kloop), so their HBM latency hides
 // under MFMA work instead of standing in front of every epilogue (measured: ~3 us per tile, 4 tiles per workgroup).  A batch
 // must have landed by the next stage's counted wait (vmcnt retires in order), which a stage's 2048 MFMA cycles cover.
-constexpr int GD_NB = 8;              // batches (= stages) a tile's 64 loads are spread over
+constexpr int GD_NB = 8;              // batches (= stages) a tile's loads are spread over
+template <int MT>
 struct GdSaved {
-  float y[16][2], g[16][2];
+  float y[16][MT], g[16][MT];
 };
-template <int NT, int J>
-__device__ __forceinline__ void gd_load_batch(GdSaved& sv, int b, const float* __restrict__ y, const float* __restrict__ gt,
+// Buffer loads: ONE per-lane byte offset (row part that depends on the lane + channel) and a SCALAR offset per (register,
+// tile) -- 64-bit per-element addresses cost two VGPRs each and, hoisted over a batch, pushed the 96-row kernel into
+// scratch (every scratch reload drains the ring).  Rows >= M and dead channels fall outside num_records and read 0.
+template <int MT, int NT, int J>
+__device__ __forceinline__ void gd_load_batch(GdSaved<MT>& sv, int b, const float* __restrict__ y, const float* __restrict__ gt,
                                               int CP, int M, int m0, int lane, int wave) {
-  const int fi = lane & 31;
+  const int fi = lane & 31, fk = lane >> 5;
   const int c = wave * 32 * NT + 32 * J + fi;
-  const bool live = c < CP;
+  const unsigned bytes = (unsigned)((size_t)M * CP * 4);
+  const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(y), 0, bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(gt), 0, bytes, 0x00020000);
+  const int dead = c < CP ? 0 : 0x7fffffff;                                 // out of range -> 0
+  const int v01 = ((m0 + 8 * fk) * CP + c) * 4 | dead, v2 = ((m0 + 64 + 4 * fk) * CP + c) * 4 | dead;
 #pragma unroll
   for (int reg = 0; reg < 16; ++reg) {
     if (reg / (16 / GD_NB) != b) continue;           // (b is a compile-time constant at every call site)
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int row = m0 + 2 * g2_row_of(reg, lane) + i;
-      const size_t o = (size_t)(row < M ? row : 0) * CP + (live ? c : 0);
-      sv.y[reg][i] = y[o];
-      sv.g[reg][i] = gt[o];
+    for (int i = 0; i < MT; ++i) {
+      // block row = [constant part] + [lane part]: tiles 0 / 1: 2 (reg & 3) + 16 (reg >> 2) + i  (+ 8 fk);  tile 2: (reg & 3) + 8 (reg >> 2)  (+ 64 + 4 fk)
+      const int crow = i < 2 ? 2 * (reg & 3) + 16 * (reg >> 2) + i : (reg & 3) + 8 * (reg >> 2);
+      const int so = __builtin_amdgcn_readfirstlane(crow * CP * 4);
+      sv.y[reg][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ry, i < 2 ? v01 : v2, so, 0));
+      sv.g[reg][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rg, i < 2 ? v01 : v2, so, 0));
     }
   }
 }
 
 // K loop of one product (phase).  PJ >= 0: the saved out / gate values of column tile PJ (tensors y / gt) are requested from
 // inside the last GD_NB stages, one batch right behind each stage's barrier (P2 >= 0: a second tile into sv2 likewise).
-template <int NT, int PJ, int P2>
+template <int MT, int NT, int PJ, int P2>
 __device__ __forceinline__ void gd_kloop(const float* As, GfRing& rg, int& rbuf, int nst, int lane, int wave,
-                                         sg_f32x16 (&acc)[2][NT], GdSaved& sv, GdSaved& sv2, const float* __restrict__ y,
-                                         const float* __restrict__ gt, int CP, int M, int m0) {
+                                         sg_f32x16 (&acc)[MT][NT], GdSaved<MT>& sv, GdSaved<MT>& sv2,
+                                         const float* __restrict__ y, const float* __restrict__ gt, int CP, int M, int m0) {
+  using T = GdTile<MT>;
   constexpr int NC = 128 * NT, RS = 32 / NT;
   const int fi = lane & 31, fk = lane >> 5;
-  const float* Ap = As + fk * GF_LDA + 2 * fi;
+  const float* Ap = As + fk * T::LDA + 2 * fi;
+  const float* Ap2 = As + fk * T::LDA + 64 + fi;
   const int boff = fk * NC + (NT == 2 ? wave * 64 + 2 * fi : wave * 32 + fi);
   const int nhead = (PJ >= 0 && nst > GD_NB) ? nst - GD_NB : (PJ >= 0 ? 0 : nst);
   int s = 0;
   for (; s < nhead; ++s) {
-    gf_wait_vm<(GF_STAGES - 2) * GF_NI>();
+    gf_wait_vm<(T::STAGES - 2) * GF_NI>();
     __builtin_amdgcn_s_barrier();
-    gd_stage<NT>(Ap + (size_t)s * RS * GF_LDA, rg.ring + rbuf * GF_STAGE + boff, acc, rg);
+    gd_stage<MT, NT>(Ap + (size_t)s * RS * T::LDA, Ap2 + (size_t)s * RS * T::LDA, rg.ring + rbuf * GF_STAGE + boff, acc, rg);
     rg.advance();
-    rbuf = rbuf + 1 == GF_STAGES ? 0 : rbuf + 1;
+    rbuf = rbuf + 1 == T::STAGES ? 0 : rbuf + 1;
   }
   if constexpr (PJ >= 0) {
     // tail: stage s of the last min(nst, GD_NB) carries batch (GD_NB - (nst - s)); batches a short loop has no stage
@@ -483,15 +545,15 @@ __device__ __forceinline__ void gd_kloop(const float* As, GfRing& rg, int& rbuf,
 #pragma unroll
     for (int b = 0; b < GD_NB; ++b) {
       if (b >= first) {
-        gf_wait_vm<(GF_STAGES - 2) * GF_NI>();
+        gf_wait_vm<(T::STAGES - 2) * GF_NI>();
         __builtin_amdgcn_s_barrier();
       }
-      gd_load_batch<NT, PJ>(sv, b, y, gt, CP, M, m0, lane, wave);
-      if constexpr (P2 >= 0) gd_load_batch<NT, P2>(sv2, b, y, gt, CP, M, m0, lane, wave);
+      gd_load_batch<MT, NT, PJ>(sv, b, y, gt, CP, M, m0, lane, wave);
+      if constexpr (P2 >= 0) gd_load_batch<MT, NT, P2>(sv2, b, y, gt, CP, M, m0, lane, wave);
       if (b >= first) {
-        gd_stage<NT>(Ap + (size_t)s * RS * GF_LDA, rg.ring + rbuf * GF_STAGE + boff, acc, rg);
+        gd_stage<MT, NT>(Ap + (size_t)s * RS * T::LDA, Ap2 + (size_t)s * RS * T::LDA, rg.ring + rbuf * GF_STAGE + boff, acc, rg);
         rg.advance();
-        rbuf = rbuf + 1 == GF_STAGES ? 0 : rbuf + 1;
+        rbuf = rbuf + 1 == T::STAGES ? 0 : rbuf + 1;
         ++s;
       }
     }
@@ -500,77 +562,91 @@ __device__ __forceinline__ void gd_kloop(const float* As, GfRing& rg, int& rbuf,
 
 // GLU backward of column tile J of the accumulators: -> d(pre-activation) of the layer below in HBM (pair order) and, when
 // TO_LDS, into the operand buffer as rows 2 (wave 32 + lane) + t of the coming phase
-template <int NT, int J, bool TO_LDS>
-__device__ __forceinline__ void gd_epilogue(const sg_f32x16 (&acc)[2][NT], float* As, const GdSaved& sv,
+template <int MT, int NT, int J, bool TO_LDS>
+__device__ __forceinline__ void gd_epilogue(const sg_f32x16 (&acc)[MT][NT], float* As, const GdSaved<MT>& sv,
                                             float* __restrict__ dpre, int CP, int M, int m0, int lane, int wave) {
+  using T = GdTile<MT>;
   const int fi = lane & 31;
   const int c = wave * 32 * NT + 32 * J + fi;
   const bool live = c < CP;
   const int q = ((c >> 4) << 5) + (c & 15);
   const int k0 = 2 * (wave * 32 + fi);
-  float left[16][2], right[16][2];
+  // the three products per value are formed twice -- for the LDS rows (every lane) and again inside the store loop (live
+  // lanes) -- rather than kept in 2 x 16 x MT registers across both
+  auto lr = [&](int reg, int i, float& left, float& right) {
+    const float d = acc[i][J][reg];
+    left = d * sv.g[reg][i];
+    right = d * sv.y[reg][i] * (1.f - sv.g[reg][i]);
+  };
+  if constexpr (TO_LDS) {
 #pragma unroll
-  for (int reg = 0; reg < 16; ++reg) {
-    const int rl = 2 * g2_row_of(reg, lane);
+    for (int reg = 0; reg < 16; ++reg) {
+      const int rl = 2 * g2_row_of(reg, lane);
+      float l[3], r[3];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const float d = acc[i][J][reg];
-      left[reg][i] = d * sv.g[reg][i];
-      right[reg][i] = d * sv.y[reg][i] * (1.f - sv.g[reg][i]);
-    }
-    if constexpr (TO_LDS) {
-      *reinterpret_cast<float2*>(As + k0 * GF_LDA + rl) = make_float2(left[reg][0], left[reg][1]);
-      *reinterpret_cast<float2*>(As + (k0 + 1) * GF_LDA + rl) = make_float2(right[reg][0], right[reg][1]);
+      for (int i = 0; i < MT; ++i) lr(reg, i, l[i], r[i]);
+      *reinterpret_cast<float2*>(As + k0 * T::LDA + rl) = make_float2(l[0], l[1]);
+      *reinterpret_cast<float2*>(As + (k0 + 1) * T::LDA + rl) = make_float2(r[0], r[1]);
+      if constexpr (MT == 3) {
+        As[k0 * T::LDA + 64 + g2_row_of(reg, lane)] = l[2];
+        As[(k0 + 1) * T::LDA + 64 + g2_row_of(reg, lane)] = r[2];
+      }
     }
   }
   // ONE lane predicate around the whole store loop: a per-store test puts every store pair into its own basic block, and
   // hipcc then waits vmcnt(0) in each (the prefetched operands look pending at every join) -- the stores serialise
   float* dp = dpre + (size_t)m0 * 2 * CP + q;
-  const bool full = m0 + GF_BM <= M;
+  const bool full = m0 + T::BM <= M;
   if (!(GF_ABL & 1) && live) {
     if (full) {
 #pragma unroll
       for (int reg = 0; reg < 16; ++reg)
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          const size_t off = (size_t)(2 * g2_row_of(reg, lane) + i) * 2 * CP;
-          dp[off] = left[reg][i];
-          dp[off + 16] = right[reg][i];
+        for (int i = 0; i < MT; ++i) {
+          const size_t off = (size_t)GfTile<MT>::row(i, reg, lane) * 2 * CP;
+          float l, r;
+          lr(reg, i, l, r);
+          dp[off] = l;
+          dp[off + 16] = r;
         }
     } else {
 #pragma unroll
       for (int reg = 0; reg < 16; ++reg)
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          const int rl = 2 * g2_row_of(reg, lane) + i;
+        for (int i = 0; i < MT; ++i) {
+          const int rl = GfTile<MT>::row(i, reg, lane);
+          float l, r;
+          lr(reg, i, l, r);
           if (m0 + rl < M) {
-            dp[(size_t)rl * 2 * CP] = left[reg][i];
-            dp[(size_t)rl * 2 * CP + 16] = right[reg][i];
+            dp[(size_t)rl * 2 * CP] = l;
+            dp[(size_t)rl * 2 * CP + 16] = r;
           }
         }
     }
   }
 }
 
-template <int NT>
+template <int MT, int NT>
 static __global__ __launch_bounds__(256, 1) void sg_glu_fused_dgrad_kernel(const GdArgs g) {
-  extern __shared__ __attribute__((aligned(16))) float gf_lds[];   // ONE array: As[KA][66] then the ring
+  using T = GdTile<MT>;
+  extern __shared__ __attribute__((aligned(16))) float gf_lds[];   // ONE array: As[KA][LDA] then the ring
   float* As = gf_lds;
   const int L = blockIdx.x, xcd = L & 7;
   const int r = (xcd >> 2) & 1, rb = (L >> 3) * 4 + (xcd & 3);
   if (rb >= g.nrb) return;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int m0 = rb * GF_BM, M = g.M, CP = g.CP;
+  const int m0 = rb * T::BM, M = g.M, CP = g.CP;
   constexpr int RS = 32 / NT;
 
   GfRing rg;
-  rg.ring = gf_lds + (size_t)g.KA * GF_LDA;
+  rg.ring = gf_lds + (size_t)g.KA * T::LDA;
   rg.wave = wave;
+  rg.nstages = T::STAGES;
   rg.src = g.wd[r] + (size_t)wave * GF_NI * 256 + lane * 4;
   rg.next = 0; rg.last = g.ns[r] - 1; rg.wbuf = 0;
 #pragma unroll
-  for (int p = 0; p < GF_STAGES - 1; ++p) {
+  for (int p = 0; p < T::STAGES - 1; ++p) {
 #pragma unroll
     for (int q = 0; q < GF_NI; ++q) rg.issue(q);
     rg.advance();
@@ -581,61 +657,76 @@ static __global__ __launch_bounds__(256, 1) void sg_glu_fused_dgrad_kernel(const
     // conflicted); the other parity of the quads is the next step, so every 128-byte line is still used in full
     const int np2 = g.np2[r], nq = np2 >> 2;
     const float* src = g.dact2[r] + (size_t)m0 * np2;
-    const int rows = M - m0 < GF_BM ? M - m0 : GF_BM;
+    const int rows = M - m0 < T::BM ? M - m0 : T::BM;
     const int r16 = lane & 15, a4 = lane >> 4;
     const int nkc = (nq + 7) >> 3;                      // chunks of 8 k-quads
-    for (int item = wave; item < 4 * nkc * 2; item += 4) {
+    for (int item = wave; item < (T::BM / 16) * nkc * 2; item += 4) {
       const int par = item & 1, kc = (item >> 1) % nkc, rblk = (item >> 1) / nkc;
       const int i = 16 * rblk + r16, kq = kc * 8 + 2 * a4 + par;
       const bool ok = i < rows && kq < nq;
       const float4 v = *reinterpret_cast<const float4*>(src + (ok ? (size_t)i * np2 + 4 * kq : 0));
       if (kq < nq) {
-        float* d = As + (4 * kq) * GF_LDA + i;
+        float* d = As + (4 * kq) * T::LDA + i;
         d[0] = ok ? v.x : 0.f;
-        d[GF_LDA] = ok ? v.y : 0.f;
-        d[2 * GF_LDA] = ok ? v.z : 0.f;
-        d[3 * GF_LDA] = ok ? v.w : 0.f;
+        d[T::LDA] = ok ? v.y : 0.f;
+        d[2 * T::LDA] = ok ? v.z : 0.f;
+        d[3 * T::LDA] = ok ? v.w : 0.f;
       }
     }
     const int kend = g.nstA[r] * RS;
-    for (int idx = tid; idx < (kend - np2) * GF_BM; idx += 256) As[(np2 + idx / GF_BM) * GF_LDA + (idx % GF_BM)] = 0.f;
+    for (int idx = tid; idx < (kend - np2) * T::BM; idx += 256) As[(np2 + idx / T::BM) * T::LDA + (idx % T::BM)] = 0.f;
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   int rbuf = 0;
-  sg_f32x16 acc1[2][NT], acc0[2][NT];
+  sg_f32x16 acc1[MT][NT], acc0[MT][NT];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < MT; ++i)
 #pragma unroll
     for (int j = 0; j < NT; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) { acc1[i][j][e] = 0.f; acc0[i][j][e] = 0.f; }
-  GdSaved sva, svb;
-  gd_kloop<NT, 0, -1>(As, rg, rbuf, g.nstA[r], lane, wave, acc1, sva, svb, g.out1[r], g.gate1[r], CP, M, m0);   // d(out of layer 1)
+  // The saved out / gate values of the coming epilogue are requested from inside the last stages of the K loop before it
+  // (PRE; `load_now` is the unpipelined form, kept for A/B: ~3 us exposed per epilogue tile).  With buffer loads (one
+  // VGPR of addressing) both forms fit the register file without scratch at 64- and at 96-row blocks.
+  constexpr bool PRE = true;
+  GdSaved<MT> sva, svb;
+  auto load_now = [&](GdSaved<MT>& sv, auto jtag, const float* y, const float* gt) {
+    constexpr int J = decltype(jtag)::value;
+#pragma unroll
+    for (int b = 0; b < GD_NB; ++b) gd_load_batch<MT, NT, J>(sv, b, y, gt, CP, M, m0, lane, wave);
+  };
+  using J0 = std::integral_constant<int, 0>;
+  using J1 = std::integral_constant<int, 1>;
+  gd_kloop<MT, NT, (PRE ? 0 : -1), -1>(As, rg, rbuf, g.nstA[r], lane, wave, acc1, sva, svb, g.out1[r], g.gate1[r], CP, M, m0);   // d(out of layer 1)
+  if constexpr (!PRE) load_now(sva, J0{}, g.out1[r], g.gate1[r]);
   __builtin_amdgcn_s_barrier();                                      // every wave is done reading the operand buffer
-  gd_epilogue<NT, 0, true>(acc1, As, sva, g.dact1[r], CP, M, m0, lane, wave);
+  gd_epilogue<MT, NT, 0, true>(acc1, As, sva, g.dact1[r], CP, M, m0, lane, wave);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   if constexpr (NT == 2) {
-    gd_kloop<NT, 1, -1>(As, rg, rbuf, g.nstB[0], lane, wave, acc0, sva, svb, g.out1[r], g.gate1[r], CP, M, m0);  // phase 0
+    gd_kloop<MT, NT, (PRE ? 1 : -1), -1>(As, rg, rbuf, g.nstB[0], lane, wave, acc0, sva, svb, g.out1[r], g.gate1[r], CP, M, m0);  // phase 0
+    if constexpr (!PRE) load_now(sva, J1{}, g.out1[r], g.gate1[r]);
     __builtin_amdgcn_s_barrier();
-    gd_epilogue<NT, 1, true>(acc1, As, sva, g.dact1[r], CP, M, m0, lane, wave);
+    gd_epilogue<MT, NT, 1, true>(acc1, As, sva, g.dact1[r], CP, M, m0, lane, wave);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    gd_kloop<NT, 0, 1>(As, rg, rbuf, g.nstB[1], lane, wave, acc0, sva, svb, g.out0[r], g.gate0[r], CP, M, m0);   // phase 1
+    gd_kloop<MT, NT, (PRE ? 0 : -1), (PRE ? 1 : -1)>(As, rg, rbuf, g.nstB[1], lane, wave, acc0, sva, svb, g.out0[r], g.gate0[r], CP, M, m0);
   } else {
-    gd_kloop<NT, 0, -1>(As, rg, rbuf, g.nstB[0], lane, wave, acc0, sva, svb, g.out0[r], g.gate0[r], CP, M, m0);
+    gd_kloop<MT, NT, (PRE ? 0 : -1), -1>(As, rg, rbuf, g.nstB[0], lane, wave, acc0, sva, svb, g.out0[r], g.gate0[r], CP, M, m0);
   }
   // third product: d(pre-activation) of layer 0 (stored for the weight gradients, kept in LDS phase by phase) -> dG slab
-  sg_f32x16 accg;
+  sg_f32x16 accg, accg2;
 #pragma unroll
-  for (int e = 0; e < 16; ++e) accg[e] = 0.f;
+  for (int e = 0; e < 16; ++e) { accg[e] = 0.f; accg2[e] = 0.f; }
+  if constexpr (!PRE) load_now(sva, J0{}, g.out0[r], g.gate0[r]);
   __builtin_amdgcn_s_barrier();
-  gd_epilogue<NT, 0, true>(acc0, As, sva, g.dact0[r], CP, M, m0, lane, wave);
+  gd_epilogue<MT, NT, 0, true>(acc0, As, sva, g.dact0[r], CP, M, m0, lane, wave);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  gd_kloop_c(As, rg, rbuf, g.nstC[0], lane, wave, accg);
+  gd_kloop_c<MT>(As, rg, rbuf, g.nstC[0], lane, wave, accg, accg2);
   if constexpr (NT == 2) {
+    if constexpr (!PRE) load_now(sva, J1{}, g.out0[r], g.gate0[r]);
     __builtin_amdgcn_s_barrier();
-    gd_epilogue<NT, 1, true>(acc0, As, svb, g.dact0[r], CP, M, m0, lane, wave);
+    gd_epilogue<MT, NT, 1, true>(acc0, As, (PRE ? svb : sva), g.dact0[r], CP, M, m0, lane, wave);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    gd_kloop_c(As, rg, rbuf, g.nstC[1], lane, wave, accg);
+    gd_kloop_c<MT>(As, rg, rbuf, g.nstC[1], lane, wave, accg, accg2);
   }
   {
     const int kin = (wave & 1) * 32 + (lane & 31), mi = wave >> 1;
@@ -645,6 +736,10 @@ static __global__ __launch_bounds__(256, 1) void sg_glu_fused_dgrad_kernel(const
       for (int reg = 0; reg < 16; ++reg) {
         const int rl = 2 * g2_row_of(reg, lane) + mi;
         if (m0 + rl < M) pg[(size_t)rl * g.KG] = accg[reg];
+        if constexpr (MT == 3) {
+          const int r2 = 64 + g2_row_of(reg, lane);
+          if (mi == 0 && m0 + r2 < M) pg[(size_t)r2 * g.KG] = accg2[reg];
+        }
       }
     }
   }

@@ -993,10 +993,38 @@ static int gru_wgrad_rows(const float* dgi, const float* dghn, const float* h_ex
   SG_TRY((sg_launch_gemm<GruWihGradOp, 64, 32, false, false, false, 64>(o2, 3 * Hd, W + 1, nsplit, st_ih)));
   return 0;
 }
+// factored output gradient (stemgnn_gru_bwd_rank2): supported by the wave-specialised per-row cluster kernels only
+extern "C" int stemgnn_gru_bwd_rank2_ok(int B, int Hd) {
+  if (B <= 0 || Hd <= 0) return 0;
+  const int P2 = gru_pick_P2(B, Hd);
+  GruWide wide;
+  if (gru_pick_wide(B, Hd, P2, &wide) > 0) return 0;
+  return (P2 >= 1 && P2 <= 4) || P2 == 6;
+}
+static int gru_bwd_impl(const float* dh_all, const float* dkey, const float* dquery, const float* wk, const float* wq,
+                        const float* x, const float* w_hh, const float* h_ext, const float* reserve, int B, int S, int Hd,
+                        int W, float* scratch, float* dw_ih, float* dw_hh, float* db_ih, float* db_hh, int* status,
+                        void* stream);
 extern "C" int stemgnn_gru_bwd(const float* dh_all, const float* x, const float* w_hh, const float* h_ext,
                                const float* reserve, int B, int S, int Hd, int W, float* scratch, float* dw_ih,
                                float* dw_hh, float* db_ih, float* db_hh, int* status, void* stream) {
-  if (!dh_all || !x || !w_hh || !h_ext || !reserve || !scratch || !dw_ih || !dw_hh || !db_ih || !db_hh || !status ||
+  if (!dh_all) return SG_EINVAL;
+  return gru_bwd_impl(dh_all, nullptr, nullptr, nullptr, nullptr, x, w_hh, h_ext, reserve, B, S, Hd, W, scratch, dw_ih, dw_hh,
+                      db_ih, db_hh, status, stream);
+}
+extern "C" int stemgnn_gru_bwd_rank2(const float* dkey, const float* dquery, const float* wk, const float* wq, const float* x,
+                                     const float* w_hh, const float* h_ext, const float* reserve, int B, int S, int Hd, int W,
+                                     float* scratch, float* dw_ih, float* dw_hh, float* db_ih, float* db_hh, int* status,
+                                     void* stream) {
+  if (!dkey || !dquery || !wk || !wq || !stemgnn_gru_bwd_rank2_ok(B, Hd)) return SG_EINVAL;
+  return gru_bwd_impl(nullptr, dkey, dquery, wk, wq, x, w_hh, h_ext, reserve, B, S, Hd, W, scratch, dw_ih, dw_hh, db_ih, db_hh,
+                      status, stream);
+}
+static int gru_bwd_impl(const float* dh_all, const float* dkey, const float* dquery, const float* wk, const float* wq,
+                        const float* x, const float* w_hh, const float* h_ext, const float* reserve, int B, int S, int Hd,
+                        int W, float* scratch, float* dw_ih, float* dw_hh, float* db_ih, float* db_hh, int* status,
+                        void* stream) {
+  if ((!dh_all && !dkey) || !x || !w_hh || !h_ext || !reserve || !scratch || !dw_ih || !dw_hh || !db_ih || !db_hh || !status ||
       B <= 0 || S <= 0 || Hd <= 0 || W <= 0)
     return SG_EINVAL;
   hipStream_t st = (hipStream_t)stream;
@@ -1047,12 +1075,12 @@ extern "C" int stemgnn_gru_bwd(const float* dh_all, const float* x, const float*
       float* ih_slab = fold_ih ? p_ih : nullptr;
 #define GRU_B4K(PP, KK) do { const size_t hog = gru_lds_hog4<PP>((const void*)gru_bwd_cluster4_kernel<PP, KK>); \
     hipLaunchKernelGGL((gru_bwd_cluster4_kernel<PP, KK>), grid, dim3((3 * PP + 2) * 64), hog, st, dh_all, w_hh, h_all, reserve, B, S, \
-                       Hd, xbuf, status, dgi, dghn, xid0, allow_fast, x, ih_slab, W); } while (0)
+                       Hd, xbuf, status, dgi, dghn, xid0, allow_fast, x, ih_slab, W, dkey, dquery, wk, wq); } while (0)
 #define GRU_B4(PP) do { if (KU2 == 32) GRU_B4K(PP, 32); else if (KU2 == 48) GRU_B4K(PP, 48); \
                         else if (KU2 == 58) GRU_B4K(PP, 58); else GRU_B4K(PP, 64); } while (0)
 #define GRU_B46K(KK) do { const size_t hog = gru_lds_hog4<6>((const void*)gru_bwd_cluster4_kernel<6, KK, 2>); \
     hipLaunchKernelGGL((gru_bwd_cluster4_kernel<6, KK, 2>), grid, dim3((3 * 6 / 2 + 2) * 64), hog, st, dh_all, w_hh, h_all, reserve, B, S, \
-                       Hd, xbuf, status, dgi, dghn, xid0, allow_fast, x, ih_slab, W); } while (0)
+                       Hd, xbuf, status, dgi, dghn, xid0, allow_fast, x, ih_slab, W, dkey, dquery, wk, wq); } while (0)
       if (v4 && P2 == 6) {
         if (KU2 <= 58) GRU_B46K(58); else GRU_B46K(64);
       } else if (v4) {

@@ -299,7 +299,12 @@ __global__ __launch_bounds__((3 * P / OW + 2) * 64) void gru_bwd_cluster4_kernel
                                                                             float* __restrict__ dgi, float* __restrict__ dghn,
                                                                             gru_u64* __restrict__ xid, int allow_fast,
                                                                             const float* __restrict__ x, float* __restrict__ ih_slab,
-                                                                            int W) {
+                                                                            int W, const float* __restrict__ dkey,
+                                                                            const float* __restrict__ dquery,
+                                                                            const float* __restrict__ wk, const float* __restrict__ wq) {
+  // dkey != nullptr (round 4): the output gradient arrives FACTORED -- in the model dh[s][b][i] = dkey[b][i] wk[s] +
+  // dquery[b][i] wq[s] (adjoint of key = sum_s h[s] wk[s], models/base_model.py:154-155), so the [S, B, Hd] tensor is never
+  // written or read and the kernel that formed it leaves the backward's critical chain; `dout` is unused then
   static_assert(P % OW == 0 && (OW == 1 || OW == 2), "owner slices per wave");
   constexpr int NMV = 3 * P / OW;
   __shared__ float part[2][NMV][64];
@@ -371,10 +376,12 @@ __global__ __launch_bounds__((3 * P / OW + 2) * 64) void gru_bwd_cluster4_kernel
 #endif
   } else if (wave == NMV + 1) {
     // ---------------- chore wave: inputs of gate(s-1) into bin[(s-1)&1] before B_s; outputs of gate(s+1) to global ----
+    const bool factored = dkey != nullptr;
+    const float dk_own = factored ? dkey[(size_t)b * Hd + gu] : 0.f, dq_own = factored ? dquery[(size_t)b * Hd + gu] : 0.f;
     auto fetch = [&](int t, float (&val)[6]) {
       const size_t rw = (size_t)t * B + b;
       const float* rs = reserve + rw * 4 * Hd + gu;
-      val[0] = dout[rw * Hd + gu];
+      val[0] = factored ? dk_own * wk[t] + dq_own * wq[t] : dout[rw * Hd + gu];      // (wk[t], wq[t]: wave-uniform scalar loads)
       val[1] = rs[0]; val[2] = rs[Hd]; val[3] = rs[2 * Hd]; val[4] = rs[3 * Hd];
       val[5] = t > 0 ? h_all[(rw - B) * Hd + gu] : 0.f;
     };

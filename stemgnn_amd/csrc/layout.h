@@ -73,8 +73,9 @@ struct GfGeom {
   int nst[3];       // stages per layer
   int ns;           // stages per branch
   int KA;           // rows of the activation buffer
-  size_t lds_bytes;
-  bool ok;
+  size_t lds_bytes; // with 64-row workgroups (MT = 2, 5 ring stages)
+  size_t lds_bytes3;// with 96-row workgroups (MT = 3, 4 ring stages); ok3: fits the 160 KB
+  bool ok, ok3;
 };
 SG_HD GfGeom gf_geom(const SgDims& d) {
   GfGeom g;
@@ -95,8 +96,18 @@ SG_HD GfGeom gf_geom(const SgDims& d) {
   }
   g.KA = (g.KA + 1) & ~1;
   g.lds_bytes = ((size_t)g.KA * GF_LDA + (size_t)GF_STAGES * GF_STAGE) * sizeof(float);
+  g.lds_bytes3 = ((size_t)g.KA * 98 + (size_t)4 * GF_STAGE) * sizeof(float);
   g.ok = g.ok && g.lds_bytes <= (size_t)160 * 1024;
+  g.ok3 = g.ok && g.lds_bytes3 <= (size_t)160 * 1024;
   return g;
+}
+// Row tiles per workgroup of a fused launch over M series rows: 64-row blocks (MT = 2) unless they would need a second,
+// mostly empty round of workgroups that 96-row blocks (MT = 3) avoid.  Cost model (measured, us): a workgroup takes
+// ~22 + 21.5 MT, a launch ceil(2 ceil(M / 32 MT) / CUs) rounds of them.
+SG_HD int gf_pick_mt(int M, int cus, bool ok3) {
+  if (!ok3 || cus <= 0) return 2;
+  const int r2 = (2 * ((M + 63) / 64) + cus - 1) / cus, r3 = (2 * ((M + 95) / 96) + cus - 1) / cus;
+  return r3 * (22.0 + 21.5 * 3) < r2 * (22.0 + 21.5 * 2) ? 3 : 2;
 }
 // floats of the fused-order weight stream of one block (both branches)
 SG_HD size_t gf_stream_floats(const SgDims& d) {
@@ -119,8 +130,9 @@ struct GdGeom {
   int nstC[2];          // stages (64 weight rows each, 64 columns) of each phase of the third product (layer 0 -> dG)
   int ns[2];            // stages per branch
   int KA;               // rows of the LDS operand buffer
-  size_t lds_bytes;
-  bool ok;
+  size_t lds_bytes;     // 64-row workgroups, 5 ring stages
+  size_t lds_bytes3;    // 96-row workgroups, 3 ring stages
+  bool ok, ok3;
 };
 SG_HD GdGeom gd_geom(const SgDims& d) {
   GdGeom g;
@@ -144,7 +156,9 @@ SG_HD GdGeom gd_geom(const SgDims& d) {
   for (int r = 0; r < 2; ++r) g.ns[r] = g.nstA[r] + g.nstB[0] + g.nstB[1] + g.nstC[0] + g.nstC[1];
   g.ok = g.ok && d.KG <= 64;                         // the third product's 64 output columns hold the 3 W columns of dG
   g.lds_bytes = ((size_t)g.KA * GF_LDA + (size_t)GF_STAGES * GF_STAGE) * sizeof(float);
+  g.lds_bytes3 = ((size_t)g.KA * 98 + (size_t)3 * GF_STAGE) * sizeof(float);
   g.ok = g.ok && g.lds_bytes <= (size_t)160 * 1024;
+  g.ok3 = g.ok && g.lds_bytes3 <= (size_t)160 * 1024;
   return g;
 }
 

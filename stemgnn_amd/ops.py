@@ -48,6 +48,9 @@ class HotPathState:
         self.fork_event = None       # optional event the next prepack_blocks forks the side stream from
         self.pending = None          # (side stream, keep-alive objects) of weight-gradient work not yet joined
         self.exact_group = None      # data-parallel "exact mode" (SURVEY 8e-ii): (process group, world size) or None
+        self.gru_front_live = False  # set by Model.hot_path when the GRU output it hands to SpectralHotPath came from GruFront
+        self.dh_factors = None       # (attn scratch, B, N, wk, wq): the factored d(loss)/d(GRU output) SpectralHotPath.backward left
+                                     # for GruFront.backward (stemgnn_gru_bwd_rank2) instead of a materialised [N,B,N] tensor
         self.block_grads_hook = None # callable run on the side stream right behind block 1's un-packing (overlap mode): the
                                      # step driver's all-reduce of the block / fc gradient range (engine.TrainStep)
         _states.add(self)
@@ -76,6 +79,7 @@ class HotPathState:
         self.preseed = None
         self.fork_event = None
         self.pending = None
+        self.dh_factors = None
 
 
 _states = weakref.WeakSet()
@@ -268,7 +272,9 @@ class GruFront(torch.autograd.Function):
         B, W, S = x.shape
         Hd = w_hh.shape[1]
         dev, f32 = x.device, torch.float32
-        dh_all = dh_all.contiguous()
+        factors, ctx.state.dh_factors = ctx.state.dh_factors, None
+        if factors is None:
+            dh_all = dh_all.contiguous()
         scratch = torch.empty(lib.stemgnn_gru_bwd_scratch_floats(B, S, Hd, W), device=dev, dtype=f32)
         prm = ctx.gru_params
         direct = ctx.state.direct and all(p.grad is not None and p.grad.is_contiguous() for p in prm)
@@ -278,10 +284,20 @@ class GruFront(torch.autograd.Function):
             dw_ih, dw_hh = torch.empty_like(w_ih), torch.empty_like(w_hh)
             db_ih = torch.empty(3 * Hd, device=dev, dtype=f32)
             db_hh = torch.empty(3 * Hd, device=dev, dtype=f32)
-        _lib.check(lib.stemgnn_gru_bwd(dh_all.data_ptr(), x.data_ptr(), w_hh.data_ptr(), h_ext.data_ptr(),
-                                       reserve.data_ptr(), B, S, Hd, W, scratch.data_ptr(), dw_ih.data_ptr(),
-                                       dw_hh.data_ptr(), db_ih.data_ptr(), db_hh.data_ptr(),
-                                       gru_status(dev).data_ptr(), _stream()), "gru_bwd")
+        if factors is not None:
+            # SpectralHotPath.backward stopped at dkey | dquery: dh[s,b,i] = dkey[b,i] wk[s] + dquery[b,i] wq[s] is formed
+            # inside the recurrence (the [N,B,N] gradient tensor is never written; `dh_all` is a zero-stride placeholder)
+            attn_scratch, fb, fn, wk, wq = factors
+            base = attn_scratch.data_ptr() + 4 * fn * fn
+            _lib.check(lib.stemgnn_gru_bwd_rank2(base, base + 4 * fb * fn, wk.data_ptr(), wq.data_ptr(), x.data_ptr(),
+                                                 w_hh.data_ptr(), h_ext.data_ptr(), reserve.data_ptr(), B, S, Hd, W,
+                                                 scratch.data_ptr(), dw_ih.data_ptr(), dw_hh.data_ptr(), db_ih.data_ptr(),
+                                                 db_hh.data_ptr(), gru_status(dev).data_ptr(), _stream()), "gru_bwd_rank2")
+        else:
+            _lib.check(lib.stemgnn_gru_bwd(dh_all.data_ptr(), x.data_ptr(), w_hh.data_ptr(), h_ext.data_ptr(),
+                                           reserve.data_ptr(), B, S, Hd, W, scratch.data_ptr(), dw_ih.data_ptr(),
+                                           dw_hh.data_ptr(), db_ih.data_ptr(), db_hh.data_ptr(),
+                                           gru_status(dev).data_ptr(), _stream()), "gru_bwd")
         ctx.state.join()                # the spectral blocks' weight gradients (side stream) overlapped this recurrence
         if direct:
             return None, None, None, None, None, None
@@ -573,6 +589,9 @@ class SpectralHotPath(torch.autograd.Function):
     def forward(ctx, h, x, wk, wq, multi, alpha, drop_p, training, seed, state, *block_params):
         lib = _lib.load()
         state = ctx.state = _state(state)
+        # `h` came from ops.GruFront of the same model (Model.hot_path says so through the state): the backward may hand
+        # the GRU its output gradient in factored form instead of materialising [N,B,N]
+        ctx.factored, state.gru_front_live = bool(getattr(state, "gru_front_live", False)), False
         for name, t in (("gru output", h), ("x", x), ("weight_key", wk), ("weight_query", wq)):
             _require_gpu(t, name)
         assert len(block_params) == 2 * _lib.SG_BLOCK_NPARAMS
@@ -787,7 +806,11 @@ class SpectralHotPath(torch.autograd.Function):
         cheb_scratch = torch.empty(2 * N * N, device=dev, dtype=f32)
         _lib.check(lib.stemgnn_cheb_bwd(mul_L.data_ptr(), dmul_L.data_ptr(), dL.data_ptr(), cheb_scratch.data_ptr(),
                                         N, st), "cheb_bwd")
-        dh = torch.empty_like(h)
+        # factored: dh[s,b,i] = dkey[b,i] wk[s] + dquery[b,i] wq[s] goes to the GRU backward as its two [B,N] factors
+        # (stemgnn_gru_bwd_rank2); the kernel that would materialise the 6.6 MB tensor (and form dwk / dwq on the way) leaves
+        # the critical chain, dwk / dwq come from a small kernel of their own on the side stream
+        factored = ctx.factored and ctx.needs_input_grad[0] and bool(lib.stemgnn_gru_bwd_rank2_ok(B, N))
+        dh = torch.empty(1, device=dev, dtype=f32).expand(N, B, N) if factored else torch.empty_like(h)   # placeholder: never read
         kq_direct = state.direct and wk.grad is not None and wq.grad is not None
         dwk = wk.grad if kq_direct else torch.empty_like(wk)
         dwq = wq.grad if kq_direct else torch.empty_like(wq)
@@ -800,9 +823,21 @@ class SpectralHotPath(torch.autograd.Function):
             _lib.check(lib.stemgnn_attn_laplacian_bwd(
                 dL.data_ptr(), h.data_ptr(), wk.data_ptr(), wq.data_ptr(), alpha, drop_p, int(training),
                 seed.data_ptr() if use_drop else None, B, N, attn_saved.data_ptr(), attn_scratch.data_ptr(), _NCHUNK,
-                dh.data_ptr(), dwk.data_ptr(), dwq.data_ptr(), part, st), "attn_laplacian_bwd")
+                None if factored else dh.data_ptr(), dwk.data_ptr(), dwq.data_ptr(),
+                part | (4 if factored and part != 1 else 0), st), "attn_laplacian_bwd")
             if exact is not None and part == 1:
                 _all_reduce_mean(attn_scratch[:N * N], exact)
+        if factored:
+            state.dh_factors = (attn_scratch, B, N, wk, wq)
+            if overlap and kq_direct:       # behind block 1's weight gradients on the side stream, under the GRU recurrence
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    _lib.check(lib.stemgnn_keyquery_wgrad(h.data_ptr(), attn_scratch.data_ptr(), dwk.data_ptr(),
+                                                          dwq.data_ptr(), B, N, side.cuda_stream), "keyquery_wgrad")
+                state.pending[1][0].append((attn_scratch, h))
+            else:
+                _lib.check(lib.stemgnn_keyquery_wgrad(h.data_ptr(), attn_scratch.data_ptr(), dwk.data_ptr(), dwq.data_ptr(),
+                                                      B, N, st), "keyquery_wgrad")
         for s_, i_ in direct_idx:
             grads[s_][i_] = None                  # already in p.grad: nothing for autograd to accumulate
         if kq_direct:

@@ -453,8 +453,8 @@ def test_fused_three_layer_glu_forward_matches_layerwise(shape, monkeypatch):
     G = torch.randn(B * N * 3 * W, device=dev)
     scr0 = torch.randn(n_scr, device=dev) * 0.1            # carries the d(pre-activation) of layer 2, the chain's input
     gp = torch.empty(n_gp, device=dev)
-    outs, scrs = [], []
-    for flag in ("0", "1"):
+    outs, scrs = {}, {}
+    for flag in ("0", "1", "2", "3"):         # per-layer launches | fused, automatic block height | 64-row | 96-row blocks forced
         monkeypatch.setenv("STEMGNN_GLU_FUSED", flag)
         sv = torch.zeros(n_saved, device=dev)
         sv[: G.numel()] = G
@@ -464,15 +464,16 @@ def test_fused_three_layer_glu_forward_matches_layerwise(shape, monkeypatch):
         _lib.check(lib.stemgnn_spectral_glu_bwd(pk.data_ptr(), sv.data_ptr(), scr.data_ptr(), gp.data_ptr(), 32, 1, B, N, W,
                                                 multi, st), "glu_bwd")
         torch.cuda.synchronize()
-        outs.append(sv.clone())
-        scrs.append(scr.clone())
+        outs[flag], scrs[flag] = sv.clone(), scr.clone()
     monkeypatch.delenv("STEMGNN_GLU_FUSED")
-    ref, got = outs
-    assert float(ref[G.numel():].abs().max()) > 0
-    assert torch.equal(got, ref)          # the forward sums every accumulator in the per-layer kernels' order: same bits
-    assert relerr(scrs[1], scrs[0]) < 1e-6 and not torch.equal(scrs[0], scr0)   # phase-ordered reduction: rounding only
+    ref = outs["0"]
+    assert float(ref[G.numel():].abs().max()) > 0 and not torch.equal(scrs["0"], scr0)
     off = lib.stemgnn_scratch_offset_dG(B, N, W, multi)
-    assert relerr(scrs[1][off:off + 2 * B * N * 3 * W], scrs[0][off:off + 2 * B * N * 3 * W]) < 1e-5
+    for flag in ("1", "2", "3"):
+        assert torch.equal(outs[flag], ref), flag   # the forward sums every accumulator in the per-layer kernels' order: same bits
+        assert relerr(scrs[flag], scrs["0"]) < 1e-6, flag                        # phase-ordered reduction: rounding only
+        assert relerr(scrs[flag][off:off + 2 * B * N * 3 * W], scrs["0"][off:off + 2 * B * N * 3 * W]) < 1e-5, flag
+    assert torch.equal(scrs["2"], scrs["3"])        # the block height changes who computes a row, never the arithmetic
 
 
 @pytest.mark.parametrize("lead,cin,cout", [((7296,), 48, 240), ((3, 20), 36, 60), ((5,), 7, 9), ((2, 3, 4), 240, 240)])
