@@ -81,8 +81,8 @@ if mfma:
               f"{(mfma[k][1] / (dn * CLOCK_GHZ * 1024) if dn else 0):.3f} | {(mfma[k][1] / (g / 8 * 1024) if g else 0):.3f} |")
 
 FAMS = {
-    "glu_fwd": lambda k: "GluFwdEpi" in k,
-    "glu_dgrad": lambda k: "GluDpreEpi" in k or "GluDgrad0Op" in k,
+    "glu_fwd": lambda k: "GluFwdEpi" in k or "sg_glu_fused_fwd" in k,            # round 4: one fused launch per block
+    "glu_dgrad": lambda k: "GluDpreEpi" in k or "GluDgrad0Op" in k or "sg_glu_fused_dgrad" in k,
     "glu_wgrad": lambda k: "G2SlabEpi, false, false, true, 128" in k or "G2SlabEpi, false, false, true, 64" in k or "sg_wgrad" in k,
 }
 out = {"source": "rocprofv3 --pmc passes (FETCH_SIZE x 2 gfx950 correction + WRITE_SIZE; SQ_VALU_MFMA_BUSY_CYCLES / (dispatch duration x 2.4 GHz x 1024 SIMDs))"
