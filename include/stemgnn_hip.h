@@ -192,7 +192,8 @@ int stemgnn_block_unpack_grads(const float* gradpart, int nsplit, const float* t
 int stemgnn_gft_fwd(const float* mul_L, const float* X, long xs_b, long xs_n, long xs_t,
                     float* G, int B, int N, int W, void* stream);
 /* dG [2][M,3W]: the two per-branch partial slabs stemgnn_spectral_glu_bwd leaves at stemgnn_scratch_offset_dG (their
- * sum is the gradient; added while loading) -> dX [B,N,W] (may be NULL) and dmul_L[1..3] (+= if accumulate). */
+ * sum is the gradient; added while loading) -> dX [B,N,W] (may be NULL) and dmul_L[1..3] (+= if accumulate; may be NULL: a
+ * caller can run the two products of a block on different streams -- only the data gradient is on the backward's chain). */
 int stemgnn_gft_bwd(const float* mul_L, const float* X, long xs_b, long xs_n, long xs_t,
                     const float* dG, float* dX, float* dmul_L, int accumulate,
                     int B, int N, int W, void* stream);

@@ -477,7 +477,7 @@ extern "C" int stemgnn_gft_fwd(const float* mul_L, const float* X, long xs_b, lo
 extern "C" int stemgnn_gft_bwd(const float* mul_L, const float* X, long xs_b, long xs_n, long xs_t,
                                const float* dG, float* dX, float* dmul_L, int accumulate,
                                int B, int N, int W, void* stream) {
-  if (!mul_L || !X || !dG || !dmul_L || B <= 0 || N <= 0 || W <= 0) return SG_EINVAL;
+  if (!mul_L || !X || !dG || (!dmul_L && !dX) || B <= 0 || N <= 0 || W <= 0) return SG_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   const bool bk128 = N <= 512;
   if (dX) {
@@ -485,6 +485,7 @@ extern "C" int stemgnn_gft_bwd(const float* mul_L, const float* X, long xs_b, lo
     if (bk128) SG_TRY((sg_launch_gemm<GftBwdDxOp, 32, 32, false, false, false, 128, true>(op, N, B * W, 1, st)));
     else SG_TRY((sg_launch_gemm<GftBwdDxOp, 32, 32, false, false, false, 64, true>(op, N, B * W, 1, st)));
   }
+  if (!dmul_L) return 0;                         // data gradient only (the caller runs the dT product elsewhere)
   GftBwdDtOp op{dG, XView{X, xs_b, xs_n, xs_t, N}, dmul_L + (size_t)N * N, B, N, W, accumulate, (size_t)B * N * 3 * W};
   if (bk128) {
     if (xs_t == 1) SG_TRY((sg_launch_gemm<GftBwdDtOp, 32, 32, true, true, false, 128, true>(op, 3 * N, N, 1, st)));

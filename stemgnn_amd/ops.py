@@ -380,10 +380,13 @@ class FcTailMse(torch.autograd.Function):
         if accum is not None and (accum.dtype != torch.float64 or accum.device != dev):
             raise _lib.StemGNNHipError("accum must be a float64 scalar on the forecast's device")
         scratch = torch.empty(lib.stemgnn_fc_tail_train_scratch_floats(B, N, W, H), device=dev, dtype=f32)
+
         _lib.check(lib.stemgnn_fc_tail_train(
             fsum.data_ptr(), target.data_ptr(), w0c.data_ptr(), b0c.data_ptr(), w2c.data_ptr(), b2c.data_ptr(), B, N, W, H,
             scratch.data_ptr(), None, loss.data_ptr(), accum.data_ptr() if accum is not None else None, dfsum.data_ptr(),
             grads[0].data_ptr(), grads[1].data_ptr(), grads[2].data_ptr(), grads[3].data_ptr(), _stream()), "fc_tail_train")
+        # (running the reduction of the per-block partials -- loss, fc gradients: off the backward's chain -- on the side
+        # stream was measured in round 4: no gain, the extra cross-queue edge costs what the 9 us launch returns)
         ctx.direct, ctx.unit_grad = direct, bool(unit_grad)
         ctx.held = (dfsum, None if direct else grads)
         ctx.set_materialize_grads(False)
@@ -797,6 +800,20 @@ class SpectralHotPath(torch.autograd.Function):
             else:
                 wgrad(st, 100)
                 unpack(st)
+            if overlap and s == 1:
+                # block 1: only its data gradient (-> dbackcast) feeds block 0's backward; its share of d(mul_L) is needed by
+                # the Chebyshev backward only, 100+ us later -> side stream, beside block 0's heads / GLU data gradients
+                _lib.check(lib.stemgnn_gft_bwd(mul_L.data_ptr(), X.data_ptr(), sb, sn, stt, dG.data_ptr(),
+                                               dbackcast.data_ptr(), None, 0, B, N, W, st), "gft_bwd dX")
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    _lib.check(lib.stemgnn_gft_bwd(mul_L.data_ptr(), X.data_ptr(), sb, sn, stt, dG.data_ptr(), None,
+                                                   dmul_L.data_ptr(), 0, B, N, W, side.cuda_stream), "gft_bwd dT")
+                    dt1_done = torch.cuda.Event()
+                    dt1_done.record(side)
+                continue
+            if overlap:
+                main.wait_event(dt1_done)             # block 0's product accumulates onto block 1's
             _lib.check(lib.stemgnn_gft_bwd(
                 mul_L.data_ptr(), X.data_ptr(), sb, sn, stt, dG.data_ptr(),
                 dbackcast.data_ptr() if s == 1 else None, dmul_L.data_ptr(), int(s == 0), B, N, W, st), "gft_bwd")
