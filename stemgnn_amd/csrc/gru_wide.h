@@ -26,6 +26,12 @@ typedef unsigned int gw_u4 __attribute__((ext_vector_type(4)));
 constexpr int GW_NW = 8;        // waves per workgroup (each takes a contiguous slice of the reduction)
 constexpr int GW_BP = 16;       // batch columns of one cluster pass = N of the MFMA tile
 constexpr int GW_LD = 17;       // LDS row stride of the partial sums
+#ifndef GW_ROT
+#define GW_ROT 1
+#endif
+#ifndef GW_FS
+#define GW_FS 32                // flag stride in 4-byte words: ONE flag per 128-byte line (round 4).  Packed (32 flags per line,
+#endif                          // rounds 2-3) all ~1600 polling waves of the chip hammered the same 7 lines / memory channels
 
 struct GruWide {
   int U, P, KG, MT, GWf, GWb;   // units per workgroup, workgroups, 16-unit groups, forward M tiles, groups per wave
@@ -45,10 +51,14 @@ __host__ __device__ inline GruWide gru_wide_geom(int Hd, int pmax) {
 __device__ __forceinline__ int gw_slot(int k, int b) {
   return ((((k >> 4) << 6) + ((k & 3) << 4) + b) << 2) + ((k >> 2) & 3);
 }
+#ifndef GW_PRE
+#define GW_PRE 8                // pause (x 64 cycles) ahead of the first look at the flags (0 / 8 / 16 / 32: 4.70 / 4.50 / 4.65 / 5.08 us per step)
+#endif
 __device__ __forceinline__ void gw_wait_flags(const unsigned* flags, int pa, int pb, unsigned want, int lane, int* status) {
+  if (GW_PRE > 0) __builtin_amdgcn_s_sleep(GW_PRE);
   for (int pp = pa + lane; pp <= pb; pp += 64) {
     unsigned spins = 0;
-    while (__hip_atomic_load(flags + pp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+    while (__hip_atomic_load(flags + (size_t)pp * GW_FS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
       __builtin_amdgcn_s_sleep(1);
       if (++spins > (1u << 22)) { atomicExch(status, 1); break; }    // producer not resident / lost: give up, flag it
     }
@@ -65,7 +75,7 @@ __device__ __forceinline__ gw_f4 gw_load(__amdgpu_buffer_rsrc_t r, int group, in
 
 // ---- forward ---------------------------------------------------------------------------------------------------
 // MT = 16-row MFMA tiles covering the 3U gate rows, GW = 16-unit groups per wave (<= GW * 8 * 16 hidden units)
-template <int MT, int GW>
+template <int MT, int GW, bool MASK>
 __global__ __launch_bounds__(GW_NW * 64) void gru_fwd_wide_kernel(
     const float* __restrict__ gi, const float* __restrict__ w_hh, const float* __restrict__ b_hh, int B, int b0, int Bc,
     int S, int Hd, int U, int KG, float* __restrict__ hx, unsigned* __restrict__ flags, int* __restrict__ status,
@@ -78,7 +88,21 @@ __global__ __launch_bounds__(GW_NW * 64) void gru_fwd_wide_kernel(
   const int H3 = 3 * Hd;
   const int G0 = wave * GW, G1 = min(KG, G0 + GW);
   const int ai = lane & 15, ak = lane >> 4;
-  // resident weights: wa[m][4 * g + slot] = W_hh[gate row (16 m + ai)][16 (G0 + g) + 4 slot + ak]
+  // Lanes whose batch column does not exist (lane & 15 >= Bc) are masked out of the payload loads -- ONE exec-mask region per
+  // chunk, not per load -- : the columns of a half-filled batch tile are never written and are not fetched either (half the
+  // all-gather traffic at batch 8: 4.5 -> 3.3 us per forward step at N = 1024).  Their B operands are whatever the registers
+  // hold: an MFMA column only feeds the same output column, and the gate threads never read columns >= Bc.
+  const bool col_live = !MASK || ai < Bc;                   // MASK: instantiated for passes of <= 8 batch columns (forward only:
+                                                            // the backward measured slower with it, 6.5 vs 6.3 ms at N = 1024)
+#if GW_ROT
+  // register slot g of the wave's slice holds group G0 + (g + rot) % GW, rot = workgroup index: the 205 workgroups walk the
+  // same exchange vector every step -- rotated starts keep them off the same cache lines / memory channels at the same time
+  const int rot = p % GW;
+#else
+  const int rot = 0;
+#endif
+  auto grp = [&](int g) { const int x = g + rot; return G0 + (x >= GW ? x - GW : x); };
+  // resident weights: wa[m][4 * g + slot] = W_hh[gate row (16 m + ai)][16 grp(g) + 4 slot + ak]
   // (validity is folded in as a 0/1 FACTOR on a clamped, always-valid address: per-element predicates would keep one
   //  64-bit lane mask per weight alive across the hoisted loads -- hundreds of SGPRs)
   float wa[MT][GW * 4];
@@ -90,8 +114,8 @@ __global__ __launch_bounds__(GW_NW * 64) void gru_fwd_wide_kernel(
     const float* wrow = w_hh + ((size_t)(rv ? g : 0) * Hd + u0 + (rv ? u : 0)) * Hd;
 #pragma unroll
     for (int q = 0; q < GW * 4; ++q) {
-      const int k = 16 * (G0 + (q >> 2)) + 4 * (q & 3) + ak;
-      const float gf = (G0 + (q >> 2)) < G1 ? rvf : 0.f;                        // wave-uniform condition
+      const int k = 16 * grp(q >> 2) + 4 * (q & 3) + ak;
+      const float gf = grp(q >> 2) < G1 ? rvf : 0.f;                            // wave-uniform condition
       wa[m][q] = wrow[min(k, Hd - 1)] * (gf * gw_below(k, Hd));
       if ((q & 7) == 7) __builtin_amdgcn_sched_barrier(0);      // 8 loads in flight at a time: bounded register peak
     }
@@ -134,13 +158,15 @@ __global__ __launch_bounds__(GW_NW * 64) void gru_fwd_wide_kernel(
       constexpr int GW_CH = MT * GW >= 48 ? 2 : 4;
       gw_f4 v[2][GW_CH];
       const __amdgpu_buffer_rsrc_t r = rs[s & 1];
+      if (col_live) {
 #pragma unroll
-      for (int g = 0; g < GW_CH; ++g) v[0][g] = gw_load(r, min(G0 + g, KG - 1), lane);
+        for (int g = 0; g < GW_CH; ++g) v[0][g] = gw_load(r, min(grp(g), KG - 1), lane);
+      }
 #pragma unroll
       for (int c = 0; c < GW / GW_CH; ++c) {
-        if (c + 1 < GW / GW_CH) {
+        if (c + 1 < GW / GW_CH && col_live) {
 #pragma unroll
-          for (int g = 0; g < GW_CH; ++g) v[(c + 1) & 1][g] = gw_load(r, min(G0 + (c + 1) * GW_CH + g, KG - 1), lane);
+          for (int g = 0; g < GW_CH; ++g) v[(c + 1) & 1][g] = gw_load(r, min(grp((c + 1) * GW_CH + g), KG - 1), lane);
         }
 #pragma unroll
         for (int g = 0; g < GW_CH; ++g)
@@ -189,7 +215,7 @@ __global__ __launch_bounds__(GW_NW * 64) void gru_fwd_wide_kernel(
     GW_ACC(c_gate, t3, t2);
     GW_ACC(c_drain, t4, t3);
     GW_ACC(c_sync2, t5, t4);
-    if (tid == 0 && s + 1 < S) __hip_atomic_store(flags + p, (unsigned)(s + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0 && s + 1 < S) __hip_atomic_store(flags + (size_t)p * GW_FS, (unsigned)(s + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (gate) {                                            // saved tensors: off the critical path, after the flag
       float* rsv = reserve + row * 4 * Hd;
       rsv[gu] = r; rsv[Hd + gu] = z; rsv[2 * Hd + gu] = n; rsv[3 * Hd + gu] = g2;
@@ -220,13 +246,20 @@ __global__ __launch_bounds__(GW_NW * 64) void gru_bwd_wide_kernel(
   const int VT = 3 * KG;                                     // virtual groups: V = gate * KG + G
   const int V0 = wave * GW, V1 = min(VT, V0 + GW);
   const int ai = lane & 15, ak = lane >> 4;
+  constexpr bool col_live = true;                            // (no column masking in the backward, see the forward kernel)
+#if GW_ROT
+  const int rot = p % GW;                                    // as in the forward: register slot g holds virtual group vgrp(g)
+#else
+  const int rot = 0;
+#endif
+  auto vgrp = [&](int g) { const int x = g + rot; return V0 + (x >= GW ? x - GW : x); };
   float wa[GW * 4];                                          // wa[4 g + slot] = W_hh[gate row j][own unit u0 + ai]
   {
     const float rvf = ai < un ? 1.f : 0.f;
     const float* wcol = w_hh + u0 + (ai < un ? ai : 0);
 #pragma unroll
     for (int q = 0; q < GW * 4; ++q) {
-      const int V = V0 + (q >> 2), gg = min(V / KG, 2), G = V - gg * KG;       // wave-uniform
+      const int V = vgrp(q >> 2), gg = min(V / KG, 2), G = V - gg * KG;        // wave-uniform
       const int kk = 16 * G + 4 * (q & 3) + ak;
       const float gf = V < V1 ? rvf : 0.f;
       wa[q] = wcol[((size_t)gg * Hd + min(kk, Hd - 1)) * Hd] * (gf * gw_below(kk, Hd));
@@ -285,7 +318,7 @@ __global__ __launch_bounds__(GW_NW * 64) void gru_bwd_wide_kernel(
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (tid == 0 && s > 0) __hip_atomic_store(flags + p, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0 && s > 0) __hip_atomic_store(flags + (size_t)p * GW_FS, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (gate) {
       float* go = dgi + row * H3;
       go[gu] = dr; go[Hd + gu] = dz; go[2 * Hd + gu] = dn;
@@ -307,13 +340,15 @@ __global__ __launch_bounds__(GW_NW * 64) void gru_bwd_wide_kernel(
       gw_f4 v[2][GW_CH];
       gw_f4 acc2 = gw_f4{0.f, 0.f, 0.f, 0.f};                 // two accumulators: 16x16x4 has a 40-cycle dependent latency
       const __amdgpu_buffer_rsrc_t r = rs[tag & 1];
+      if (col_live) {
 #pragma unroll
-      for (int g = 0; g < GW_CH; ++g) v[0][g] = gw_load(r, min(V0 + g, VT - 1), lane);
+        for (int g = 0; g < GW_CH; ++g) v[0][g] = gw_load(r, min(vgrp(g), VT - 1), lane);
+      }
 #pragma unroll
       for (int c = 0; c < GW / GW_CH; ++c) {
-        if (c + 1 < GW / GW_CH) {
+        if (c + 1 < GW / GW_CH && col_live) {
 #pragma unroll
-          for (int g = 0; g < GW_CH; ++g) v[(c + 1) & 1][g] = gw_load(r, min(V0 + (c + 1) * GW_CH + g, VT - 1), lane);
+          for (int g = 0; g < GW_CH; ++g) v[(c + 1) & 1][g] = gw_load(r, min(vgrp((c + 1) * GW_CH + g), VT - 1), lane);
         }
 #pragma unroll
         for (int g = 0; g < GW_CH; ++g) {
@@ -335,7 +370,7 @@ __global__ __launch_bounds__(GW_NW * 64) void gru_bwd_wide_kernel(
 // exchange buffer (floats): 2 parities x 3 KG x 256, then P flag words; sized for the backward (the forward uses a third)
 static inline size_t gru_wide_xbuf_floats(int Hd) {
   const size_t KG = (size_t)(Hd + 15) / 16;
-  return 2 * 3 * KG * 256 + 1024 + 16;
+  return 2 * 3 * KG * 256 + 1024 * GW_FS + 16;
 }
 // 0 = not applicable (template range exceeded); otherwise the number of workgroups
 static inline int gru_wide_plan(int Hd, int pmax, GruWide* out) {
@@ -353,12 +388,14 @@ static inline hipError_t gru_wide_fwd(const float* gi, const float* w_hh, const 
   unsigned* flags = (unsigned*)(xbuf + (size_t)2 * 3 * g.KG * 256);
   for (int b0 = 0; b0 < B; b0 += GW_BP) {
     const int Bc = B - b0 < GW_BP ? B - b0 : GW_BP;
-    hipError_t e = hipMemsetAsync(xbuf, 0, ((size_t)2 * 3 * g.KG * 256 + 1024) * sizeof(float), st);
+    hipError_t e = hipMemsetAsync(xbuf, 0, ((size_t)2 * 3 * g.KG * 256 + (size_t)1024 * GW_FS) * sizeof(float), st);
     if (e != hipSuccess) return e;
-#define GWF(MT_, GW_) hipLaunchKernelGGL((gru_fwd_wide_kernel<MT_, GW_>), dim3(g.P), dim3(GW_NW * 64), 0, st, gi, w_hh, b_hh, \
-                                         B, b0, Bc, S, Hd, g.U, g.KG, hx, flags, status, h_all, reserve)
+#define GWF2(MT_, GW_, MK_) hipLaunchKernelGGL((gru_fwd_wide_kernel<MT_, GW_, MK_>), dim3(g.P), dim3(GW_NW * 64), 0, st, gi, w_hh, \
+                                               b_hh, B, b0, Bc, S, Hd, g.U, g.KG, hx, flags, status, h_all, reserve)
+#define GWF(MT_, GW_) do { if (Bc <= 8) GWF2(MT_, GW_, true); else GWF2(MT_, GW_, false); } while (0)
     if (g.GWf <= 8) { if (g.MT == 1) GWF(1, 8); else if (g.MT == 2) GWF(2, 8); else GWF(3, 8); }
     else            { if (g.MT == 1) GWF(1, 16); else if (g.MT == 2) GWF(2, 16); else GWF(3, 16); }
+#undef GWF2
 #undef GWF
     e = hipGetLastError();
     if (e != hipSuccess) return e;
@@ -373,7 +410,7 @@ static inline hipError_t gru_wide_bwd(const float* dout, const float* w_hh, cons
   unsigned* flags = (unsigned*)(xbuf + (size_t)2 * 3 * g.KG * 256);
   for (int b0 = 0; b0 < B; b0 += GW_BP) {
     const int Bc = B - b0 < GW_BP ? B - b0 : GW_BP;
-    hipError_t e = hipMemsetAsync(xbuf, 0, ((size_t)2 * 3 * g.KG * 256 + 1024) * sizeof(float), st);
+    hipError_t e = hipMemsetAsync(xbuf, 0, ((size_t)2 * 3 * g.KG * 256 + (size_t)1024 * GW_FS) * sizeof(float), st);
     if (e != hipSuccess) return e;
 #define GWB(GW_) hipLaunchKernelGGL((gru_bwd_wide_kernel<GW_>), dim3(g.P), dim3(GW_NW * 64), 0, st, dout, w_hh, h_all, reserve, \
                                     B, b0, Bc, S, Hd, g.U, g.KG, hx, flags, status, dgi, dghn)
