@@ -1125,6 +1125,18 @@ static int gru_bwd_impl(const float* dh_all, const float* dkey, const float* dqu
       }
       const int ntiles = wg_tile_index(q, 2);
       const size_t ws_floats = (size_t)GRU_NSPLIT * 3 * Hd * (Hd + 1);
+      if (ok && ntiles > 64) {
+        // hidden > 512: hundreds of tiles (216 at 1024, 816 at 2048) -- the flat work list of wgrad.h; arrival counters at
+        // the end of the slab region (which is 32 full copies of dW_hh: far more than the few partial tiles per output tile)
+        const size_t ncnt = ((size_t)ntiles + 63) & ~(size_t)63;
+        const size_t ws_use = (ws_floats - ncnt) & ~(size_t)3;
+        const int smax_big = (int)(ws_use / ((size_t)ntiles * WG_TILE_FLOATS));
+        if (smax_big >= 1) {
+          SG_TRY(wg_launch(q, 2, S * B, p_hh, reinterpret_cast<unsigned*>(p_hh + ws_use), smax_big > 8 ? 8 : smax_big, st, true,
+                           100, true));
+          hh_fused = true;
+        }
+      }
       const int smax_ws = (int)(ws_floats / ((size_t)ntiles * WG_TILE_FLOATS));
       if (ok && smax_ws >= 1 && ntiles <= 64) {
         // arrival counters: the last 64 words of the 16-byte aligned part of the scratch tail (>= 128 spare floats)

@@ -61,7 +61,8 @@ struct WgArgs {
   int S;            // splits of the K range
   int ktps;         // K tiles (of BK rows) per split
   int tmax;         // max nx * ny over the products (grid padding of the formula block order, `use_tab` == 0)
-  int use_tab;      // 1: blockIdx -> work item through `tab` (balanced XCD assignment built by the host)
+  int use_tab;      // 1: blockIdx -> work item through `tab` (balanced XCD assignment built by the host); 2: flat list,
+                    //    XCD c walks items [c * tmax, (c + 1) * tmax) of the (product, split, tile) order (launches of many tiles)
   unsigned short tab[8][WG_SLOTS];   // per XCD (= blockIdx % 8): (group << 6) | tile-in-group, 0xFFFF = no work
   float* ws;        // partial tiles [tile][split][WG_TILE_FLOATS] (lane-linear image), unused when S == 1
   unsigned* cnt;    // arrival counters [tiles], zero at launch
@@ -230,6 +231,27 @@ __global__ __launch_bounds__(256, (STAGES * BK * 1024 <= 80 * 1024 ? 2 : 1)) voi
   {
     const int L = blockIdx.x, c = L & 7, idx = L >> 3;
     int t, group;
+    if (g.use_tab == 2) {
+      // many more tiles than CUs (the GRU's dW_hh at hidden > 512): every XCD owns a contiguous range of the work list,
+      // so the 32 workgroups it runs at a time are neighbours -- tiles are numbered in bands of 8 along i, i.e. 32
+      // consecutive tiles form an 8 x 4 patch that shares its A / B panels through the XCD's L2
+      int w = c * g.tmax + idx;
+      gi = -1;
+      for (int i = 0; i < g.ngemm; ++i) {
+        const int n_i = g.g[i].nx * g.g[i].ny * g.S;
+        if (gi < 0) {
+          if (w < n_i) gi = i;
+          else w -= n_i;
+        }
+      }
+      if (gi < 0) return;
+      const int nx = g.g[gi].nx, ny = g.g[gi].ny;
+      s = w / (nx * ny);
+      t = w - s * nx * ny;
+      const int band = t / (8 * ny), bw = min(8, nx - 8 * band), r = t - band * 8 * ny;
+      by = r / bw;
+      bx = band * 8 + (r - by * bw);
+    } else {
     if (g.use_tab) {
       const unsigned it = g.tab[c][idx];
       if (it == 0xFFFFu) return;
@@ -243,6 +265,7 @@ __global__ __launch_bounds__(256, (STAGES * BK * 1024 <= 80 * 1024 ? 2 : 1)) voi
     if (t >= g.g[gi].nx * g.g[gi].ny) return;
     bx = t % g.g[gi].nx;
     by = t / g.g[gi].nx;
+    }
   }
 #ifdef SG_WG_DEBUG
   const unsigned long long t_start = __builtin_amdgcn_s_memtime();
@@ -454,8 +477,10 @@ static inline int wg_tile_index(WgGemm* q, int n) {
 // S <= smax_ws is guaranteed.
 // cu_percent: share of the chip the launch should fill (100 = every CU; 50 leaves half of the CUs to whatever runs
 // beside it on another stream) -- fewer, longer splits, same results
+// flat: the work-list order for launches of many more tiles than CUs (`use_tab` = 2); the split count then balances the
+// LAST round (816 tiles on 256 CUs: 4 rounds of which the last is 19 % full -> 5 splits: 4080 items = 15.94 rounds of 1/5)
 static inline hipError_t wg_launch(WgGemm* q, int n, int K, float* ws, unsigned* cnt, int smax_ws, hipStream_t st,
-                                   bool zero_counters = true, int cu_percent = 100) {
+                                   bool zero_counters = true, int cu_percent = 100, bool flat = false) {
   if (n <= 0 || n > WG_MAXG || K <= 0) return hipErrorInvalidValue;
   const WgPlan p = wg_plan();
   WgArgs a;
@@ -474,6 +499,15 @@ static inline hipError_t wg_launch(WgGemm* q, int n, int K, float* ws, unsigned*
 #endif
   const int KT = (K + p.bk - 1) / p.bk;
   int S = wg_splits(ntiles, K, p.bk, p.per_cu, smax_ws, cu_percent);
+  if (flat) {
+    const int slots = sg_num_cus() * p.per_cu;
+    double best_cost = 1e30;
+    for (int c = 1; c <= 8 && c <= smax_ws && (c == 1 || KT / c >= 8); ++c) {
+      const int rounds = (ntiles * c + slots - 1) / slots;
+      const double cost = (double)rounds / c + 0.002 * c;
+      if (cost < best_cost - 1e-9) { best_cost = cost; S = c; }
+    }
+  }
   a.ktps = (KT + S - 1) / S;
   a.S = (KT + a.ktps - 1) / a.ktps;              // no empty split
   if (a.S > 1 && zero_counters) {
@@ -485,7 +519,15 @@ static inline hipError_t wg_launch(WgGemm* q, int n, int K, float* ws, unsigned*
   const int groups = n * a.S;
   // deal the groups to the XCDs: each to the XCD with the fewest workgroups so far (host-side, a few hundred operations)
   int load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  a.use_tab = groups < 1024 && tmax <= 64;
+  a.use_tab = !flat && groups < 1024 && tmax <= 64;
+  if (flat) {
+    int items = 0;
+    for (int i = 0; i < n; ++i) items += q[i].nx * q[i].ny * a.S;
+    a.use_tab = 2;
+    a.tmax = (items + 7) / 8;
+    hipLaunchKernelGGL((sg_wgrad_kernel<16, 6>), dim3(8 * a.tmax), dim3(256), 0, st, a);
+    return hipGetLastError();
+  }
   if (a.use_tab) {
     for (int c = 0; c < 8; ++c)
       for (int k = 0; k < WG_SLOTS; ++k) a.tab[c][k] = 0xFFFFu;
