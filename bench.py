@@ -302,19 +302,21 @@ def run_training(cfg, steps, warmup, dev, world, rank, graph=True, T=12672, coll
     order = torch.cat([torch.randperm(n_windows, generator=g) for _ in range(epochs)])[: total * cfg["B"]]
     hi_all = (order + cfg["W"]).to(dev).view(total, cfg["B"])        # window-end rows (ForecastDataset.x_end_idx)
 
+    # the shuffled order is loaded once (device-side iterator, stemgnn_window_gather_queue): per step the host only
+    # replays the graph; every step still gathers its own B fresh windows from the series inside the timed region
     stepper = TrainStep(model, opt, cfg["B"], cfg["W"], cfg["H"], cfg["N"], series=series, world=world, graph=graph,
-                        collective=collective)
-    stepper.run_indices(hi_all[0])          # eager step (lazy init of tables, seed, state) + graph capture
+                        collective=collective, order_capacity=total * cfg["B"])
+    stepper.load_order(hi_all)
+    stepper.run_next()                      # eager step (lazy init of tables, seed, state) + graph capture
     torch.cuda.synchronize()
-    it = iter(range(1, total))
     for _ in range(warmup):
-        stepper.run_indices(hi_all[next(it)])
+        stepper.run_next()
     if dist.is_initialized():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
-        stepper.run_indices(hi_all[next(it)])
+        stepper.run_next()
     torch.cuda.synchronize()
     if dist.is_initialized():
         dist.barrier()

@@ -64,6 +64,7 @@ SIGNATURES = {
     "stemgnn_adam_step": (c_int, [_P, _P, _P, _P, c_size_t, _P, _P, c_float, c_float, c_float, c_int, c_float, _P]),
     "stemgnn_normalize_series": (c_int, [_P, _P, _P, c_int, _P, c_long, c_int, _P]),
     "stemgnn_window_gather": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_long, _P, _P]),
+    "stemgnn_window_gather_queue": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_long, _P, _P]),
     "stemgnn_mse_scratch_floats": (c_size_t, []),
     "stemgnn_mse_fwd": (c_int, [_P, _P, c_size_t, _P, _P, _P, _P]),
     "stemgnn_mse_bwd": (c_int, [_P, _P, c_size_t, _P, _P, _P]),

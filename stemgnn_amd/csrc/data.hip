@@ -77,6 +77,62 @@ extern "C" int stemgnn_window_gather(const float* series, const long long* hi, f
   return 0;
 }
 
+// Queue form of the gather (the DataLoader's iteration over one shuffled epoch, models/handler.py:136-138,157-159): the
+// window-end rows of a whole epoch sit in `order` (device), `q` is the device-side iterator {position, arrival ticket,
+// count}: every launch takes the next B windows and the LAST workgroup to arrive moves the position on -- so a captured
+// hipGraph step replays with no per-step index copy ahead of it (that copy and its launch gap were ~10 us of a 1.26 ms
+// step).  A position past `count` writes zeros and sets bit 1 of *status.
+__global__ void sg_window_gather_queue_kernel(const float* __restrict__ series, const long long* __restrict__ order,
+                                              long long* __restrict__ q, float* __restrict__ x, float* __restrict__ y,
+                                              int W, int H, int N, long T, int rows_per_wg, int* __restrict__ status) {
+  // few, larger workgroups (<= ~64: rows_per_wg slab rows of one batch element each), so that the arrival count costs
+  // 64 atomics on one word, not one per slab row
+  __shared__ long long pos_s;
+  if (threadIdx.x == 0) pos_s = __hip_atomic_load(&q[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  const long long pos = pos_s;
+  const int b = blockIdx.y, B = gridDim.y;
+  const long long count = q[2];
+  const bool have = pos >= 0 && pos + b < count;
+  const long long h0 = have ? order[pos + b] : 0;
+  const bool ok = have && h0 - W >= 0 && h0 + H <= T;
+  if (!ok && threadIdx.x == 0 && blockIdx.x == 0 && status) atomicOr(status, have ? 1 : 2);
+  const int r0 = blockIdx.x * rows_per_wg, r1 = min(W + H, r0 + rows_per_wg);
+  for (int r = r0; r < r1; ++r) {
+    float* dst = r < W ? x + ((size_t)b * W + r) * N : y + ((size_t)b * H + (r - W)) * N;
+    const float* src = series + (size_t)(ok ? h0 - W + r : 0) * N;
+    if ((N & 3) == 0) {
+      const float4* s4 = reinterpret_cast<const float4*>(src);
+      float4* d4 = reinterpret_cast<float4*>(dst);
+      for (int i = threadIdx.x; i < N / 4; i += blockDim.x) d4[i] = ok ? s4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    } else {
+      for (int i = threadIdx.x; i < N; i += blockDim.x) dst[i] = ok ? src[i] : 0.f;
+    }
+  }
+  if (threadIdx.x == 0) {
+    // thread 0 read the position before it takes its ticket, so the last arriver is the last reader as well
+    const long long nblk = (long long)gridDim.x * gridDim.y;
+    const long long ticket = __hip_atomic_fetch_add(&q[1], 1ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (ticket == nblk - 1) {
+      __hip_atomic_store(&q[1], 0ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&q[0], pos + B, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+extern "C" int stemgnn_window_gather_queue(const float* series, const long long* order, long long* queue, float* x, float* y,
+                                           int B, int W, int H, int N, long T, int* status, void* stream) {
+  if (!series || !order || !queue || !x || !y || B <= 0 || W <= 0 || H < 0 || N <= 0 || T < (long)W + H) return SG_EINVAL;
+  if ((N & 3) == 0 && ((((uintptr_t)series | (uintptr_t)x | (uintptr_t)y) & 15) != 0)) return SG_EINVAL;
+  const int threads = N >= 512 ? 256 : (N >= 128 ? 128 : 64);
+  int rows_per_wg = ((W + H) * B + 63) / 64;
+  if (rows_per_wg > W + H) rows_per_wg = W + H;
+  hipLaunchKernelGGL(sg_window_gather_queue_kernel, dim3((W + H + rows_per_wg - 1) / rows_per_wg, B), dim3(threads), 0,
+                     (hipStream_t)stream, series, order, queue, x, y, W, H, N, T, rows_per_wg, status);
+  SG_TRY(hipGetLastError());
+  return 0;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // MSE (nn.MSELoss(reduction='mean'), handler.py:140): loss = sum((f-y)^2)/n; two-stage fixed-order reduction.
 constexpr int MSE_BLOCKS = 128;

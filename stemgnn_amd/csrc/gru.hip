@@ -45,8 +45,20 @@ struct GruGiOp {
   const float *x, *w_ih, *b_ih;
   float* gi;
   int B, S, Hd, W;
+  // two word ranges the launch zeroes on the side (h_{-1} slab, exchange granules of the per-row clusters): every workgroup
+  // of the grid clears an even share ahead of its tile -- no zeroing launch of its own ahead of the recurrence
+  unsigned *za, *zb;
+  unsigned na, nb;
   __device__ bool setup(int, int& M, int& N, int& K0, int& K1) const {
     M = S * B; N = 3 * Hd; K0 = 0; K1 = W;
+    if (na + nb) {
+      const unsigned nwg = gridDim.x * gridDim.y, id = blockIdx.y * gridDim.x + blockIdx.x;
+      const unsigned per = (na + nb + nwg - 1) / nwg, hi = min(na + nb, (id + 1) * per);
+      for (unsigned i = id * per + threadIdx.x; i < hi; i += blockDim.x) {
+        if (i < na) za[i] = 0u;
+        else zb[i - na] = 0u;
+      }
+    }
     return true;
   }
   __device__ float a(int, int i, int k) const {
@@ -851,17 +863,6 @@ static int gru_pick_wide(int B, int Hd, int P2, GruWide* g) {
   return gru_wide_plan(Hd, gru_resident_limit(), g);
 }
 
-// zero two word ranges in one launch (4 words per thread where aligned; ranges are 4-byte aligned)
-__global__ __launch_bounds__(256) void gru_zero2_kernel(unsigned* __restrict__ a, size_t na, unsigned* __restrict__ b, size_t nb) {
-  const size_t i0 = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
-#pragma unroll
-  for (int u = 0; u < 4; ++u) {
-    const size_t i = i0 + u;
-    if (i < na) a[i] = 0u;
-    else if (i < na + nb) b[i - na] = 0u;
-  }
-}
-
 extern "C" size_t stemgnn_gru_fwd_scratch_floats(int B, int S, int Hd) {
   return (size_t)3 * Hd * Hd + (size_t)3 * S * B * Hd + gru_xbuf_floats(B, Hd) + 4;   // W_hh^T | gi | exchange
 }
@@ -896,20 +897,20 @@ extern "C" int stemgnn_gru_fwd(const float* x, const float* w_ih, const float* w
   float* w_hhT = scratch;
   float* gi = scratch + (size_t)3 * Hd * Hd;
   gru_u64* xbuf2 = (gru_u64*)(scratch + ((((size_t)3 * Hd * Hd + (size_t)3 * S * B * Hd) + 1) & ~(size_t)1));
+  size_t zn0 = 0, zn1 = 0;
   if (!use_wide && P2 > 0) {
     // per-row clusters: slab 0 (h_{-1} = 0) and the exchange granules (tags := 0 every launch) are zeroed ahead of the
-    // recurrence by one small kernel ahead of the projection GEMM instead of fill nodes of their own (each costs ~5 us of
-    // launch latency on the step's critical path).  (A streaming input-projection kernel that also did the zeroing was
-    // measured not faster in round 3 -- 25 us against 20 + 5 -- and removed in round 4.)
-    const size_t n0 = (size_t)B * Hd, n1 = ((size_t)2 * B * Hd + (size_t)8 * B) * 2;        // in 4-byte words
-    hipLaunchKernelGGL(gru_zero2_kernel, dim3((unsigned)((n0 + n1 + 1023) / 1024)), dim3(256), 0, st,
-                       reinterpret_cast<unsigned*>(h_ext), n0, reinterpret_cast<unsigned*>(xbuf2), n1);
-    SG_TRY(hipGetLastError());
+    // recurrence INSIDE the projection GEMM's launch (GruGiOp::setup: every workgroup clears a share) instead of fill
+    // nodes / a zeroing kernel of their own (each costs ~5 us of launch latency on the step's critical path).  (A
+    // streaming input-projection kernel that also did the zeroing was measured not faster in round 3 -- 25 us against
+    // 20 + 5 -- and removed in round 4.)
+    zn0 = (size_t)B * Hd; zn1 = ((size_t)2 * B * Hd + (size_t)8 * B) * 2;                   // in 4-byte words
   } else {
     SG_TRY(hipMemsetAsync(h_ext, 0, (size_t)B * Hd * sizeof(float), st));    // slab 0: h_{-1} = 0
   }
   {
-    GruGiOp op{x, w_ih, b_ih, gi, B, S, Hd, W};
+    GruGiOp op{x, w_ih, b_ih, gi, B, S, Hd, W, reinterpret_cast<unsigned*>(h_ext), reinterpret_cast<unsigned*>(xbuf2),
+               (unsigned)zn0, (unsigned)zn1};
     SG_TRY((sg_launch_gemm<GruGiOp, 64, 64, true, true, false>(op, S * B, 3 * Hd, 1, st)));
   }
   if (use_wide) {
@@ -918,7 +919,7 @@ extern "C" int stemgnn_gru_fwd(const float* x, const float* w_ih, const float* w
     return 0;
   }
   if (P2 > 0) {
-    gru_u64* xbuf = xbuf2;                                                          // zeroed by gru_zero2_kernel above
+    gru_u64* xbuf = xbuf2;                                                          // zeroed inside the projection GEMM's launch above
     gru_u64* xid = xbuf + (size_t)2 * B * Hd;                                       // P XCC-id granules per batch row
     static const int allow_fast = !(getenv("STEMGNN_GRU_FAST_XCD") && atoi(getenv("STEMGNN_GRU_FAST_XCD")) == 0);
     // Wave-specialised forward (gru_cluster4.h): P + 2 waves per workgroup, so every P <= 8 fits; its cluster size may
@@ -1035,7 +1036,7 @@ static int gru_bwd_impl(const float* dh_all, const float* dkey, const float* dqu
   float* p_ih = p_hh + (size_t)GRU_NSPLIT * 3 * Hd * (Hd + 1);
   const int P2 = gru_pick_P2(B, Hd);
   const int P = P2 > 0 ? 0 : gru_pick_P(B, Hd);
-  bool fold_ih = false, hh_fused = false, cnt_zeroed = false;
+  bool fold_ih = false, hh_fused = false, cnt_zeroed = false, ih_reduced = false;
   GruWide wide;
   if (gru_pick_wide(B, Hd, P2, &wide) > 0) {
     float* xb = scratch + ((((size_t)(p_ih - scratch) + (size_t)gru_ih_slabs(B) * 3 * Hd * (W + 1)) + 3) & ~(size_t)3);
@@ -1125,6 +1126,10 @@ static int gru_bwd_impl(const float* dh_all, const float* dkey, const float* dqu
       }
       const int ntiles = wg_tile_index(q, 2);
       const size_t ws_floats = (size_t)GRU_NSPLIT * 3 * Hd * (Hd + 1);
+      // the sum of the dW_ih | db_ih slabs rides along in the same launch (extra workgroups): no reduce launch on the tail
+      WgExtra ex;
+      ex.part = p_ih; ex.out_w = dw_ih; ex.out_b = db_ih; ex.rows = 3 * Hd; ex.cols = W; ex.nsplit = B;
+      const WgExtra* exr = fold_ih ? &ex : nullptr;
       if (ok && ntiles > 64) {
         // hidden > 512: hundreds of tiles (216 at 1024, 816 at 2048) -- the flat work list of wgrad.h; arrival counters at
         // the end of the slab region (which is 32 full copies of dW_hh: far more than the few partial tiles per output tile)
@@ -1142,8 +1147,9 @@ static int gru_bwd_impl(const float* dh_all, const float* dkey, const float* dqu
         // arrival counters: the last 64 words of the 16-byte aligned part of the scratch tail (>= 128 spare floats)
         const size_t tail = (stemgnn_gru_bwd_scratch_floats(B, S, Hd, W) - 64) & ~(size_t)3;
         unsigned* cnt = reinterpret_cast<unsigned*>(scratch + tail);
-        SG_TRY(wg_launch(q, 2, S * B, p_hh, cnt, smax_ws > 32 ? 32 : smax_ws, st, !cnt_zeroed));
+        SG_TRY(wg_launch(q, 2, S * B, p_hh, cnt, smax_ws > 32 ? 32 : smax_ws, st, !cnt_zeroed, 100, false, exr));
         hh_fused = true;
+        ih_reduced = exr != nullptr;
       }
     }
     const int rc = gru_wgrad_rows(dgi, dghn, h_ext, x, p_hh, p_ih, B, S, Hd, W, 0, S * B, 0, GRU_NSPLIT, st, st, !fold_ih,
@@ -1159,6 +1165,7 @@ static int gru_bwd_impl(const float* dh_all, const float* dkey, const float* dqu
     J.part[2] = p_ih; J.out_w[2] = dw_ih; J.out_b[2] = db_ih; J.rows[2] = 3 * Hd; J.cols[2] = W;
     J.nsplit[0] = J.nsplit[1] = GRU_NSPLIT; J.nsplit[2] = fold_ih ? B : GRU_NSPLIT;
     if (hh_fused) J.rows[0] = J.rows[1] = 0;           // dw_hh / db_hh are complete already
+    if (hh_fused && ih_reduced) return 0;              // ... and so are dw_ih / db_ih (WgExtra)
     size_t nmax = n0;
     const size_t n2 = (size_t)3 * Hd * (W + 1);
     if (n2 > nmax) nmax = n2;

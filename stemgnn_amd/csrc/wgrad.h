@@ -54,7 +54,19 @@ struct WgGemm {
   int tile0;        // index of this product's first tile (workspace / counter numbering)
 };
 
+// optional fixed-order slab sum riding along in the launch as extra workgroups behind the GEMM's (the GRU's dW_ih | db_ih
+// batch-row slabs: a 10 us launch of its own on the step's tail otherwise):
+//   out_w[j][k] = sum_z part[z][j][k] (k < cols),  out_b[j] = sum_z part[z][j][cols];  part = [nsplit][rows][cols + 1]
+struct WgExtra {
+  const float* part;
+  float* out_w;
+  float* out_b;
+  int rows, cols, nsplit;
+};
+
 struct WgArgs {
+  WgExtra ex;       // ex.rows == 0: none
+  int nmain;        // workgroups of the GEMM part of the grid (the slab sum's follow)
   WgGemm g[WG_MAXG];
   int ngemm;
   int K;            // reduction length (rows of every operand)
@@ -227,6 +239,17 @@ __global__ __launch_bounds__(256, (STAGES * BK * 1024 <= 80 * 1024 ? 2 : 1)) voi
   // one (product, split) GROUP share their operand panels, so a group stays on one XCD; the host deals the groups to the
   // XCDs so that every XCD gets (nearly) the same number of workgroups (`tab`), or, for launches too big for the table,
   // the closed-form order (group g on XCD g % 8, padded to the largest tile count).
+  if ((int)blockIdx.x >= g.nmain) {              // ride-along slab sum (WgExtra): 256 outputs per workgroup, splits in order
+    const size_t idx = (size_t)(blockIdx.x - g.nmain) * 256 + threadIdx.x;
+    const size_t slab = (size_t)g.ex.rows * (g.ex.cols + 1);
+    if (idx >= slab) return;
+    float sum = 0.f;
+    for (int z = 0; z < g.ex.nsplit; ++z) sum += g.ex.part[(size_t)z * slab + idx];
+    const int j = (int)(idx / (g.ex.cols + 1)), k = (int)(idx - (size_t)j * (g.ex.cols + 1));
+    if (k < g.ex.cols) g.ex.out_w[(size_t)j * g.ex.cols + k] = sum;
+    else g.ex.out_b[j] = sum;
+    return;
+  }
   int gi, s, bx, by;
   {
     const int L = blockIdx.x, c = L & 7, idx = L >> 3;
@@ -480,7 +503,8 @@ static inline int wg_tile_index(WgGemm* q, int n) {
 // flat: the work-list order for launches of many more tiles than CUs (`use_tab` = 2); the split count then balances the
 // LAST round (816 tiles on 256 CUs: 4 rounds of which the last is 19 % full -> 5 splits: 4080 items = 15.94 rounds of 1/5)
 static inline hipError_t wg_launch(WgGemm* q, int n, int K, float* ws, unsigned* cnt, int smax_ws, hipStream_t st,
-                                   bool zero_counters = true, int cu_percent = 100, bool flat = false) {
+                                   bool zero_counters = true, int cu_percent = 100, bool flat = false,
+                                   const WgExtra* extra = nullptr) {
   if (n <= 0 || n > WG_MAXG || K <= 0) return hipErrorInvalidValue;
   const WgPlan p = wg_plan();
   WgArgs a;
@@ -492,6 +516,12 @@ static inline hipError_t wg_launch(WgGemm* q, int n, int K, float* ws, unsigned*
     tmax = t > tmax ? t : tmax;
   }
   a.ngemm = n; a.K = K; a.tmax = tmax; a.ws = ws; a.cnt = cnt;
+  a.ex.part = nullptr; a.ex.out_w = a.ex.out_b = nullptr; a.ex.rows = a.ex.cols = a.ex.nsplit = 0;
+  unsigned nextra = 0;
+  if (extra && extra->rows > 0) {
+    a.ex = *extra;
+    nextra = (unsigned)(((size_t)extra->rows * (extra->cols + 1) + 255) / 256);
+  }
 #ifdef SG_WG_DEBUG
   a.dbg = getenv("STEMGNN_WG_DEBUG") ? atoi(getenv("STEMGNN_WG_DEBUG")) : 0;
 #else
@@ -525,7 +555,8 @@ static inline hipError_t wg_launch(WgGemm* q, int n, int K, float* ws, unsigned*
     for (int i = 0; i < n; ++i) items += q[i].nx * q[i].ny * a.S;
     a.use_tab = 2;
     a.tmax = (items + 7) / 8;
-    hipLaunchKernelGGL((sg_wgrad_kernel<16, 6>), dim3(8 * a.tmax), dim3(256), 0, st, a);
+    a.nmain = 8 * a.tmax;
+    hipLaunchKernelGGL((sg_wgrad_kernel<16, 6>), dim3(a.nmain + nextra), dim3(256), 0, st, a);
     return hipGetLastError();
   }
   if (a.use_tab) {
@@ -542,8 +573,8 @@ static inline hipError_t wg_launch(WgGemm* q, int n, int K, float* ws, unsigned*
   }
   int maxload = 0;
   for (int c = 0; c < 8; ++c) maxload = load[c] > maxload ? load[c] : maxload;
-  dim3 grid(a.use_tab ? 8 * maxload : 8 * ((groups + 7) / 8) * tmax);
-  hipLaunchKernelGGL((sg_wgrad_kernel<16, 6>), grid, dim3(256), 0, st, a);
+  a.nmain = a.use_tab ? 8 * maxload : 8 * ((groups + 7) / 8) * tmax;
+  hipLaunchKernelGGL((sg_wgrad_kernel<16, 6>), dim3(a.nmain + nextra), dim3(256), 0, st, a);
   return hipGetLastError();
 }
 

@@ -47,8 +47,11 @@ def capture(fn, warmups=3, on_fail=None):
 
 class TrainStep:
     def __init__(self, model, optimizer, batch_size, window_size, horizon, units, series=None, world=1, graph=True,
-                 exact=False, group=None, collective=None, one_graph=None):
-        """collective: run the data-parallel step structure (gradient all-reduce between backward and optimizer); default
+                 exact=False, group=None, collective=None, one_graph=None, order_capacity=0):
+        """order_capacity > 0 (with a resident `series`): the step takes its windows from a device-side queue of window-end
+        rows (`load_order` once per epoch, `run_next` per step; stemgnn_window_gather_queue advances the position on the
+        device), so a hipGraph replay is the whole per-step host work -- no index copy ahead of it.
+        collective: run the data-parallel step structure (gradient all-reduce between backward and optimizer); default
         world > 1, True forces it for a one-rank group (RCCL readiness on a 1-GPU box).  one_graph: capture the
         all-reduce INSIDE the step's hipGraph (one replay per step) instead of graph / eager collective / graph.  Default
         since round 4: ON (STEMGNN_DDP_ONE_GRAPH=0 forces the two-graph form) -- the capture attempt itself is the start-up
@@ -76,6 +79,11 @@ class TrainStep:
         self.hi = torch.zeros(self.B, dtype=torch.int64, device=dev)    # static window-end indices
         if series is not None:
             self.hi.fill_(self.W)
+        self.order = self.queue = None
+        self._q_left = 0
+        if series is not None and order_capacity > 0:
+            self.order = torch.full((max(int(order_capacity), 4 * self.B),), self.W, dtype=torch.int64, device=dev)
+            self.queue = torch.zeros(4, dtype=torch.int64, device=dev)      # {position, arrival ticket, count, -}
         self.x = torch.zeros(self.B, self.W, self.N, device=dev)
         self.y = torch.zeros(self.B, self.H, self.N, device=dev)
         self.loss = torch.zeros((), device=dev)
@@ -121,7 +129,10 @@ class TrainStep:
             self.state.fork_event = torch.cuda.Event()
             self.state.fork_event.record()
         if self.series is not None:
-            ops.window_gather(self.series, hi, self.W, self.H, x, y)
+            if hi is None:
+                ops.window_gather_queue(self.series, self.order, self.queue, self.B, self.W, self.H, x, y)
+            else:
+                ops.window_gather(self.series, hi, self.W, self.H, x, y)
         if early:
             self.model.prefetch_side(self.device)
         if not self.fuse_zero:
@@ -174,13 +185,25 @@ class TrainStep:
                 self.bucket.all_reduce_mean(self.group)
 
     def _arm(self):
+        # queue mode: the capture's warm-up steps walk the order buffer from its start over its whole capacity (every slot
+        # holds a valid row: loaded ones, or the initial fill), and the iterator is put back afterwards
+        if self.queue is None:
+            return self._arm_inner()
+        keep = self.queue.clone()
+        self.queue.copy_(torch.tensor([0, 0, self.order.numel(), 0], dtype=torch.int64))
+        try:
+            self._arm_inner()
+        finally:
+            self.queue.copy_(keep)
+
+    def _arm_inner(self):
         """First full batch: one eager step happened already (lazy state), now capture."""
         self._armed = True
         if not self.want_graph:
             return
         if not self.collective or self.one_graph:
             def whole():
-                loss = self._fwd_bwd(self.hi, self.x, self.y)
+                loss = self._fwd_bwd(None if self.queue is not None else self.hi, self.x, self.y)
                 self._sync()                                        # no-op unless the collective is captured too
                 self._finish(loss)
             snap = self._snapshot()
@@ -199,7 +222,7 @@ class TrainStep:
             box = {}
 
             def part_a():
-                box["loss"] = self._fwd_bwd(self.hi, self.x, self.y)
+                box["loss"] = self._fwd_bwd(None if self.queue is not None else self.hi, self.x, self.y)
 
             def part_b():
                 self._finish(box.get("loss"))
@@ -218,6 +241,7 @@ class TrainStep:
                   loss=self.loss.clone(), loss_sum=self.loss_sum.clone())
         seed = getattr(self.model, "_seed", None)
         st["seed"] = None if seed is None else seed.clone()
+        st["queue"] = None if self.queue is None else self.queue.clone()
         for name in ("exp_avg", "_step_dev"):                      # FusedAdam's extra state
             t = getattr(self.opt, name, None)
             st[name] = None if t is None else t.clone()
@@ -228,14 +252,48 @@ class TrainStep:
         self.loss.copy_(st["loss"]); self.loss_sum.copy_(st["loss_sum"])
         if st["seed"] is not None:
             self.model._seed.copy_(st["seed"])
+        if st.get("queue") is not None:
+            self.queue.copy_(st["queue"])
         for name in ("exp_avg", "_step_dev"):
             if st.get(name) is not None:
                 getattr(self.opt, name).copy_(st[name])
         torch.cuda.synchronize()
 
     # -- public ----------------------------------------------------------------------------------------------
+    def load_order(self, hi_all):
+        """Queue mode: the window-end rows of the coming steps (an epoch's shuffled order; int64, any device), consumed
+        batch_size at a time by `run_next`."""
+        if self.queue is None:
+            raise RuntimeError("TrainStep was built without order_capacity: use run_indices")
+        hi_all = hi_all.reshape(-1)
+        n = hi_all.numel()
+        if n > self.order.numel():
+            raise ValueError(f"load_order: {n} windows exceed order_capacity {self.order.numel()}")
+        self.order[:n].copy_(hi_all)
+        self.queue.copy_(torch.tensor([0, 0, n, 0], dtype=torch.int64))
+        self._q_left = n
+
+    def run_next(self):
+        """Queue mode: one optimizer step on the next batch_size windows of the loaded order."""
+        if self.queue is None:
+            raise RuntimeError("TrainStep was built without order_capacity: use run_indices")
+        if self._q_left < self.B:
+            raise IndexError("run_next: fewer than batch_size windows left in the loaded order (ragged tail: run_indices)")
+        self._q_left -= self.B
+        if self._replay is not None:
+            self.opt.sync_lr()
+            self._replay()
+            return
+        self._finish_eager(None, self.x, self.y)
+        if not self._armed:
+            self._arm()
+
     def run_indices(self, hi):
         """One optimizer step on the windows ending at `hi` (int64 device tensor, <= batch_size of them)."""
+        if self.queue is not None and hi.numel() == self.B:
+            self.load_order(hi)
+            self.run_next()
+            return
         if hi.numel() == self.B:
             if self._replay is not None:
                 self.hi.copy_(hi)

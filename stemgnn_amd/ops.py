@@ -287,12 +287,14 @@ class GruFront(torch.autograd.Function):
         if factors is not None:
             # SpectralHotPath.backward stopped at dkey | dquery: dh[s,b,i] = dkey[b,i] wk[s] + dquery[b,i] wq[s] is formed
             # inside the recurrence (the [N,B,N] gradient tensor is never written; `dh_all` is a zero-stride placeholder)
-            attn_scratch, fb, fn, wk, wq = factors
+            attn_scratch, fb, fn, wk, wq, after = factors
             base = attn_scratch.data_ptr() + 4 * fn * fn
             _lib.check(lib.stemgnn_gru_bwd_rank2(base, base + 4 * fb * fn, wk.data_ptr(), wq.data_ptr(), x.data_ptr(),
                                                  w_hh.data_ptr(), h_ext.data_ptr(), reserve.data_ptr(), B, S, Hd, W,
                                                  scratch.data_ptr(), dw_ih.data_ptr(), dw_hh.data_ptr(), db_ih.data_ptr(),
                                                  db_hh.data_ptr(), gru_status(dev).data_ptr(), _stream()), "gru_bwd_rank2")
+            if after is not None:
+                after()                 # dwk / dwq on the side stream (needs dkey | dquery only)
         else:
             _lib.check(lib.stemgnn_gru_bwd(dh_all.data_ptr(), x.data_ptr(), w_hh.data_ptr(), h_ext.data_ptr(),
                                            reserve.data_ptr(), B, S, Hd, W, scratch.data_ptr(), dw_ih.data_ptr(),
@@ -385,8 +387,10 @@ class FcTailMse(torch.autograd.Function):
             fsum.data_ptr(), target.data_ptr(), w0c.data_ptr(), b0c.data_ptr(), w2c.data_ptr(), b2c.data_ptr(), B, N, W, H,
             scratch.data_ptr(), None, loss.data_ptr(), accum.data_ptr() if accum is not None else None, dfsum.data_ptr(),
             grads[0].data_ptr(), grads[1].data_ptr(), grads[2].data_ptr(), grads[3].data_ptr(), _stream()), "fc_tail_train")
-        # (running the reduction of the per-block partials -- loss, fc gradients: off the backward's chain -- on the side
-        # stream was measured in round 4: no gain, the extra cross-queue edge costs what the 9 us launch returns)
+        # (the reduction of the per-block partials -- loss, fc gradients -- stays a launch of its own on this stream.  Measured
+        # in round 4: on the side stream no gain (the cross-queue edge costs what the 9 us launch returns); as the job of the
+        # LAST workgroup to arrive of the first launch, 40 us instead of 12 + 10 -- one workgroup summing 114 partials that
+        # other XCDs just wrote is a serial chain of fabric round trips)
         ctx.direct, ctx.unit_grad = direct, bool(unit_grad)
         ctx.held = (dfsum, None if direct else grads)
         ctx.set_materialize_grads(False)
@@ -778,45 +782,56 @@ class SpectralHotPath(torch.autograd.Function):
         # GRU recurrence.  Measured alternatives (round 3, removed in round 4): forking block 1's right behind its own chain,
         # beside block 0's MFMA-bound data-gradient kernels, +170 us per step (two GEMM streams on one chip are zero-sum);
         # forking only behind the Chebyshev backward +32 us; block 0's GFT backward ahead of the fork +9 us.
+        # Capture order matters inside the hipGraph step: at a fork the FIRST captured successor of a node stays on its
+        # queue, every later one moves to another queue behind a cross-queue edge (~10 us).  So at every fork the main
+        # stream's next kernel (the critical chain) is queued before the side stream's work that forks at the same node.
+        dt1 = None
         for s in (1, 0):
             scratch = bufs[s][0]
             dG = scratch[off_dG:]
             X, sb, sn, stt = xviews[s]
             heads, glu, wgrad, unpack = stage_fns(s)
             heads(st)
-            glu(st)
-            if overlap:
-                if s == 0:
-                    side.wait_stream(main)               # fork: every data-gradient chain is queued
-                    with torch.cuda.stream(side):
-                        sst = side.cuda_stream
-                        for ss in (0, 1):
-                            _h, _g, w2, u2 = (heads, glu, wgrad, unpack) if ss == 0 else stage_fns(1)
-                            w2(sst, _wg_cu(ss, B, N))
-                            u2(sst)
-                        if state.block_grads_hook is not None:
-                            state.block_grads_hook()     # data-parallel: reduce the finished range under the GRU recurrence
-                    keep.append(bufs)                    # alive until the join
-            else:
-                wgrad(st, 100)
-                unpack(st)
-            if overlap and s == 1:
-                # block 1: only its data gradient (-> dbackcast) feeds block 0's backward; its share of d(mul_L) is needed by
-                # the Chebyshev backward only, 100+ us later -> side stream, beside block 0's heads / GLU data gradients
-                _lib.check(lib.stemgnn_gft_bwd(mul_L.data_ptr(), X.data_ptr(), sb, sn, stt, dG.data_ptr(),
-                                               dbackcast.data_ptr(), None, 0, B, N, W, st), "gft_bwd dX")
-                side.wait_stream(main)
+            if dt1 is not None:
+                # block 1's share of d(mul_L) is needed by the Chebyshev backward only, 100+ us later -> side stream, beside
+                # block 0's heads / GLU data gradients (forked behind block 1's dX product, queued behind block 0's heads)
+                X1, sb1, sn1, stt1, dG1, dx_done = dt1
+                side.wait_event(dx_done)
                 with torch.cuda.stream(side):
-                    _lib.check(lib.stemgnn_gft_bwd(mul_L.data_ptr(), X.data_ptr(), sb, sn, stt, dG.data_ptr(), None,
+                    _lib.check(lib.stemgnn_gft_bwd(mul_L.data_ptr(), X1.data_ptr(), sb1, sn1, stt1, dG1.data_ptr(), None,
                                                    dmul_L.data_ptr(), 0, B, N, W, side.cuda_stream), "gft_bwd dT")
                     dt1_done = torch.cuda.Event()
                     dt1_done.record(side)
-                continue
-            if overlap:
-                main.wait_event(dt1_done)             # block 0's product accumulates onto block 1's
-            _lib.check(lib.stemgnn_gft_bwd(
-                mul_L.data_ptr(), X.data_ptr(), sb, sn, stt, dG.data_ptr(),
-                dbackcast.data_ptr() if s == 1 else None, dmul_L.data_ptr(), int(s == 0), B, N, W, st), "gft_bwd")
+            glu(st)
+            if not overlap:
+                wgrad(st, 100)
+                unpack(st)
+                _lib.check(lib.stemgnn_gft_bwd(
+                    mul_L.data_ptr(), X.data_ptr(), sb, sn, stt, dG.data_ptr(),
+                    dbackcast.data_ptr() if s == 1 else None, dmul_L.data_ptr(), int(s == 0), B, N, W, st), "gft_bwd")
+            elif s == 1:
+                # block 1: only its data gradient (-> dbackcast) feeds block 0's backward
+                _lib.check(lib.stemgnn_gft_bwd(mul_L.data_ptr(), X.data_ptr(), sb, sn, stt, dG.data_ptr(),
+                                               dbackcast.data_ptr(), None, 0, B, N, W, st), "gft_bwd dX")
+                dx_done = torch.cuda.Event()
+                dx_done.record(main)
+                dt1 = (X, sb, sn, stt, dG, dx_done)
+            else:
+                fork = torch.cuda.Event()                # every data-gradient chain is queued
+                fork.record(main)
+                main.wait_event(dt1_done)                # block 0's product accumulates onto block 1's
+                _lib.check(lib.stemgnn_gft_bwd(mul_L.data_ptr(), X.data_ptr(), sb, sn, stt, dG.data_ptr(), None,
+                                               dmul_L.data_ptr(), 1, B, N, W, st), "gft_bwd")
+                side.wait_event(fork)
+                with torch.cuda.stream(side):
+                    sst = side.cuda_stream
+                    for ss in (0, 1):
+                        _h, _g, w2, u2 = (heads, glu, wgrad, unpack) if ss == 0 else stage_fns(1)
+                        w2(sst, _wg_cu(ss, B, N))
+                        u2(sst)
+                    if state.block_grads_hook is not None:
+                        state.block_grads_hook()         # data-parallel: reduce the finished range under the GRU recurrence
+                keep.append(bufs)                        # alive until the join
         if overlap:
             state.pending = (side, (keep, packed, saved, split, backcast, dfsum, dbackcast))
         dL = torch.empty(N, N, device=dev, dtype=f32)
@@ -845,14 +860,20 @@ class SpectralHotPath(torch.autograd.Function):
             if exact is not None and part == 1:
                 _all_reduce_mean(attn_scratch[:N * N], exact)
         if factored:
-            state.dh_factors = (attn_scratch, B, N, wk, wq)
-            if overlap and kq_direct:       # behind block 1's weight gradients on the side stream, under the GRU recurrence
-                side.wait_stream(main)
-                with torch.cuda.stream(side):
-                    _lib.check(lib.stemgnn_keyquery_wgrad(h.data_ptr(), attn_scratch.data_ptr(), dwk.data_ptr(),
-                                                          dwq.data_ptr(), B, N, side.cuda_stream), "keyquery_wgrad")
-                state.pending[1][0].append((attn_scratch, h))
-            else:
+            after = None
+            if overlap and kq_direct:       # behind block 1's weight gradients on the side stream, under the GRU recurrence;
+                kq_ready = torch.cuda.Event()                         # queued by GruFront.backward BEHIND its own launches
+                kq_ready.record(main)                                 # (capture order, see above)
+                pend, hh, kdwk, kdwq = state.pending, h, dwk, dwq
+
+                def after():
+                    side.wait_event(kq_ready)
+                    with torch.cuda.stream(side):
+                        _lib.check(lib.stemgnn_keyquery_wgrad(hh.data_ptr(), attn_scratch.data_ptr(), kdwk.data_ptr(),
+                                                              kdwq.data_ptr(), B, N, side.cuda_stream), "keyquery_wgrad")
+                    pend[1][0].append((attn_scratch, hh))
+            state.dh_factors = (attn_scratch, B, N, wk, wq, after)
+            if after is None:
                 _lib.check(lib.stemgnn_keyquery_wgrad(h.data_ptr(), attn_scratch.data_ptr(), dwk.data_ptr(), dwq.data_ptr(),
                                                       B, N, st), "keyquery_wgrad")
         for s_, i_ in direct_idx:
@@ -955,12 +976,33 @@ def window_gather(series, hi, W, H, x=None, y=None):
     return x, y
 
 
+def window_gather_queue(series, order, queue, B, W, H, x, y):
+    """Iterator form (stemgnn_window_gather_queue): the next B windows of `order` (int64, device) at the device-side
+    position queue[0]; the kernel advances the position itself.  queue: int64[4] = {position, 0, count, -}."""
+    lib = _lib.load()
+    _require_gpu(series, "series")
+    for t, n in ((order, "order"), (queue, "queue")):
+        if t.dtype != torch.int64 or t.device != series.device or not t.is_contiguous():
+            raise _lib.StemGNNHipError(f"window_gather_queue: {n} must be a contiguous int64 tensor on the series' device")
+    T, N = series.shape
+    key = str(series.device)
+    st = _gather_status.get(key)
+    if st is None:
+        st = _gather_status[key] = torch.zeros(1, dtype=torch.int32, device=series.device)
+    _lib.check(lib.stemgnn_window_gather_queue(series.data_ptr(), order.data_ptr(), queue.data_ptr(), x.data_ptr(),
+                                               y.data_ptr(), B, W, H, N, T, st.data_ptr(), _stream()), "window_gather_queue")
+    return x, y
+
+
 def check_gather_status(device):
     """Raise if any window_gather since the last check saw an out-of-range index (one sync; call per epoch)."""
     st = _gather_status.get(str(device))
-    if st is not None and int(st.item()) != 0:
-        st.zero_()
-        raise IndexError("window_gather: window index outside the series")
+    if st is not None:
+        v = int(st.item())
+        if v != 0:
+            st.zero_()
+            raise IndexError("window_gather: window index outside the series" if v & 1 else
+                             "window_gather_queue: stepped past the end of the loaded order")
 
 
 def roll_window(inputs, forecast, forecast_steps, step, horizon):

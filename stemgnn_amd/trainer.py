@@ -158,14 +158,23 @@ class DeviceTrainer:
         valid_loader = WindowLoader(valid_set, batch_size=self.batch_size, shuffle=False)
         log(f"trainable parameters: {sum(p.numel() for p in self.model.parameters() if p.requires_grad)}")
         self.stepper = TrainStep(self.model, self.optimizer, self.batch_size, self.window, self.horizon, self.units,
-                                 series=train_set.data, graph=self.hipgraph)
+                                 series=train_set.data, graph=self.hipgraph, order_capacity=len(train_set))
         best, stale, metrics = float("inf"), 0, {}
         for epoch in range(epochs):
             t0 = time.time()
             self.model.train()
             n_steps = 0
-            for i, idx in enumerate(batches.index_batches()):
-                self.stepper.run_indices(train_set.hi_all.index_select(0, idx))
+            # the epoch's shuffled order goes to the device-side iterator once; full batches are then one graph replay
+            # each (TrainStep.run_next), the ragged last batch (drop_last=False, handler.py:136) runs eagerly
+            epoch_batches = list(batches.index_batches())
+            full = [idx for idx in epoch_batches if idx.numel() == self.batch_size]
+            if full:
+                self.stepper.load_order(train_set.hi_all.index_select(0, torch.cat(full)))
+            for i, idx in enumerate(epoch_batches):
+                if idx.numel() == self.batch_size:
+                    self.stepper.run_next()
+                else:
+                    self.stepper.run_indices(train_set.hi_all.index_select(0, idx))
                 n_steps += 1
                 if on_step is not None:
                     on_step(epoch, i, self.stepper)

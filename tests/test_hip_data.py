@@ -74,6 +74,30 @@ def test_window_gather_full_size_and_bad_index():
     ops.check_gather_status(series.device)                                           # cleared
 
 
+def test_window_gather_queue_iterates_on_the_device():
+    """stemgnn_window_gather_queue: successive launches walk the loaded order B windows at a time with no host-side index
+    traffic (bitwise the windows the plain gather returns), and a launch past the end reports it through the status word."""
+    from stemgnn_amd import ops
+    T, N, W, H, B = 500, 36, 12, 3, 8
+    g = torch.Generator().manual_seed(3)
+    series = torch.randn(T, N, generator=g).to(DEV)
+    order = (torch.randperm(T - W - H + 1, generator=g)[:3 * B] + W).to(DEV)
+    queue = torch.tensor([0, 0, 3 * B, 0], dtype=torch.int64, device=DEV)
+    x = torch.empty(B, W, N, device=DEV)
+    y = torch.empty(B, H, N, device=DEV)
+    for k in range(3):
+        ops.window_gather_queue(series, order, queue, B, W, H, x, y)
+        xr, yr = ops.window_gather(series, order[k * B:(k + 1) * B], W, H)
+        assert torch.equal(x, xr) and torch.equal(y, yr)
+        assert queue.tolist()[:3] == [(k + 1) * B, 0, 3 * B]
+    ops.check_gather_status(series.device)
+    ops.window_gather_queue(series, order, queue, B, W, H, x, y)                     # nothing left
+    assert float(x.abs().max()) == 0.0
+    with pytest.raises(IndexError, match="past the end"):
+        ops.check_gather_status(series.device)
+    ops.check_gather_status(series.device)
+
+
 def test_metrics_match_reference():
     from stemgnn_amd import math_utils
     from stemgnn_amd.forecast_dataloader import denorm_coefficients

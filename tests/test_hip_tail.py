@@ -116,6 +116,40 @@ def test_train_step_with_fused_adam_captures_a_graph_and_matches_eager():
     assert relerr(outs[0], outs[1]) < 1e-6
 
 
+def test_train_step_queue_mode_equals_per_step_indices():
+    """TrainStep(order_capacity=...): load_order once + run_next per step (device-side iterator, graph replay only) gives
+    the parameters run_indices gives on the same batches -- eager first step, capture warm-ups (rolled back, iterator
+    included) and replays; stepping past the loaded order raises on the host."""
+    from stemgnn_amd import Model, ops
+    from stemgnn_amd.engine import TrainStep
+    from stemgnn_amd.optim import FusedRMSprop
+    N, W, H, multi, B, T = 20, 12, 3, 5, 4, 120
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(5)
+    series = torch.randn(T, N, generator=g).to(dev)
+    hi = (torch.randint(0, T - W - H, (6, B), generator=g) + W).to(dev)
+    outs = []
+    for queue in (True, False):
+        torch.manual_seed(7)
+        model = Model(N, 2, W, multi, horizon=H, dropout_rate=0.0).to(dev).train()
+        opt = FusedRMSprop(model.parameters(), lr=1e-3)
+        step = TrainStep(model, opt, B, W, H, N, series=series, graph=True, order_capacity=6 * B if queue else 0)
+        if queue:
+            step.load_order(hi)
+            for i in range(6):
+                step.run_next()
+            with pytest.raises(IndexError):
+                step.run_next()
+        else:
+            for i in range(6):
+                step.run_indices(hi[i])
+        torch.cuda.synchronize()
+        assert step.mode.startswith("hipgraph"), step.mode
+        ops.check_gather_status(dev)
+        outs.append((opt.flat_p.clone(), float(step.epoch_loss_sum())))
+    assert torch.equal(outs[0][0], outs[1][0]) and outs[0][1] == outs[1][1]
+
+
 @pytest.mark.parametrize("B,N,W,H", [(32, 228, 12, 3), (5, 33, 12, 1), (3, 50, 8, 4), (16, 64, 48, 12)])
 def test_fused_train_tail_matches_separate_stages(B, N, W, H):
     """stemgnn_fc_tail_train (fc fwd + MSE + both backwards, 2 launches) == FcTail -> MSELoss -> backward (5 launches):
