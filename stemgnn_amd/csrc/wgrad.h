@@ -388,45 +388,6 @@ __global__ __launch_bounds__(256, (STAGES * BK * 1024 <= 80 * 1024 ? 2 : 1)) voi
       acc[c >> 3][(c >> 2) & 1][4 * (c & 3) + 2] = v.z; acc[c >> 3][(c >> 2) & 1][4 * (c & 3) + 3] = v.w;
     }
     int ss = 1;
-    // FOUR partials (64 x 16 B per lane) in flight while there are that many left: the sum is a chain of fabric round trips
-    // (the partials were written through by other XCDs), and the ring's registers are dead here.  Same split order as the
-    // two-at-a-time loop below: a = (((a + p[ss]) + p[ss+1]) + p[ss+2]) + p[ss+3] -- bitwise the same sums.
-    for (; ss + 3 < S; ss += 4) {
-      // hand-issued loads (wave-uniform base in SGPRs + the lane's byte offset) with counted waits: left to the scheduler,
-      // every load sinks to its add and 4 are in flight instead of 64
-      const float* sb = wsl + (size_t)ss * WG_TILE_FLOATS + wave * 4096;
-      const unsigned voff = lane * 16;
-      wg_f4 u[4][16];
-#pragma unroll
-      for (int p = 0; p < 4; ++p)
-#pragma unroll
-        for (int c = 0; c < 16; ++c)
-          asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(u[p][c]) : "v"(voff), "s"(sb + p * WG_TILE_FLOATS + c * 256) : "memory");
-#define WG_TIE16(P, N) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(u[P][0]), "+v"(u[P][1]), "+v"(u[P][2]), "+v"(u[P][3]), \
-      "+v"(u[P][4]), "+v"(u[P][5]), "+v"(u[P][6]), "+v"(u[P][7]), "+v"(u[P][8]), "+v"(u[P][9]), "+v"(u[P][10]), "+v"(u[P][11]),  \
-      "+v"(u[P][12]), "+v"(u[P][13]), "+v"(u[P][14]), "+v"(u[P][15]) :: "memory")
-      WG_TIE16(0, 48);
-#pragma unroll
-      for (int c = 0; c < 16; ++c)
-#pragma unroll
-        for (int k = 0; k < 4; ++k) acc[c >> 3][(c >> 2) & 1][4 * (c & 3) + k] += u[0][c][k];
-      WG_TIE16(1, 32);
-#pragma unroll
-      for (int c = 0; c < 16; ++c)
-#pragma unroll
-        for (int k = 0; k < 4; ++k) acc[c >> 3][(c >> 2) & 1][4 * (c & 3) + k] += u[1][c][k];
-      WG_TIE16(2, 16);
-#pragma unroll
-      for (int c = 0; c < 16; ++c)
-#pragma unroll
-        for (int k = 0; k < 4; ++k) acc[c >> 3][(c >> 2) & 1][4 * (c & 3) + k] += u[2][c][k];
-      WG_TIE16(3, 0);
-#pragma unroll
-      for (int c = 0; c < 16; ++c)
-#pragma unroll
-        for (int k = 0; k < 4; ++k) acc[c >> 3][(c >> 2) & 1][4 * (c & 3) + k] += u[3][c][k];
-#undef WG_TIE16
-    }
     for (; ss + 1 < S; ss += 2) {
       const float* r0 = rd + (size_t)ss * WG_TILE_FLOATS;
       const float* r1 = r0 + WG_TILE_FLOATS;
