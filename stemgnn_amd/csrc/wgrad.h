@@ -380,6 +380,9 @@ __global__ __launch_bounds__(256, (STAGES * BK * 1024 <= 80 * 1024 ? 2 : 1)) voi
     if (reinterpret_cast<volatile int*>(lds)[0] == 0 || WG_DBG(g, 8)) return;
     // last arriver: sum the S partial tiles in split order 0, 1, .. S-1 (fixed association -> bitwise reproducible).
     // Two partials (32 x 16 B per lane) are requested before the first is added: the sum is latency-bound otherwise.
+    // (Four at a time -- 64 loads = 256 VGPRs beside the 64 accumulators -- does not fit the 256 architectural VGPRs a VMEM
+    // load can target: the register allocator parks just-requested destinations in AGPRs before the data has arrived.
+    // Tried in round 4 with hand-issued loads and counted waits: wrong results, reverted.)
     const float* rd = wsl + wave * 4096 + lane * 4;
 #pragma unroll
     for (int c = 0; c < 16; ++c) {
