@@ -10,11 +10,27 @@ world > 1) and replayed per batch: the host only copies B int64 indices into a s
 """
 import os
 import sys
+import time
 
 import torch
 
 from . import ops
 from .distributed import FlatGradBucket
+
+
+def _let_watchdog_retire_eager_collectives():
+    """ProcessGroupNCCL's watchdog thread polls the end event of every EAGER collective it still holds (every ~100 ms).  On
+    this HIP stack an event query fails with hipErrorCapturedEvent while the stream the event was recorded on (RCCL's
+    internal stream) is being captured -- even though the record itself was eager -- and the exception terminates the
+    process (seen as an intermittent SIGABRT of the one-rank launcher tests: the warm-up steps' all-reduces had completed,
+    but the watchdog had not looked yet when the capture began).  All device work is complete here; give the watchdog a few
+    polling periods to notice and drop those work objects before a capture pulls RCCL's stream into capture mode."""
+    try:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            time.sleep(0.35)
+    except Exception:  # noqa: BLE001
+        pass
 
 
 def capture(fn, warmups=3, on_fail=None):
@@ -29,6 +45,7 @@ def capture(fn, warmups=3, on_fail=None):
                 fn()
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
+        _let_watchdog_retire_eager_collectives()
         g = torch.cuda.CUDAGraph()
         # thread_local: only this thread's calls are policed during capture -- with torch.distributed initialised, the
         # RCCL watchdog thread queries events concurrently, which the default global mode may treat as a capture violation

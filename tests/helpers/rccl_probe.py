@@ -62,6 +62,8 @@ def main():
             dist.all_reduce(buf)                   # warm-up outside capture (communicator set-up)
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
+        from stemgnn_amd.engine import _let_watchdog_retire_eager_collectives
+        _let_watchdog_retire_eager_collectives()   # the watchdog must not poll the warm-up's event during the capture
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g, capture_error_mode="thread_local"):
             buf.mul_(2.0)

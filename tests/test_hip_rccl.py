@@ -24,6 +24,11 @@ def _launch(script_args, timeout=600):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
            "--master-port", str(port)] + script_args
     p = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=timeout)
+    if p.returncode != 0:                                  # keep the whole transcript (the assertion message is truncated)
+        out_dir = os.path.join(ROOT, "gpurun_out")
+        if os.path.isdir(out_dir):
+            with open(os.path.join(out_dir, f"rccl_launch_failed_{port}.log"), "w") as f:
+                f.write("CMD " + " ".join(cmd) + "\n---- stdout\n" + p.stdout + "\n---- stderr\n" + p.stderr)
     assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-3000:])
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     assert lines, p.stdout[-2000:]
