@@ -168,7 +168,9 @@ def time_gru(cfg, iters=5):
     fb = e[1].elapsed_time(e[2]) * 1e3 / iters
     return {"bound": "latency (N dependent recurrence steps, one cross-workgroup exchange each)", "recurrence_steps": N,
             "fwd_us": f, "bwd_incl_weight_grads_us": fb - f, "fwd_us_per_recurrence_step": f / N,
-            "bwd_us_per_recurrence_step": (fb - f) / N}
+            "bwd_us_per_recurrence_step": (fb - f) / N,
+            "note": "fwd includes the input-projection GEMM, bwd the dW_hh / dW_ih weight-gradient launches; the recurrence "
+                    "kernels alone are in profiles/r04_gru_wide_kernel_stats.txt (rocprofv3 of tools/gru_wide_time.py)"}
 
 
 def roofline_objects(cfg):
