@@ -51,6 +51,16 @@ __host__ __device__ inline GruWide gru_wide_geom(int Hd, int pmax) {
 __device__ __forceinline__ int gw_slot(int k, int b) {
   return ((((k >> 4) << 6) + ((k & 3) << 4) + b) << 2) + ((k >> 2) & 3);
 }
+// Backward payload walk: chunks of GW_CH groups (one 16-byte load per lane each), the loads of chunk c + 1 requested ahead
+// of the MFMAs of chunk c.  Left alone, the instruction scheduler sinks every load to just ahead of its MFMAs (the ISA showed
+// "one load, vmcnt(1), four MFMAs": one L2 round trip per group); an empty asm with a memory clobber (a load cannot be moved
+// across it) plus a scheduling barrier between "request chunk c + 1" and "MFMAs of chunk c" pins the order at no run-time
+// cost: N=2048 backward 26.8 -> 25.6 ms, N=1024 6.22 -> 6.12.  Measured and not kept: the same pin in the FORWARD (N=2048
+// 6.29 -> 6.49 us per step) and deeper chunks (8 groups at N=1024: 6.38 ms backward; 8 in the N=2048 forward: 7.46 us) -- more
+// requests in flight from 205 workgroups at once congest the L2s again.
+#define GW_PIN_LOADS() do { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+constexpr int GW_CHB48 = 2;     // backward, 48 groups (N = 2048): 192 of a wave's 256 registers are resident weights
+constexpr int GW_CHB24 = 4;     // backward, smaller instantiations
 #ifndef GW_PRE
 #define GW_PRE 8                // pause (x 64 cycles) ahead of the first look at the flags (0 / 8 / 16 / 32: 4.70 / 4.50 / 4.65 / 5.08 us per step)
 #endif
@@ -336,7 +346,8 @@ __global__ __launch_bounds__(GW_NW * 64) void gru_bwd_wide_kernel(
     if (V0 < V1) {
       gw_wait_flags(flags, pa[0], pb[0], tag, lane, status);
       gw_wait_flags(flags, pa[1], pb[1], tag, lane, status);
-      constexpr int GW_CH = GW >= 48 ? 2 : 4;
+      constexpr int GW_CH = GW >= 48 ? GW_CHB48 : GW_CHB24;
+      static_assert(GW % GW_CH == 0, "chunking");
       gw_f4 v[2][GW_CH];
       gw_f4 acc2 = gw_f4{0.f, 0.f, 0.f, 0.f};                 // two accumulators: 16x16x4 has a 40-cycle dependent latency
       const __amdgpu_buffer_rsrc_t r = rs[tag & 1];
@@ -350,6 +361,7 @@ __global__ __launch_bounds__(GW_NW * 64) void gru_bwd_wide_kernel(
 #pragma unroll
           for (int g = 0; g < GW_CH; ++g) v[(c + 1) & 1][g] = gw_load(r, min(vgrp((c + 1) * GW_CH + g), VT - 1), lane);
         }
+        GW_PIN_LOADS();
 #pragma unroll
         for (int g = 0; g < GW_CH; ++g) {
           acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[4 * (c * GW_CH + g) + 0], v[c & 1][g][0], acc, 0, 0, 0);
