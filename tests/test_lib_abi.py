@@ -82,6 +82,10 @@ def test_tables_host_math(lib):
 def test_invalid_args_return_einval(lib):
     assert lib.stemgnn_cheb_fwd(None, 8, None) == -10001
     assert lib.stemgnn_make_tables_host(0, 5, None) == -10001
+    # the data-path entries refuse NULL buffers and series shorter than one window before any HIP call
+    assert lib.stemgnn_window_gather(None, None, None, None, 4, 12, 3, 8, 100, None, None) == -10001
+    assert lib.stemgnn_window_gather_queue(None, None, None, None, None, 4, 12, 3, 8, 100, None, None) == -10001
+    assert lib.stemgnn_gru_bwd_rank2_ok(0, 228) == 0       # (what it answers for a real shape depends on the device's CU count)
 
 
 def test_model_refuses_cpu():
