@@ -1114,7 +1114,9 @@ static int gru_bwd_impl(const float* dh_all, const float* dkey, const float* dqu
   {
     // dW_hh | db_hh on the fused weight-gradient kernel (csrc/wgrad.h: direct-to-LDS ring, in-kernel fixed-order split
     // reduction, results written straight into dw_hh / db_hh; the slab region doubles as its partial-tile workspace) when
-    // the 16-byte rules hold (Hd % 4 == 0); otherwise 32 slabs + the reduce below
+    // the 16-byte rules hold (Hd % 4 == 0); otherwise 32 slabs + the reduce below.  (Round 4 tried Hd % 4 == 2 -- PEMS03's
+    // 358 -- on the fused kernel with its 16-byte DMA pieces requested from 8-byte aligned rows: correct, every GRU test
+    // green, but SLOWER than slabs + reduce: backward incl. weight gradients 0.836 -> 0.863 ms at N=358, B=32.)
     {
       WgGemm q[2];
       q[0].A = dgi;  q[0].lda = 3 * Hd; q[0].Mi = 2 * Hd; q[0].out = dw_hh; q[0].out_bias = db_hh;
