@@ -80,6 +80,9 @@ int stemgnn_attn_laplacian_bwd(const float* dL, const float* h, const float* wk,
                                float* dh, float* dwk, float* dwq, int parts, void* stream);
 /* test hook: write the 0/1 keep-mask [B,N,N] the kernels above generate for `seed`. */
 int stemgnn_dropout_mask(float drop_p, const uint64_t* seed, int B, int N, float* mask, void* stream);
+/* One step of a model's dropout stream (nn.Dropout draws a fresh mask per forward, models/base_model.py:101,142): used[0..1] :=
+ * seed[0..1] (the {key, offset} the coming forward / backward pair reads), then seed[1] += 1 -- one launch, graph-capturable. */
+int stemgnn_dropout_seed_next(uint64_t* seed, uint64_t* used, void* stream);
 
 /* ---- Chebyshev basis  (models/base_model.py:121-134) --------------------------------------------
  * in: mul_L slot 1 = L;  out: slot 2 = 2LL, slot 3 = 2L(2LL) - L  (fp32 MFMA GEMMs). */

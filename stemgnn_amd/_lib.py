@@ -31,6 +31,7 @@ SIGNATURES = {
     "stemgnn_attn_laplacian_bwd": (c_int, [_P, _P, _P, _P, c_float, c_float, c_int, _P, c_int, c_int, _P, _P, c_int,
                                            _P, _P, _P, c_int, _P]),
     "stemgnn_dropout_mask": (c_int, [c_float, _P, c_int, c_int, _P, _P]),
+    "stemgnn_dropout_seed_next": (c_int, [_P, _P, _P]),
     "stemgnn_cheb_fwd": (c_int, [_P, c_int, _P]),
     "stemgnn_cheb_bwd": (c_int, [_P, _P, _P, _P, c_int, _P]),
     "stemgnn_eigh_scratch_floats": (c_size_t, [c_int]),

@@ -123,8 +123,10 @@ class Model(nn.Module):
                                                  else torch.cuda.current_device()].initial_seed()
                    + 0x9E3779B97F4A7C15 * (self._instance + 1) + 0xD1B54A32D192ED03 * rank) % (1 << 62)
             self._seed = torch.tensor([key, 0], dtype=torch.int64, device=device)
-        used = self._seed.clone()
-        self._seed[1] += 1          # device-side increment: graph-capturable, no host sync
+        used = torch.empty_like(self._seed)
+        # used := seed, seed.offset += 1 on the device in one launch: graph-capturable, no host sync
+        _lib.check(_lib.load().stemgnn_dropout_seed_next(self._seed.data_ptr(), used.data_ptr(),
+                                                         torch.cuda.current_stream(device).cuda_stream), "dropout_seed_next")
         return used
 
     def set_dropout_seed(self, seed, offset=0, device=None):

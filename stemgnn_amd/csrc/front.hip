@@ -599,6 +599,23 @@ extern "C" int stemgnn_keyquery_wgrad(const float* h, const float* attn_scratch,
   return 0;
 }
 
+// used := seed; seed.offset += 1 -- the per-forward step of the model's Philox stream as ONE launch (a clone + an in-place
+// add were two dispatches of the step)
+__global__ void sg_dropout_seed_next_kernel(uint64_t* __restrict__ seed, uint64_t* __restrict__ used) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    const uint64_t key = seed[0], off = seed[1];
+    used[0] = key;
+    used[1] = off;
+    seed[1] = off + 1;
+  }
+}
+extern "C" int stemgnn_dropout_seed_next(uint64_t* seed, uint64_t* used, void* stream) {
+  if (!seed || !used || seed == used) return SG_EINVAL;
+  hipLaunchKernelGGL(sg_dropout_seed_next_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, seed, used);
+  SG_TRY(hipGetLastError());
+  return 0;
+}
+
 extern "C" int stemgnn_dropout_mask(float drop_p, const uint64_t* seed, int B, int N, float* mask, void* stream) {
   if (!seed || !mask || B <= 0 || N <= 0) return SG_EINVAL;
   const size_t n = (size_t)B * N * N;
