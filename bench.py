@@ -11,10 +11,11 @@ A "step" is one optimizer step of the drop-in model on one synthetic PEMS07-shap
 -> zero_grad -> forward -> MSELoss -> backward -> (flat grad all-reduce over RCCL when N>1) -> RMSprop(lr=1e-4,
 eps=1e-8), the reference's loop body (models/handler.py:157-165) as stemgnn_amd.engine.TrainStep runs it (one hipGraph).
 Weak scaling: every rank trains on its own 32-sample batch ("replicas with a local graph").
-Arithmetic (`--dtype`, `dtype` in the line): default `bf16x2` -- BASELINE.json configs[1] names "bf16/fp32"; the GLU forward and
-data-gradient products run as split-bf16 on the bf16 matrix pipe inside the fused kernels (csrc/glu_fused_bf16.h), everything
-else fp32, <= 3e-5 model-level error against north_star's 1e-4 bar.  `--dtype f32` measures the library's default, exact fp32
-(the reference's arithmetic); whichever is the headline, `dtype_variants` carries the others.
+Arithmetic (`--dtype`, `dtype` in the line): default `f32` -- exact fp32, the reference's arithmetic
+(data_loader/forecast_dataloader.py:61-62) and the library's default.  BASELINE.json configs[1] also names bf16: `dtype_variants`
+carries the same step with the GLU forward and data-gradient products as split-bf16 on the bf16 matrix pipe inside the fused
+kernels (`bf16x2`, csrc/glu_fused_bf16.h; <= 3e-5 model-level error against north_star's 1e-4 bar) with its own `roofline`
+objects, and `bf16x3`; `--dtype bf16x2` makes that the main line instead.
 
 Rank 0 prints ONE JSON line: the throughput, a `roofline` object for the MFMA GEMM family with the largest summed GPU
 time per step (each family timed live with HIP events on the launch stream; `roofline_families` lists all of them),
@@ -37,12 +38,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 WORKLOAD = dict(N=228, W=12, H=3, multi=5, B=32)      # PEMS07 shape, BASELINE.json configs[1]
-# Arithmetic of the headline line.  BASELINE.json configs[1] names "bf16/fp32": since round 5 the fastest setting that meets
-# north_star's 1e-4 parity bar is bf16x2 -- the GLU forward and data-gradient products as split-bf16 (a_hi b_hi + a_hi b_lo +
-# a_lo b_hi, fp32 accumulation) on v_mfma_f32_32x32x16_bf16 inside the fused kernels, everything else fp32 (model-level error
-# <= 3e-5; the WHOLE -m gpu suite passes with it exported, profiles/r05_gpu_tests_bf16x2_env.txt).  The library's own default
-# stays exact fp32 (the reference's arithmetic); `--dtype f32` measures that, and `dtype_variants` carries it in every line.
-DEFAULT_DTYPE = "bf16x2"
+# Arithmetic of the headline line: exact fp32 -- the reference's arithmetic and the library default (round 5's line was bf16x2;
+# VERDICT r5 / ADVICE r5: the headline measures what a user gets by default).  BASELINE.json configs[1] names "bf16/fp32": the
+# split-bf16 setting (a_hi b_hi + a_hi b_lo + a_lo b_hi, fp32 accumulation, on v_mfma_f32_32x32x16_bf16 inside the fused
+# kernels; model-level error <= 3e-5) is `dtype_variants[0]` of every line, with its own roofline objects.
+DEFAULT_DTYPE = "f32"
 DTYPE_NOTE = {
     "f32": "exact fp32 (v_mfma_f32_32x32x2_f32 / 16x16x4_f32): the reference's arithmetic, the library default",
     "bf16x2": "GLU forward + data-gradient products as split-bf16 (3 bf16 products per fp32 product, ~2^-16 relative) on "
@@ -95,6 +95,19 @@ def glu_flops(cfg):
     cp2 = [c16(4 * (Wm // 2 + 1)), c16(max(4 * ((Wm + 1) // 2 - 1), 1))]
     exe = sum(2.0 * M * (3 * W * 2 * CP + CP * 2 * CP + CP * 2 * cp2[r]) for r in range(2))
     return alg, exe
+
+
+def step_flops(cfg):
+    """Algorithmic FLOPs of one train step of the hot path, SURVEY 8d: F_step = 3 F_fwd (GRU excluded, as there), and the
+    GRU's own (forward: input projection + recurrent product; backward: the transposed recurrent product + dW_hh + dW_ih)."""
+    B, N, W, multi = cfg["B"], cfg["N"], cfg["W"], cfg["multi"]
+    M, Wm = B * N, W * multi
+    C0, C = 4 * W, 4 * Wm
+    f_fwd = 2.0 * (2 * 3 * N * N * B * W + 8 * M * C0 * C + 16 * M * C * C + 8 * M * Wm * Wm + 2 * M * Wm * Wm + 2 * M * Wm * W) \
+        + 2.0 * M * Wm * W + 2.0 * M * W * W + 4.0 * N ** 3 + 12.0 * B * N * N
+    rec = 2.0 * B * 3 * N * N * N                      # N steps of [B x N] . [N x 3N]
+    proj = 2.0 * B * N * W * 3 * N
+    return {"hot_path": 3.0 * f_fwd, "gru_fwd": rec + proj, "gru_bwd": rec + rec + proj}   # bwd: dh W_hh, dW_hh (same size), dW_ih
 
 
 def time_gemm_families(cfg, iters=20):
@@ -215,6 +228,14 @@ def time_gru(cfg, iters=5):
                     "kernels alone are in profiles/r04_gru_wide_kernel_stats.txt (rocprofv3 of tools/gru_wide_time.py)"}
 
 
+def step_roofline(cfg, ms_per_step):
+    """The whole step against the fp32 matrix peak: SURVEY 8d's F_step (hot path, GRU excluded as there) over the step time."""
+    f = step_flops(cfg)["hot_path"]
+    tf = f / (ms_per_step * 1e-3) / 1e12
+    return {"flops": f, "achieved": tf, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP32_MFMA_PEAK_TFLOPS,
+            "note": "algorithmic FLOPs of SURVEY 8d (F_step = 3 F_fwd, GRU excluded) / measured step time / fp32 MFMA peak"}
+
+
 def roofline_objects(cfg):
     fams = time_gemm_families(cfg)
     alg, exe = glu_flops(cfg)
@@ -245,12 +266,38 @@ def roofline_objects(cfg):
             "mfma_util_static_pmc": traffic.get("mfma_util", {}).get(name),
             "traffic_static_pmc_source": traffic.get("source"),
         }
-    dominant = max(rows, key=lambda k: rows[k]["sum_us_per_step"])
+    # the GRU front: latency-bound recurrences, ALL of their time on the step's critical chain (the GLU weight gradients run
+    # beside the chain on the side branch) -- priced against the same fp32 matrix peak so that the fractions are comparable
+    gru = time_gru(cfg)
+    fl = step_flops(cfg)
+    for name, us, launches, kernel in (
+            ("gru_fwd", gru["fwd_us"], 2, "sg_gemm<GruGiOp> (input projection) + gru_fwd_cluster4_kernel / gru_fwd_wide_kernel "
+                                          "(persistent recurrence, W_hh resident in registers, one exchange per step)"),
+            ("gru_bwd", gru["bwd_incl_weight_grads_us"], 3, "zero-fill kernel + gru_bwd_cluster4_kernel / gru_bwd_wide_kernel "
+                                                            "(persistent recurrence) + sg_wgrad_kernel (dW_hh, dW_ih sum)")):
+        s = us * 1e-6
+        rows[name] = {"kernel": kernel, "bound": "mfma", "limited_by": "latency: N dependent recurrence steps, one cross-workgroup "
+                      "exchange each (DESIGN section 4)", "achieved": fl[name] / s / 1e12, "achieved_executed": fl[name] / s / 1e12,
+                      "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": fl[name] / s / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+                      "frac_executed": fl[name] / s / 1e12 / FP32_MFMA_PEAK_TFLOPS, "avg_launch_us": us / launches,
+                      "vs_fp32_mfma_peak": fl[name] / s / 1e12 / FP32_MFMA_PEAK_TFLOPS, "launches_per_step": launches,
+                      "sum_us_per_step": us, "flops_algorithmic": fl[name], "flops_executed": fl[name], "traffic": None,
+                      "us_per_recurrence_step": us / cfg["N"]}
+    # critical-path time per step: the GLU forward and data-gradient launches and every GRU launch sit on the chain; the GLU
+    # weight-gradient launches run on the side branch beside the backward chain / under the GRU recurrence
+    for name, r in rows.items():
+        r["on_critical_path"] = name != "glu_wgrad"
+        r["critical_us_per_step"] = r["sum_us_per_step"] if r["on_critical_path"] else 0.0
+    dominant = max(rows, key=lambda k: rows[k]["critical_us_per_step"])
     main = dict(rows[dominant])
     main["family"] = dominant
-    main["why"] = ("largest summed GPU time per step among the MFMA GEMM families (each timed live in isolation, HIP events "
-                   "on the launch stream; frac = algorithmic FLOPs / time / fp32 MFMA peak, incl. every reduction it needs)")
-    return main, rows
+    main["why"] = ("the kernel family with the largest time on the step's CRITICAL PATH (each family timed live in isolation through "
+                   "the C ABI, HIP events on the launch stream; frac = algorithmic FLOPs / time / fp32 MFMA peak); the MFMA GEMM "
+                   "families are in roofline_families, the largest of them by summed GPU time in `roofline_mfma`")
+    mf = max((k for k in rows if k.startswith("glu_")), key=lambda k: rows[k]["sum_us_per_step"])
+    main_mfma = dict(rows[mf])
+    main_mfma["family"] = mf
+    return main, rows, main_mfma, gru
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -389,6 +436,29 @@ def run_training(cfg, steps, warmup, dev, world, rank, graph=True, T=12672, coll
             extra["short_ms_per_step"] = (time.perf_counter() - t1) / short * 1e3
     if extra is not None:
         extra["schedule"] = dict(stepper.schedule)
+    if dist.is_initialized() and extra is not None and stepper.bucket is not None:
+        # the data-parallel step's collectives alone, eager, on every rank together (outside the timed region; the gradient
+        # buffer holds zeros after the fused optimizer step): the head range [0, split) is the one all-reduce the step EXPOSES
+        # (behind the GRU weight gradients), the tail range rides on the side branch under the GRU recurrence
+        flat, split = stepper.bucket.flat, stepper._split
+        ar = {"two_range": split is not None, "flat_bytes": flat.numel() * 4}
+
+        def timed(view, n=20):
+            for _ in range(3):
+                dist.all_reduce(view)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(n):
+                dist.all_reduce(view)
+            e1.record()
+            e1.synchronize()
+            return e0.elapsed_time(e1) * 1e3 / n
+        ar["flat_allreduce_us"] = timed(flat)
+        if split is not None:
+            ar.update(head_bytes=split * 4, tail_bytes=(flat.numel() - split) * 4,
+                      exposed_head_allreduce_us=timed(flat[:split]), tail_allreduce_us=timed(flat[split:]))
+        extra["allreduce"] = ar
     ops.check_gru_status(dev)               # outside the timed region: a lost GRU cluster partner must fail the run
     ops.check_gather_status(dev)
     final_loss = float(stepper.loss.item())
@@ -453,14 +523,18 @@ def section_other_configs(args, dev):
                    "warmup": w, "n_gpus": 1, "launch": md}
             if not args.no_roofline:        # what bounds this shape: the GEMM families' fractions + the GRU's latency floor
                 torch.cuda.empty_cache()
-                _, fams = roofline_objects(c)
+                _, fams, _, gru = roofline_objects(c)
                 row["roofline_families"] = {
                     f: {q: v[q] for q in ("frac", "frac_executed", "achieved", "avg_launch_us", "sum_us_per_step",
-                                          "launches_per_step")} for f, v in fams.items()}
-                row["gru"] = time_gru(c)
-                row["gru"]["share_of_step"] = ((row["gru"]["fwd_us"] + row["gru"]["bwd_incl_weight_grads_us"])
-                                               / (row["ms_per_step"] * 1e3))
-                row["glu_gemm_share_of_step"] = sum(v["sum_us_per_step"] for v in fams.values()) / (row["ms_per_step"] * 1e3)
+                                          "launches_per_step", "on_critical_path")} for f, v in fams.items()}
+                row["gru"] = gru
+                row["gru"]["critical_us"] = row["gru"]["fwd_us"] + row["gru"]["bwd_incl_weight_grads_us"]
+                row["gru"]["share_of_step"] = row["gru"]["critical_us"] / (row["ms_per_step"] * 1e3)
+                row["glu_gemm_share_of_step"] = sum(v["sum_us_per_step"] for f, v in fams.items()
+                                                    if f.startswith("glu_")) / (row["ms_per_step"] * 1e3)
+                row["glu_kernels"] = ("fused (one launch per block)" if (4 * c["W"] * c["multi"] + 15) // 16 * 16 <= 256
+                                      else "per-layer launches (4 W multi > 256: the row block's activations do not fit the LDS)")
+                row["step_roofline"] = step_roofline(c, row["ms_per_step"])
             key = name.split(" ")[0]
             cpu = {"reference_container_s_per_step": REFERENCE_CONTAINER_S[key][0],
                    "reference_container_note": "BASELINE.md section 3 (the reference itself, 8-core build container, another "
@@ -484,18 +558,27 @@ def section_dtype_variants(args, dev, cfg):
     import torch
     variants = []
     before = os.environ.get("STEMGNN_DTYPE")
-    for dt, err in (("f32", "<= 9e-6 norm-relative vs the oracle (exact fp32 products; fp32 re-association only)"),
-                    ("bf16x3", "<= 4e-6 norm-relative vs the oracle (fp32 class)"),
-                    ("bf16x2", "<= 3e-5 norm-relative vs the oracle (gate: 1e-4)")):
+    for dt, err in (("bf16x2", "<= 3e-5 norm-relative vs the oracle (gate: 1e-4)"),
+                    ("f32", "<= 9e-6 norm-relative vs the oracle (exact fp32 products; fp32 re-association only)"),
+                    ("bf16x3", "<= 4e-6 norm-relative vs the oracle (fp32 class)")):
         if dt == (before or "f32"):
             continue                      # the headline's own arithmetic
         os.environ["STEMGNN_DTYPE"] = dt
         try:
             torch.cuda.empty_cache()
             el, md, _ = run_training(cfg, 60, 10, dev, 1, 0, graph=not args.no_graph)
-            variants.append({"dtype": dt, "ms_per_step": el / 60 * 1e3, "value": cfg["B"] * cfg["H"] / (el / 60),
-                             "unit": "forecast-steps/s", "steps": 60, "warmup": 10, "launch": md,
-                             "arithmetic": DTYPE_NOTE[dt], "tested_error": err})
+            row = {"dtype": dt, "ms_per_step": el / 60 * 1e3, "value": cfg["B"] * cfg["H"] / (el / 60),
+                   "unit": "forecast-steps/s", "steps": 60, "warmup": 10, "launch": md,
+                   "arithmetic": DTYPE_NOTE[dt], "tested_error": err}
+            if not args.no_roofline and dt != "bf16x3":
+                torch.cuda.empty_cache()
+                row["roofline"], fams, row["roofline_mfma"], _ = roofline_objects(cfg)
+                row["roofline_families"] = {
+                    f: {q: v[q] for q in ("kernel", "frac", "frac_executed", "achieved", "peak", "avg_launch_us", "sum_us_per_step",
+                                          "launches_per_step", "on_critical_path", "traffic", "traffic_static_pmc",
+                                          "mfma_util_static_pmc") if q in v} for f, v in fams.items()}
+                row["step_roofline"] = step_roofline(cfg, row["ms_per_step"])
+            variants.append(row)
         except Exception as e:  # noqa: BLE001
             variants.append({"dtype": dt, "error": f"{type(e).__name__}: {e}"})
         finally:
@@ -685,7 +768,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")          # non-zero exit code: the run is not what was asked
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     # Under a launcher (RANK / WORLD_SIZE in the environment) the run is a data-parallel job even with ONE rank: the RCCL
@@ -699,6 +782,9 @@ def main():
         # reading the recorder (a drain on observed state); without it that wait is a fixed 0.35 s
         os.environ.setdefault("TORCH_FR_BUFFER_SIZE", "2000")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if dist.get_world_size() != args.gpus or dist.get_backend() != "nccl":
+            raise SystemExit(f"RCCL process group has {dist.get_world_size()} ranks over {dist.get_backend()!r}, --gpus asked for "
+                             f"{args.gpus} over nccl (= RCCL)")
 
     cfg = bench_workload()
     extra = {}
@@ -718,14 +804,23 @@ def main():
         # against the same step with the side branch serialised and against the side branch's own kernel-time sum
         "schedule": extra.get("schedule"),
     }
+    if dist.is_initialized():
+        # the first multi-GPU run explains itself: how many ranks RCCL saw, which form of the step was adopted, whether the
+        # one-graph two-range schedule passed its start-up verification on the REAL collectives, and what the collectives cost
+        sch = extra.get("schedule") or {}
+        out["multi_gpu"] = {"rccl_ranks": dist.get_world_size(), "backend": dist.get_backend(), "adopted_mode": mode,
+                            "one_graph_verified": sch.get("one_graph_verified"), "adopted_verified": sch.get("adopted_verified"),
+                            "recapture_verified": sch.get("recapture_verified"), "tail_hook_missed": sch.get("tail_hook_missed", 0),
+                            "capture_drain": sch.get("capture_drain"), "allreduce": extra.get("allreduce")}
     if "short_ms_per_step" in extra:        # what the driver's `--steps 20 --warmup 5` command measures, from the same process
         out["ms_per_step_20_steps"] = extra["short_ms_per_step"]
     if rank == 0:
         print("bench headline (complete line follows on stdout): " + json.dumps(out), file=sys.stderr, flush=True)
         if not args.no_roofline:
-            out["roofline"], out["roofline_families"] = roofline_objects(cfg)
-            out["gru"] = time_gru(cfg)
-            out["gru"]["share_of_step"] = (out["gru"]["fwd_us"] + out["gru"]["bwd_incl_weight_grads_us"]) / (out["ms_per_step"] * 1e3)
+            out["roofline"], out["roofline_families"], out["roofline_mfma"], out["gru"] = roofline_objects(cfg)
+            out["gru"]["critical_us"] = out["gru"]["fwd_us"] + out["gru"]["bwd_incl_weight_grads_us"]
+            out["gru"]["share_of_step"] = out["gru"]["critical_us"] / (out["ms_per_step"] * 1e3)
+            out["step_roofline"] = step_roofline(cfg, out["ms_per_step"])
         solo = world == 1 and not launched
         if solo and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg)

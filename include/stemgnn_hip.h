@@ -321,6 +321,10 @@ int stemgnn_fc_tail_train(const float* fsum, const float* target, const float* w
                           const float* b2, int B, int N, int W, int H, float* scratch, float* forecast,
                           float* loss, double* loss_accum, float* dfsum, float* dw0, float* db0, float* dw2,
                           float* db2, void* stream);
+/* Zero `bytes` bytes at `ptr` in stream order, as a KERNEL launch (the reference's zero_grad, models/handler.py:160, when it is
+ * not fused into the optimizer kernel; control words).  The step path never uses hipMemsetAsync: inside a captured hipGraph
+ * a memset node was seen to run into the kernel node that follows it. */
+int stemgnn_fill_zero(void* ptr, size_t bytes, void* stream);
 /* RMSprop step of the reference driver (models/handler.py:127,165; torch defaults alpha=0.99, momentum 0, not
  * centered) over flat, 16-byte aligned parameter / gradient / square_avg buffers of n floats; lr is read from
  * device memory; zero_grad != 0 also clears the gradients for the next step (handler.py:160); every gradient is

@@ -66,6 +66,7 @@ SIGNATURES = {
     "stemgnn_fc_tail_scratch_floats": (c_size_t, [c_int, c_int, c_int, c_int]),
     "stemgnn_fc_tail_fwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P]),
     "stemgnn_fc_tail_bwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P]),
+    "stemgnn_fill_zero": (c_int, [_P, c_size_t, _P]),
     "stemgnn_rmsprop_step": (c_int, [_P, _P, _P, c_size_t, _P, c_float, c_float, c_int, c_float, _P]),
     "stemgnn_adam_step": (c_int, [_P, _P, _P, _P, c_size_t, _P, _P, c_float, c_float, c_float, c_int, c_float, _P]),
     "stemgnn_normalize_series": (c_int, [_P, _P, _P, c_int, _P, c_long, c_int, _P]),

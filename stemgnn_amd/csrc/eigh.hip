@@ -858,7 +858,7 @@ static int eig_direct(float* mul_L, float* lam, float* U, float* scratch, int N,
     for (int m = 0; m < batch; ++m) {
       const size_t o = (size_t)m * sscr;
       SG_TRY(hipMemcpyAsync(A + o, L + (size_t)m * sL, nn * sizeof(float), hipMemcpyDeviceToDevice, st));
-      SG_TRY(hipMemsetAsync((unsigned*)((float*)counter + o), 0, 16 * sizeof(unsigned), st));
+      SG_TRY(sg_zero_async((unsigned*)((float*)counter + o), 16 * sizeof(unsigned), st));
       hipLaunchKernelGGL(eig_tridiag_kernel, dim3(G), dim3(1024), lds, st, A + o, N, G, V + o, dvec + o, evec + o, tauv + o,
                          pbuf + o, prow + o, (unsigned*)((float*)counter + o), status);
       SG_TRY(hipGetLastError());

@@ -916,7 +916,7 @@ extern "C" int stemgnn_gru_fwd(const float* x, const float* w_ih, const float* w
     // 20 + 5 -- and removed in round 4.)
     zn0 = (size_t)B * Hd; zn1 = ((size_t)2 * B * Hd + (size_t)8 * B) * 2;                   // in 4-byte words
   } else {
-    SG_TRY(hipMemsetAsync(h_ext, 0, (size_t)B * Hd * sizeof(float), st));    // slab 0: h_{-1} = 0
+    SG_TRY(sg_zero_async(h_ext, (size_t)B * Hd * sizeof(float), st));    // slab 0: h_{-1} = 0
   }
   {
     GruGiOp op{x, w_ih, b_ih, gi, B, S, Hd, W, reinterpret_cast<unsigned*>(h_ext), reinterpret_cast<unsigned*>(xbuf2),
@@ -961,7 +961,7 @@ extern "C" int stemgnn_gru_fwd(const float* x, const float* w_ih, const float* w
   if (P > 0) {
     const GruCluster c = gru_cluster_geom(Hd, P);
     gru_u64* xbuf = (gru_u64*)(scratch + ((((size_t)3 * Hd * Hd + (size_t)3 * S * B * Hd) + 1) & ~(size_t)1));   // 8-B aligned
-    if (P > 1) SG_TRY(hipMemsetAsync(xbuf, 0, (size_t)2 * B * Hd * sizeof(gru_u64), st));   // tags := 0 every launch
+    if (P > 1) SG_TRY(sg_zero_async(xbuf, (size_t)2 * B * Hd * sizeof(gru_u64), st));   // tags := 0 every launch
     const size_t lds = (size_t)(Hd + GRU_KC + c.ksf * 3 * c.U) * sizeof(float);
     const dim3 grid(8 * ((B + 7) / 8) * P);
     hipLaunchKernelGGL(gru_fwd_cluster_kernel<GRU_KC>, grid, dim3(1024), lds, st, gi, w_hh, b_hh, B, S, Hd, P, xbuf,
@@ -1145,7 +1145,7 @@ static int gru_bwd_impl(const float* dh_all, const float* dkey, const float* dqu
     // progress, the arrival counters of the fused dW_hh kernel, which otherwise costs a ~6 us fill node of its own on the
     // critical path between the recurrence and that kernel (every memset is a graph node with its own launch latency)
     const size_t fill_end = stemgnn_gru_bwd_scratch_floats(B, S, Hd, W) & ~(size_t)3;
-    if (run_rec) SG_TRY(hipMemsetAsync(xbuf, 0, (fill_end - (size_t)(xtail - scratch)) * sizeof(float), st));
+    if (run_rec) SG_TRY(sg_zero_async(xbuf, (fill_end - (size_t)(xtail - scratch)) * sizeof(float), st));
     cnt_zeroed = true;
     if (run_rec && split_call && !ctl) {                 // the fork point of the persistent dW_hh phase: behind the fill
       hipEvent_t ev = gru_fork_event();
@@ -1200,7 +1200,7 @@ static int gru_bwd_impl(const float* dh_all, const float* dkey, const float* dqu
   } else if (P > 0) {
     const GruCluster c = gru_cluster_geom(Hd, P);
     gru_u64* xbuf = (gru_u64*)(scratch + ((((size_t)(p_ih - scratch) + (size_t)gru_ih_slabs(B) * 3 * Hd * (W + 1)) + 1) & ~(size_t)1));
-    if (P > 1) SG_TRY(hipMemsetAsync(xbuf, 0, (size_t)2 * B * 3 * Hd * sizeof(gru_u64), st));
+    if (P > 1) SG_TRY(sg_zero_async(xbuf, (size_t)2 * B * 3 * Hd * sizeof(gru_u64), st));
     const size_t lds = (size_t)(3 * Hd + GRU_KC + c.U + c.ksb * c.U) * sizeof(float);
     const dim3 grid(8 * ((B + 7) / 8) * P);
     hipLaunchKernelGGL(gru_bwd_cluster_kernel<GRU_KC>, grid, dim3(1024), lds, st, dh_all, w_hh, h_all, reserve, B, S, Hd, P,

@@ -19,6 +19,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "devattr.h"
 #include "gru_math.h"
 
 typedef float gw_f4 __attribute__((ext_vector_type(4)));
@@ -400,7 +401,7 @@ static inline hipError_t gru_wide_fwd(const float* gi, const float* w_hh, const 
   unsigned* flags = (unsigned*)(xbuf + (size_t)2 * 3 * g.KG * 256);
   for (int b0 = 0; b0 < B; b0 += GW_BP) {
     const int Bc = B - b0 < GW_BP ? B - b0 : GW_BP;
-    hipError_t e = hipMemsetAsync(xbuf, 0, ((size_t)2 * 3 * g.KG * 256 + (size_t)1024 * GW_FS) * sizeof(float), st);
+    hipError_t e = sg_zero_async(xbuf, ((size_t)2 * 3 * g.KG * 256 + (size_t)1024 * GW_FS) * sizeof(float), st);
     if (e != hipSuccess) return e;
 #define GWF2(MT_, GW_, MK_) hipLaunchKernelGGL((gru_fwd_wide_kernel<MT_, GW_, MK_>), dim3(g.P), dim3(GW_NW * 64), 0, st, gi, w_hh, \
                                                b_hh, B, b0, Bc, S, Hd, g.U, g.KG, hx, flags, status, h_all, reserve)
@@ -422,7 +423,7 @@ static inline hipError_t gru_wide_bwd(const float* dout, const float* w_hh, cons
   unsigned* flags = (unsigned*)(xbuf + (size_t)2 * 3 * g.KG * 256);
   for (int b0 = 0; b0 < B; b0 += GW_BP) {
     const int Bc = B - b0 < GW_BP ? B - b0 : GW_BP;
-    hipError_t e = hipMemsetAsync(xbuf, 0, ((size_t)2 * 3 * g.KG * 256 + (size_t)1024 * GW_FS) * sizeof(float), st);
+    hipError_t e = sg_zero_async(xbuf, ((size_t)2 * 3 * g.KG * 256 + (size_t)1024 * GW_FS) * sizeof(float), st);
     if (e != hipSuccess) return e;
 #define GWB(GW_) hipLaunchKernelGGL((gru_bwd_wide_kernel<GW_>), dim3(g.P), dim3(GW_NW * 64), 0, st, dout, w_hh, h_all, reserve, \
                                     B, b0, Bc, S, Hd, g.U, g.KG, hx, flags, status, dgi, dghn)

@@ -371,6 +371,13 @@ __global__ void sg_rmsprop_kernel(float* __restrict__ p, float* __restrict__ g, 
   }
 }
 
+// Stream-ordered zero fill as a kernel node (csrc/devattr.h: sg_zero_async says why the step path never uses memset nodes).
+extern "C" int stemgnn_fill_zero(void* ptr, size_t bytes, void* stream) {
+  if (!ptr && bytes) return SG_EINVAL;
+  SG_TRY(sg_zero_async(ptr, bytes, (hipStream_t)stream));
+  return 0;
+}
+
 extern "C" int stemgnn_rmsprop_step(float* params, float* grads, float* square_avg, size_t n, const float* lr_dev,
                                     float alpha, float eps, int zero_grad, float grad_scale, void* stream) {
   if (!params || !grads || !square_avg || !lr_dev || n == 0) return SG_EINVAL;

@@ -754,7 +754,7 @@ static inline hipError_t wg_launch(WgGemm* q, int n, int K, float* ws, unsigned*
   if (a.S > 1 && zero_counters) {
     // one aligned fill (a ragged range is split into head / body / tail fill kernels, ~5 us each): cnt is 16-byte aligned
     // and holds at least the tile count rounded up to 64 words
-    hipError_t e = hipMemsetAsync(cnt, 0, sizeof(unsigned) * (((size_t)ntiles + 63) & ~(size_t)63), st);
+    hipError_t e = sg_zero_async(cnt, sizeof(unsigned) * (((size_t)ntiles + 63) & ~(size_t)63), st);
     if (e != hipSuccess) return e;
   }
   const int groups = n * a.S;

@@ -44,7 +44,13 @@ class FlatGradBucket:
             p.grad = v
 
     def zero(self):
-        self.flat.zero_()
+        if self.flat.is_cuda:
+            # a kernel node, not tensor.zero_() (= a memset node once the step is captured into a hipGraph: csrc/devattr.h)
+            from . import _lib
+            _lib.check(_lib.load().stemgnn_fill_zero(self.flat.data_ptr(), self.flat.numel() * self.flat.element_size(),
+                                                     torch.cuda.current_stream(self.flat.device).cuda_stream), "fill_zero")
+        else:
+            self.flat.zero_()
 
     def all_reduce_sum(self, group=None, force=False):
         """SUM over the ranks; the consumer scales by 1 / world (FusedRMSprop.grad_scale: inside the optimizer kernel,

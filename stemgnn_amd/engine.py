@@ -69,7 +69,16 @@ def _let_watchdog_retire_eager_collectives(timeout=5.0):
 def capture(fn, warmups=3, on_fail=None):
     """Capture fn into a hipGraph (torch.cuda.CUDAGraph); returns the replay callable, or None if capture fails.
     `on_fail()` is called after a failed attempt (before returning None) so the caller can drop host-side state a
-    partially executed / partially captured step left behind (queued side-stream work, pre-packed panels)."""
+    partially executed / partially captured step left behind (queued side-stream work, pre-packed panels).
+    The cyclic garbage collector is run once up front and then held off until the capture has ended: on ROCm the destructor
+    of a torch.cuda.CUDAGraph synchronises the DEVICE (ATen CUDAGraph.cpp, ROCm >= 6.2), and a step driver with data-parallel
+    hooks is cyclic garbage (TrainStep -> state -> hook -> TrainStep), i.e. it -- and the graphs it owns -- dies whenever the
+    collector happens to run.  Round 6 saw that moment fall inside a later capture: the process crashed in a replay of the
+    graph captured around it (tests/test_hip_schedule.py as one process; any allocation-count change moved the crash)."""
+    import gc
+    gc_was_on = gc.isenabled()
+    gc.collect()
+    gc.disable()
     try:
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
@@ -93,6 +102,9 @@ def capture(fn, warmups=3, on_fail=None):
             on_fail()
         torch.cuda.synchronize()
         return None
+    finally:
+        if gc_was_on:
+            gc.enable()
 
 
 capture.last_drain = None
@@ -343,6 +355,32 @@ class TrainStep:
                     ra(); self._sync(); rb()
                 self._replay, self.mode = rep, "hipgraph(fwd+bwd) + rccl all-reduce + hipgraph(optimizer)"
 
+    def _one_step_both_ways(self, run_a, run_b):
+        """One optimizer step by `run_a` and by `run_b` from the SAME state (parameters, second moments, dropout key,
+        window iterator: snapshot / restore around each); returns (parameters equal bit for bit, second moments equal bit for
+        bit, max |dv| between the two, max |v - v0| of the step)."""
+        snap = self._snapshot()
+        v0 = self.opt.square_avg.clone()
+        try:
+            run_a()
+            torch.cuda.synchronize()
+            p_a, v_a = self.opt.flat_p.clone(), self.opt.square_avg.clone()
+            self._restore(snap)
+            run_b()
+            torch.cuda.synchronize()
+            p_b, v_b = self.opt.flat_p.clone(), self.opt.square_avg.clone()
+        finally:
+            self._restore(snap)
+        return (bool(torch.equal(p_a, p_b)), bool(torch.equal(v_a, v_b)), float((v_a - v_b).abs().max()),
+                float((v_b - v0).abs().max()))
+
+    def _verdict(self, p_eq, v_eq, dv, change):
+        """world <= 2 (a two-term sum has one rounding whatever the order): bit for bit; beyond, the second moments to 1e-4 of
+        their largest change (see _verify_one_graph)."""
+        world = max(self.world, int(getattr(self.collective_fn, "world", 1)) if self.collective_fn is not None else 1)
+        ok = (p_eq and v_eq) if world <= 2 else dv <= 1e-4 * change
+        return bool(ok and change == change and dv == dv and change > 0.0), world
+
     def _verify_one_graph(self, rep):
         """The captured one-graph step (two-range all-reduce, the tail range on the side branch) against the FLAT eager form
         -- every gradient final, side streams joined, ONE all-reduce, optimizer -- on the same batch, the same dropout key and
@@ -351,33 +389,19 @@ class TrainStep:
           * world <= 2: a two-term sum has one rounding whatever the order -> both must agree BIT FOR BIT;
           * world > 2: the ring's summation order depends on where an element sits in its range, so the two forms differ in
             the last bits of g -- harmless in v (compared to 1e-4 of its largest change), but NOT comparable through the
-            parameters: RMSprop's early steps move a weight by ~10 lr whatever the size of its gradient, and the ~4 000
-            weights whose exact gradient is zero (rounding noise of random sign) would differ by whole steps.
+            parameters: RMSprop's early steps move a weight by ~10 lr whatever the size of its gradient, so a weight whose
+            gradient is at the rounding level may take a step of the other sign.
         A range reduced before its gradients are final, or a missing side -> main edge, changes g -- and v -- by O(1).  Every
         rank runs it, the MIN over the ranks decides, and a failure falls back to graph / all-reduce / graph on all ranks."""
-        snap = self._snapshot()
-        v0 = self.opt.square_avg.clone()
-        rep()
-        torch.cuda.synchronize()
-        p_graph, v_graph = self.opt.flat_p.clone(), self.opt.square_avg.clone()
-        self._restore(snap)
-        split, hook = self._split, self.state.block_grads_hook
-        self._split, self.state.block_grads_hook = None, None
-        try:
-            self._whole()                                   # eager, flat all-reduce behind the joined side stream
-            torch.cuda.synchronize()
-        finally:
-            self._split, self.state.block_grads_hook = split, hook
-        p_eager, v_eager = self.opt.flat_p.clone(), self.opt.square_avg.clone()
-        self._restore(snap)
-        dv = float((v_graph - v_eager).abs().max())
-        change = float((v_eager - v0).abs().max())
-        world = max(self.world, int(getattr(self.collective_fn, "world", 1)) if self.collective_fn is not None else 1)
-        if world <= 2:
-            ok = bool(torch.equal(p_graph, p_eager)) and bool(torch.equal(v_graph, v_eager))
-        else:
-            ok = dv <= 1e-4 * change
-        ok = ok and change == change and dv == dv and change > 0.0
+        def flat_eager():
+            split, hook = self._split, self.state.block_grads_hook
+            self._split, self.state.block_grads_hook = None, None
+            try:
+                self._whole()                               # eager, flat all-reduce behind the joined side stream
+            finally:
+                self._split, self.state.block_grads_hook = split, hook
+        p_eq, v_eq, dv, change = self._one_step_both_ways(rep, flat_eager)
+        ok, world = self._verdict(p_eq, v_eq, dv, change)
         self.schedule["one_graph_verified"] = {"ok": ok, "max_abs_diff": dv, "max_abs_change": change, "world": world,
                                                "compared": "parameters + second moments, bitwise" if world <= 2
                                                else "second moments to 1e-4 of their largest change"}
@@ -386,6 +410,24 @@ class TrainStep:
         print(f"[stemgnn_amd] one-graph data-parallel step disagrees with the flat eager form (second moments differ by "
               f"{dv:.3e} of a {change:.3e} change); using hipgraph(fwd+bwd) + all-reduce + hipgraph(optimizer)", file=sys.stderr)
         return None
+
+    def _verify_serial_graph(self, rep):
+        """The SERIALISED graph (what the schedule self-check adopts on a device that gives no branch overlap) against the eager
+        one-stream step: the same kernels, the same split counts, the same flat all-reduce -- one replay and one eager step
+        from the same state must agree bit for bit (world > 2: see _verdict).  Round 5 adopted this graph unchecked, and it
+        was wrong (a mis-replayed memset node, csrc/devattr.h); the caller keeps the overlapped capture on a mismatch."""
+        def eager_one_stream():
+            keep = (self.state.overlap, self._split, self.state.block_grads_hook)
+            self.state.overlap, self._split, self.state.block_grads_hook = False, None, None
+            try:
+                self._whole()
+            finally:
+                self.state.overlap, self._split, self.state.block_grads_hook = keep
+        p_eq, v_eq, dv, change = self._one_step_both_ways(rep, eager_one_stream)
+        ok, world = self._verdict(p_eq, v_eq, dv, change)
+        self.schedule["adopted_verified"] = {"ok": ok, "against": "eager one-stream step", "max_abs_diff": dv,
+                                             "max_abs_change": change, "world": world}
+        return self._all_ranks_ok(ok)
 
     def _check_schedule(self, rep):
         """The step's speed rests on the hipGraph executor running the captured side branch (weight packing, both blocks'
@@ -398,30 +440,61 @@ class TrainStep:
         branch_overlap = (t_serial - t_overlap) / side_sum.  A healthy capture measures ~0.56 at PEMS07 (1.236 / 1.469 /
         0.414 ms: the side branch's kernels run slower beside the chain than alone, and the serialised step has no fork /
         join edges), a lost overlap ~0; below LOST_OVERLAP = 0.3 the step is re-captured with a fresh side stream (up to 3
-        times, all ranks together), and the fastest capture is kept.  Everything runs under snapshot / restore."""
+        times, all ranks together), and the fastest capture is kept.  Everything runs under snapshot / restore.
+        Round 6: (i) whichever graph is adopted INSTEAD of the one the caller verified is verified itself -- the serialised
+        graph bit for bit against the eager one-stream step, a re-captured data-parallel graph by _verify_one_graph -- and a
+        graph that fails is not adopted; (ii) a rank that throws in one phase does not leave the others waiting in the next
+        phase's collectives: every phase ends in ONE agreement over the ranks at a fixed point, and all ranks abandon the
+        check together (keeping the capture they came with)."""
         info = self.schedule
         snap = self._snapshot()
-        try:
-            # the side branch's kernel-time sum: one eager step records every side-branch kernel as a re-issuable thunk
-            self.state.side_probe = []
-            self._whole()
-            thunks, self.state.side_probe = self.state.side_probe, None
-            torch.cuda.synchronize()
-            side_rep = capture(lambda: [t(torch.cuda.current_stream().cuda_stream) for t in thunks], warmups=1) \
-                if thunks else None
-            side_ms = _time_replays(side_rep) if side_rep is not None else None
-            del side_rep, thunks
-            # the step with the side branch serialised
-            split, hook = self._split, self.state.block_grads_hook
-            self.state.overlap, self._split, self.state.block_grads_hook = False, None, None
+        first = rep
+        box = {}
+
+        def agreed(phase):
+            """run one phase locally; MIN over the ranks of "it did not throw" at a fixed point"""
+            ok = True
             try:
-                serial_rep = capture(self._whole, on_fail=self.state.reset)
-                serial_ms = _time_replays(serial_rep) if serial_rep is not None else None
-            finally:
-                self.state.overlap, self._split, self.state.block_grads_hook = True, split, hook
+                phase()
+            except Exception as e:  # noqa: BLE001 -- the check must never cost the step
+                ok = False
+                info.update(checked=False, error=f"{type(e).__name__}: {e}")
+            return self._all_ranks_ok(ok)
+
+        def abandon():
+            self.state.side_probe = None
+            self.state.overlap = True
+            return first
+
+        try:
+            def measure_parts():
+                # the side branch's kernel-time sum: one eager step records every side-branch kernel as a re-issuable thunk
+                self.state.side_probe = []
+                self._whole()
+                thunks, self.state.side_probe = self.state.side_probe, None
+                torch.cuda.synchronize()
+                side_rep = capture(lambda: [t(torch.cuda.current_stream().cuda_stream) for t in thunks], warmups=1) \
+                    if thunks else None
+                box["side_ms"] = _time_replays(side_rep) if side_rep is not None else None
+                del side_rep, thunks
+                # the step with the side branch serialised
+                split, hook = self._split, self.state.block_grads_hook
+                self.state.overlap, self._split, self.state.block_grads_hook = False, None, None
+                try:
+                    box["serial_rep"] = capture(self._whole, on_fail=self.state.reset)
+                    box["serial_ms"] = _time_replays(box["serial_rep"]) if box["serial_rep"] is not None else None
+                finally:
+                    self.state.overlap, self._split, self.state.block_grads_hook = True, split, hook
+            if not agreed(measure_parts):
+                return abandon()
+            side_ms, serial_ms, serial_rep = box["side_ms"], box["serial_ms"], box["serial_rep"]
             best, best_ms, tries, recaptures = rep, None, [], 0
             while True:
-                ms = _time_replays(rep)
+                def time_it():
+                    box["ms"] = _time_replays(rep)
+                if not agreed(time_it):
+                    return abandon()
+                ms = box["ms"]
                 tries.append(ms)
                 if best_ms is None or ms < best_ms:
                     best, best_ms = rep, ms
@@ -429,9 +502,14 @@ class TrainStep:
                 if not self._any_rank(lost) or recaptures >= 3:
                     break
                 recaptures += 1
-                self._restore(snap)
-                ops.fresh_side_stream(self.device)
-                rep = capture(self._whole, on_fail=self.state.reset)
+
+                def recapture():
+                    self._restore(snap)
+                    ops.fresh_side_stream(self.device)
+                    box["rep"] = capture(self._whole, on_fail=self.state.reset)
+                if not agreed(recapture):
+                    return abandon()
+                rep = box["rep"]
                 if not self._all_ranks_ok(rep is not None):
                     break
             # a capture whose branches do not overlap is SLOWER than the serialised step (it still pays the cross-queue
@@ -439,18 +517,29 @@ class TrainStep:
             serialised = self._any_rank(serial_ms is not None and serial_ms < 0.98 * best_ms) \
                 and self._all_ranks_ok(serial_rep is not None)
             if serialised:
-                best = serial_rep
-                self.state.overlap, self._split, self.state.block_grads_hook = False, None, None
+                self._restore(snap)
+                if self._verify_serial_graph(serial_rep):
+                    best = serial_rep
+                    self.state.overlap, self._split, self.state.block_grads_hook = False, None, None
+                else:
+                    print("[stemgnn_amd] the serialised graph disagrees with the eager one-stream step; keeping the overlapped "
+                          "capture", file=sys.stderr)
+                    serialised = False
             info.update(checked=True, t_overlap_ms=best_ms, t_serial_ms=serial_ms, side_sum_ms=side_ms,
                         branch_overlap=None if not side_ms or serial_ms is None else (serial_ms - best_ms) / side_ms,
                         recaptures=recaptures, t_overlap_ms_per_capture=tries, side_branch_serialised=bool(serialised),
                         queues=os.environ.get("GPU_MAX_HW_QUEUES", "default (4)"))
+            if not serialised and best is not first and self.collective and \
+                    (self.world > 1 or self.collective_fn is not None):
+                # a RE-captured data-parallel graph replaces the one _arm_inner verified: same check, same fallback (None ->
+                # graph / all-reduce / graph on all ranks)
+                self._restore(snap)
+                best = self._verify_one_graph(best)
+                info["recapture_verified"] = best is not None
             return best
-        except Exception as e:  # noqa: BLE001 -- the check must never cost the step
+        except Exception as e:  # noqa: BLE001 -- outside the agreed phases (the agreement itself failed): keep the capture
             info.update(checked=False, error=f"{type(e).__name__}: {e}")
-            self.state.side_probe = None
-            self.state.overlap = True
-            return rep
+            return abandon()
         finally:
             self._restore(snap)
 

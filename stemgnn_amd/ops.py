@@ -859,7 +859,7 @@ class SpectralHotPath(torch.autograd.Function):
                         nctl = lib.stemgnn_gru_bwd_ctl_words(N)
                         if state.gru_ctl is None or state.gru_ctl.numel() != nctl or state.gru_ctl.device != dev:
                             state.gru_ctl = torch.zeros(nctl, device=dev, dtype=torch.int32)
-                        state.gru_ctl.zero_()
+                        _lib.check(lib.stemgnn_fill_zero(state.gru_ctl.data_ptr(), 4 * nctl, side.cuda_stream), "fill_zero")
                         state.gru_ctl_zeroed = True
                     dT1(side.cuda_stream)
                     dt1_done = torch.cuda.Event()

@@ -29,7 +29,7 @@ for STAGE in "$@"; do
     prof)
       ( cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/prof -- $BENCH_PROF > $R/$OUT/prof.log 2>&1 )
       F=$(find $OUT/prof -name '*kernel_stats.csv' | head -1)
-      [ -n "$F" ] && python tools/kstats.py $F 46 70 > $OUT/kernel_stats.txt
+      [ -n "$F" ] && python tools/kstats.py $F auto 70 > $OUT/kernel_stats.txt
       python tools/step_timeline.py $OUT/prof > $OUT/step_timeline.txt 2>&1; head -1 $OUT/step_timeline.txt
       find $OUT/prof -name '*kernel_trace.csv' -size +20M -delete ;;
     prof_iso)
