@@ -60,10 +60,18 @@ def _let_watchdog_retire_eager_collectives(timeout=5.0):
         time.sleep(0.35)
         return "sleep"
     deadline = time.monotonic() + timeout
-    while n and time.monotonic() < deadline:
-        time.sleep(0.01)
+    while time.monotonic() < deadline:
+        while n and time.monotonic() < deadline:
+            time.sleep(0.01)
+            n = _active_collectives()
+        # round 6: the recorder's "retired" and the watchdog's own list are not the same object -- one run in seven of the
+        # launcher test still died with hipErrorCapturedEvent although the recorder showed nothing active (a work object the
+        # watchdog had marked but not yet dropped).  Let it go round its loop (~100 ms period) a few more times and look again.
+        time.sleep(0.3)
         n = _active_collectives()
-    return "drained" if not n else "timeout"
+        if not n:
+            return "drained + 0.3 s settle"
+    return "timeout"
 
 
 def capture(fn, warmups=3, on_fail=None):
@@ -322,6 +330,7 @@ class TrainStep:
         if not self.collective or self.one_graph:
             snap = self._snapshot()
             rep = capture(self._whole, on_fail=self.state.reset)
+            self.schedule["capture_drain"] = capture.last_drain
             self._restore(snap)
             if not self._all_ranks_ok(rep is not None):
                 rep = None
@@ -482,6 +491,7 @@ class TrainStep:
                 self.state.overlap, self._split, self.state.block_grads_hook = False, None, None
                 try:
                     box["serial_rep"] = capture(self._whole, on_fail=self.state.reset)
+                    info["capture_drain"] = capture.last_drain
                     box["serial_ms"] = _time_replays(box["serial_rep"]) if box["serial_rep"] is not None else None
                 finally:
                     self.state.overlap, self._split, self.state.block_grads_hook = True, split, hook

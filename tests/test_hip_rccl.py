@@ -46,8 +46,8 @@ def test_rccl_single_rank_group_collectives_and_graph_capture_probe():
     assert res["allreduce_world"] == 1 and res["allreduce_unchanged"]
     # the wait ahead of a capture ended on an observed state ("drained": the flight recorder lists no unretired collective)
     # or, where the recorder is off, on the fixed wait ("sleep") -- never on its time-out
-    assert res.get("watchdog_drain") in ("drained", "sleep"), res
-    assert res.get("watchdog_drain_last_capture") in ("drained", "sleep"), res
+    assert str(res.get("watchdog_drain")).startswith("drained") or res.get("watchdog_drain") == "sleep", res
+    assert str(res.get("watchdog_drain_last_capture")).startswith("drained") or res.get("watchdog_drain_last_capture") == "sleep", res
     assert res["mode_collective"].startswith("hipgraph(fwd+bwd) + rccl all-reduce"), res
     assert res["collective_equals_plain"], res
     if res["graph_capture_allreduce"]:                 # recorded either way; asserted only where the stack supports it
