@@ -235,6 +235,11 @@ int stemgnn_gft_fwd(const float* mul_L, const float* X, long xs_b, long xs_n, lo
 int stemgnn_gft_bwd(const float* mul_L, const float* X, long xs_b, long xs_n, long xs_t,
                     const float* dG, float* dX, float* dmul_L, int accumulate,
                     int B, int N, int W, void* stream);
+/* d(mul_L)[1..3] of BOTH blocks as one product (written, not accumulated): the reduction runs over block 0's (b, t) range,
+ * then block 1's.  X0 / X1, dG0 / dG1 as in stemgnn_gft_bwd (reference: autograd of models/base_model.py:64, mul_L is shared
+ * by the two blocks, :172). */
+int stemgnn_gft_bwd_dt2(const float* X0, long xs0_b, long xs0_n, long xs0_t, const float* dG0, const float* X1, long xs1_b,
+                        long xs1_n, long xs1_t, const float* dG1, float* dmul_L, int B, int N, int W, void* stream);
 
 /* ---- spe_seq_cell: DFT -> 3x GLU on Re and Im (models/base_model.py:46-54, GLU :12-13) ----------
  * G = saved + offset(G) is read; GLU outputs and gates are written into `saved`. */
@@ -321,6 +326,14 @@ int stemgnn_fc_tail_train(const float* fsum, const float* target, const float* w
                           const float* b2, int B, int N, int W, int H, float* scratch, float* forecast,
                           float* loss, double* loss_accum, float* dfsum, float* dw0, float* db0, float* dw2,
                           float* db2, void* stream);
+/* The same two launches as separate calls: `_rows` = the per-row part (forecast, d(fsum), per-row-block partial sums in
+ * `scratch`), `_finish` = the fixed-order sum of the partials into loss / loss_accum / the fc gradients.  Nothing on the
+ * backward's chain reads what `_finish` writes, so a step driver may queue it on another stream; same bits as the one call. */
+int stemgnn_fc_tail_train_rows(const float* fsum, const float* target, const float* w0, const float* b0, const float* w2,
+                               const float* b2, int B, int N, int W, int H, float* scratch, float* forecast, float* dfsum,
+                               void* stream);
+int stemgnn_fc_tail_train_finish(const float* scratch, int B, int N, int W, int H, float* loss, double* loss_accum,
+                                 float* dw0, float* db0, float* dw2, float* db2, void* stream);
 /* Zero `bytes` bytes at `ptr` in stream order, as a KERNEL launch (the reference's zero_grad, models/handler.py:160, when it is
  * not fused into the optimizer kernel; control words).  The step path never uses hipMemsetAsync: inside a captured hipGraph
  * a memset node was seen to run into the kernel node that follows it. */

@@ -83,6 +83,7 @@ SIGNATURES = {
     "stemgnn_block_unpack_grads": (c_int, [_P, c_int, _P, _PP, c_int, c_int, c_int, _P]),
     "stemgnn_gft_fwd": (c_int, [_P, _P, c_long, c_long, c_long, _P, c_int, c_int, c_int, _P]),
     "stemgnn_gft_bwd": (c_int, [_P, _P, c_long, c_long, c_long, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
+    "stemgnn_gft_bwd_dt2": (c_int, [_P, c_long, c_long, c_long, _P, _P, c_long, c_long, c_long, _P, _P, c_int, c_int, c_int, _P]),
     "stemgnn_spectral_glu_fwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
     "stemgnn_spectral_glu_bwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "stemgnn_glu_split_floats": (c_size_t, [c_int, c_int, c_int]),
@@ -97,6 +98,8 @@ SIGNATURES = {
     "stemgnn_fc_tail_train_scratch_floats": (c_size_t, [c_int, c_int, c_int, c_int]),
     "stemgnn_fc_tail_train": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P,
                                       _P, _P]),
+    "stemgnn_fc_tail_train_rows": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P]),
+    "stemgnn_fc_tail_train_finish": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P]),
     "stemgnn_block_wgrad": (c_int, [_PP, _P, _P, _P, c_long, c_long, c_long, _P, c_int, _P, _P, c_int, c_int,
                                     c_int, c_int, c_int, c_int, _P]),
 }

@@ -114,6 +114,35 @@ struct GftBwdDtOp {
   }
 };
 
+// Both blocks' shares of d(mul_L) as ONE product (round 6): dT_{kq+1}[n][m] = sum over (block, b, t) of
+// dG_block[(b,n)][kq*W+t] X_block[b][m][t] -- the reduction axis is the two blocks' (b, t) ranges back to back (K = 2 B W).
+// Replaces block 1's product on the side branch + block 0's accumulating product on the chain: one launch, no fork / join
+// edge on the critical chain (~15 us of cross-queue latency at PEMS07), no read-modify-write of d(mul_L).
+struct GftBwdDt2Op {
+  const float* dG[2];    // per block: two partial slabs, `slab` floats apart
+  XView X[2];
+  float* dT;             // dmul_L slot 1
+  int B, N, W;
+  size_t slab;
+  __device__ bool setup(int, int& M, int& Nn, int& K0, int& K1) const {
+    M = 3 * N; Nn = N; K0 = 0; K1 = 2 * B * W;
+    return true;
+  }
+  __device__ float a(int, int i, int k) const {
+    const int blk = k >= B * W ? 1 : 0, kk = k - blk * B * W;
+    const int kq = i / N, n = i - kq * N, bb = kk / W, t = kk - bb * W;
+    const size_t o = ((size_t)bb * N + n) * (3 * W) + kq * W + t;
+    const float* g = dG[blk];
+    return g[o] + g[o + slab];
+  }
+  __device__ float b(int, int k, int j) const {
+    const int blk = k >= B * W ? 1 : 0, kk = k - blk * B * W;
+    const int bb = kk / W;
+    return X[blk].at(bb, j, kk - bb * W);
+  }
+  __device__ void epi(int, int i, int j, float v) const { dT[(size_t)i * N + j] = v; }
+};
+
 // =================================================================================================
 // GLU layers on the 128x128 MFMA GEMM (gemm2.h).  Epilogues:
 // =================================================================================================
@@ -495,6 +524,18 @@ extern "C" int stemgnn_gft_bwd(const float* mul_L, const float* X, long xs_b, lo
   }
   if (xs_t == 1) SG_TRY((sg_launch_gemm<GftBwdDtOp, 32, 32, true, true, false, 64, true>(op, 3 * N, N, 1, st)));
   else SG_TRY((sg_launch_gemm<GftBwdDtOp, 32, 32, true, false, false, 64, true>(op, 3 * N, N, 1, st)));
+  return 0;
+}
+
+extern "C" int stemgnn_gft_bwd_dt2(const float* X0, long xs0_b, long xs0_n, long xs0_t, const float* dG0, const float* X1,
+                                   long xs1_b, long xs1_n, long xs1_t, const float* dG1, float* dmul_L, int B, int N, int W,
+                                   void* stream) {
+  if (!X0 || !dG0 || !X1 || !dG1 || !dmul_L || B <= 0 || N <= 0 || W <= 0) return SG_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  GftBwdDt2Op op{{dG0, dG1}, {XView{X0, xs0_b, xs0_n, xs0_t, N}, XView{X1, xs1_b, xs1_n, xs1_t, N}}, dmul_L + (size_t)N * N,
+                 B, N, W, (size_t)B * N * 3 * W};
+  if (N <= 512) SG_TRY((sg_launch_gemm<GftBwdDt2Op, 32, 32, true, false, false, 128, true>(op, 3 * N, N, 1, st)));
+  else SG_TRY((sg_launch_gemm<GftBwdDt2Op, 32, 32, true, false, false, 64, true>(op, 3 * N, N, 1, st)));
   return 0;
 }
 

@@ -317,26 +317,52 @@ static size_t fc_tail_train_lds(int W, int H) {
 extern "C" size_t stemgnn_fc_tail_train_scratch_floats(int B, int N, int W, int H) {
   return (size_t)((B * N + TAIL_RB - 1) / TAIL_RB) * (W * W + W + H * W + H + 1);
 }
+static int fc_tail_train_impl(const float* fsum, const float* target, const float* w0, const float* b0, const float* w2,
+                              const float* b2, int B, int N, int W, int H, float* scratch, float* forecast, float* loss,
+                              double* loss_accum, float* dfsum, float* dw0, float* db0, float* dw2, float* db2, void* stream,
+                              int parts) {
+  if (!scratch || B <= 0 || N <= 0 || !stemgnn_fc_tail_supported(W, H) || fc_tail_train_lds(W, H) > 150 * 1024) return SG_EINVAL;
+  if ((parts & 1) && (!fsum || !target || !w0 || !b0 || !w2 || !b2 || !dfsum)) return SG_EINVAL;
+  if ((parts & 2) && (!loss || !dw0 || !db0 || !dw2 || !db2)) return SG_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const int nacc = W * W + W + H * W + H;
+  const int nblocks = (B * N + TAIL_RB - 1) / TAIL_RB;
+  if (parts & 1) {
+    const size_t lds = fc_tail_train_lds(W, H);
+    static SgDynLds lds_guard;
+    SG_TRY(sg_ensure_dyn_lds((const void*)sg_fc_tail_train_kernel, lds, lds_guard));
+    hipLaunchKernelGGL(sg_fc_tail_train_kernel, dim3(nblocks), dim3(256), lds, st, fsum, target, w0, b0, w2, b2, B, N, W, H,
+                       forecast, dfsum, scratch);
+    SG_TRY(hipGetLastError());
+  }
+  if (parts & 2) {
+    hipLaunchKernelGGL(sg_fc_tail_train_reduce_kernel, dim3((nacc + 1 + 63) / 64), dim3(256), 0, st, scratch, nblocks, W, H,
+                       1.f / ((float)B * (float)H * (float)N), dw0, db0, dw2, db2, loss, loss_accum);
+    SG_TRY(hipGetLastError());
+  }
+  return 0;
+}
 extern "C" int stemgnn_fc_tail_train(const float* fsum, const float* target, const float* w0, const float* b0, const float* w2,
                                      const float* b2, int B, int N, int W, int H, float* scratch, float* forecast,
                                      float* loss, double* loss_accum, float* dfsum, float* dw0, float* db0, float* dw2,
                                      float* db2, void* stream) {
-  if (!fsum || !target || !w0 || !b0 || !w2 || !b2 || !scratch || !loss || !dfsum || !dw0 || !db0 || !dw2 || !db2 ||
-      B <= 0 || N <= 0 || !stemgnn_fc_tail_supported(W, H) || fc_tail_train_lds(W, H) > 150 * 1024)
-    return SG_EINVAL;
-  hipStream_t st = (hipStream_t)stream;
-  const int nacc = W * W + W + H * W + H;
-  const int nblocks = (B * N + TAIL_RB - 1) / TAIL_RB;
-  const size_t lds = fc_tail_train_lds(W, H);
-  static SgDynLds lds_guard;
-  SG_TRY(sg_ensure_dyn_lds((const void*)sg_fc_tail_train_kernel, lds, lds_guard));
-  hipLaunchKernelGGL(sg_fc_tail_train_kernel, dim3(nblocks), dim3(256), lds, st, fsum, target, w0, b0, w2, b2, B, N, W, H,
-                     forecast, dfsum, scratch);
-  SG_TRY(hipGetLastError());
-  hipLaunchKernelGGL(sg_fc_tail_train_reduce_kernel, dim3((nacc + 1 + 63) / 64), dim3(256), 0, st, scratch, nblocks, W, H,
-                     1.f / ((float)B * (float)H * (float)N), dw0, db0, dw2, db2, loss, loss_accum);
-  SG_TRY(hipGetLastError());
-  return 0;
+  return fc_tail_train_impl(fsum, target, w0, b0, w2, b2, B, N, W, H, scratch, forecast, loss, loss_accum, dfsum, dw0, db0, dw2,
+                            db2, stream, 3);
+}
+// The two launches of stemgnn_fc_tail_train as separate calls (round 6): `_rows` is all the backward's chain needs (d(fsum));
+// `_finish` -- the fixed-order sum of the row blocks' partials into the loss and the fc gradients -- has no consumer before
+// the optimizer step, so a step driver may queue it on another stream (stemgnn_amd.ops: behind block 1's un-packing on the
+// side branch, under the GRU recurrence).  Same kernels, same bits as the one call.
+extern "C" int stemgnn_fc_tail_train_rows(const float* fsum, const float* target, const float* w0, const float* b0,
+                                          const float* w2, const float* b2, int B, int N, int W, int H, float* scratch,
+                                          float* forecast, float* dfsum, void* stream) {
+  return fc_tail_train_impl(fsum, target, w0, b0, w2, b2, B, N, W, H, scratch, forecast, nullptr, nullptr, dfsum, nullptr,
+                            nullptr, nullptr, nullptr, stream, 1);
+}
+extern "C" int stemgnn_fc_tail_train_finish(const float* scratch, int B, int N, int W, int H, float* loss, double* loss_accum,
+                                            float* dw0, float* db0, float* dw2, float* db2, void* stream) {
+  return fc_tail_train_impl(nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, B, N, W, H, const_cast<float*>(scratch),
+                            nullptr, loss, loss_accum, nullptr, dw0, db0, dw2, db2, stream, 2);
 }
 
 // ---- fused RMSprop over flat buffers ------------------------------------------------------------------------------

@@ -63,6 +63,8 @@ class HotPathState:
                                      # step driver's all-reduce of the block / fc gradient range (engine.TrainStep)
         self.gru_ctl = None          # int32 control words of the GRU's dW_hh product beside the recurrence (stemgnn_gru_bwd_rank2_begin
         self.gru_ctl_zeroed = False  # / _finish); True: zeroed on the side stream by this backward pass, ahead of both streams' use
+        self.tail_finish = None      # thunk(stream): the fc tail's partial-sum launch (loss, fc gradients) FcTailMse.forward left for
+                                     # SpectralHotPath.backward to queue on the side branch (nothing on the chain reads its output)
         self.side_probe = None       # a list: every kernel the step would put on the SIDE branch is also appended as a
                                      # re-issuable thunk(stream) -- engine.TrainStep's schedule self-check replays them alone to
                                      # measure the side branch's kernel-time sum (collectives and the dropout key step excluded)
@@ -94,6 +96,7 @@ class HotPathState:
         self.pending = None
         self.dh_factors = None
         self.gru_ctl_zeroed = False
+        self.tail_finish = None
 
 
 _states = weakref.WeakSet()
@@ -425,10 +428,27 @@ class FcTailMse(torch.autograd.Function):
             raise _lib.StemGNNHipError("accum must be a float64 scalar on the forecast's device")
         scratch = torch.empty(lib.stemgnn_fc_tail_train_scratch_floats(B, N, W, H), device=dev, dtype=f32)
 
-        _lib.check(lib.stemgnn_fc_tail_train(
-            fsum.data_ptr(), target.data_ptr(), w0c.data_ptr(), b0c.data_ptr(), w2c.data_ptr(), b2c.data_ptr(), B, N, W, H,
-            scratch.data_ptr(), None, loss.data_ptr(), accum.data_ptr() if accum is not None else None, dfsum.data_ptr(),
-            grads[0].data_ptr(), grads[1].data_ptr(), grads[2].data_ptr(), grads[3].data_ptr(), _stream()), "fc_tail_train")
+        acc_ptr = accum.data_ptr() if accum is not None else None
+        # direct + unit_grad + side-stream mode: the step driver promises an immediate backward with an upstream gradient of 1
+        # (engine.TrainStep) -> only the per-row launch runs here; the partial-sum launch (loss, fc gradients: no consumer
+        # before the optimizer) is left for SpectralHotPath.backward to queue on the side branch (-10 us on the chain)
+        defer = direct and ctx.state.overlap and ctx.state.tail_finish is None
+        if defer:
+            _lib.check(lib.stemgnn_fc_tail_train_rows(
+                fsum.data_ptr(), target.data_ptr(), w0c.data_ptr(), b0c.data_ptr(), w2c.data_ptr(), b2c.data_ptr(), B, N, W, H,
+                scratch.data_ptr(), None, dfsum.data_ptr(), _stream()), "fc_tail_train_rows")
+            g0, g1, g2, g3 = grads
+
+            def finish(stream, scratch=scratch, loss=loss, g0=g0, g1=g1, g2=g2, g3=g3):
+                _lib.check(lib.stemgnn_fc_tail_train_finish(scratch.data_ptr(), B, N, W, H, loss.data_ptr(), acc_ptr, g0.data_ptr(),
+                                                            g1.data_ptr(), g2.data_ptr(), g3.data_ptr(), stream),
+                           "fc_tail_train_finish")
+            ctx.state.tail_finish = finish
+        else:
+            _lib.check(lib.stemgnn_fc_tail_train(
+                fsum.data_ptr(), target.data_ptr(), w0c.data_ptr(), b0c.data_ptr(), w2c.data_ptr(), b2c.data_ptr(), B, N, W, H,
+                scratch.data_ptr(), None, loss.data_ptr(), acc_ptr, dfsum.data_ptr(),
+                grads[0].data_ptr(), grads[1].data_ptr(), grads[2].data_ptr(), grads[3].data_ptr(), _stream()), "fc_tail_train")
         # (the reduction of the per-block partials -- loss, fc gradients -- stays a launch of its own on this stream.  Measured
         # in round 4: on the side stream no gain (the cross-queue edge costs what the 9 us launch returns); as the job of the
         # LAST workgroup to arrive of the first launch, 40 us instead of 12 + 10 -- one workgroup summing 114 partials that
@@ -444,6 +464,9 @@ class FcTailMse(torch.autograd.Function):
     def backward(ctx, grad_loss):
         dfsum, grads = ctx.held
         ctx.held = None
+        if ctx.state.tail_finish is not None and not ctx.state.overlap:      # the mode changed between forward and backward
+            fin, ctx.state.tail_finish = ctx.state.tail_finish, None
+            fin(_stream())
         if not ctx.unit_grad:
             dfsum = dfsum * grad_loss
             if grads is not None:
@@ -748,6 +771,7 @@ class SpectralHotPath(torch.autograd.Function):
         dev, f32 = x.device, torch.float32
         st = _stream()
         dfsum = dfsum.contiguous()
+        tail_finish, state.tail_finish = state.tail_finish, None     # FcTailMse.forward's deferred partial-sum launch
         nsplit = _NSPLIT
         n_scratch = lib.stemgnn_scratch_floats(B, N, W, multi)
         off_dG = lib.stemgnn_scratch_offset_dG(B, N, W, multi)
@@ -775,6 +799,9 @@ class SpectralHotPath(torch.autograd.Function):
         side = _side_stream(dev) if overlap else None
         main = torch.cuda.current_stream()
         keep = []
+        if tail_finish is not None and not overlap:
+            tail_finish(st)
+            tail_finish = None
         # Scheduling of the weight-gradient work (heads + GLU weight-gradient GEMMs + un-packing), which feeds nothing
         # downstream in the backward pass.  overlap: both blocks' weight gradients go to the side stream, block 0's
         # first (it overlaps the cheb / attention chain), then block 1's, which then runs under the GRU recurrence
@@ -836,6 +863,12 @@ class SpectralHotPath(torch.autograd.Function):
         # Capture order matters inside the hipGraph step: at a fork the FIRST captured successor of a node stays on its
         # queue, every later one moves to another queue behind a cross-queue edge (~10 us).  So at every fork the main
         # stream's next kernel (the critical chain) is queued before the side stream's work that forks at the same node.
+        # Block 1's share of d(mul_L): round 6 -- ONE product for both blocks behind block 0's data-gradient chain
+        # (stemgnn_gft_bwd_dt2, K = the two blocks' (b, t) ranges back to back) instead of block 1's product on the side branch +
+        # block 0's accumulating product on the chain: the fork behind block 1's dX product and the join ahead of block 0's
+        # product were ~15 us of cross-queue latency on the critical chain.  The round-4 form stays where the side branch needs
+        # its edge into the chain anyway (the opt-in dW_hh product beside the recurrence zeroes its control words there).
+        legacy_dt1 = overlap and ctx.factored and bool(lib.stemgnn_gru_bwd_overlap_ok(B, N, N, W))
         dt1 = None
         for s in (1, 0):
             scratch = bufs[s][0]
@@ -843,7 +876,7 @@ class SpectralHotPath(torch.autograd.Function):
             X, sb, sn, stt = xviews[s]
             heads, glu, wgrad, unpack = stage_fns(s)
             heads(st)
-            if dt1 is not None:
+            if dt1 is not None and legacy_dt1:
                 # block 1's share of d(mul_L) is needed by the Chebyshev backward only, 100+ us later -> side stream, beside
                 # block 0's heads / GLU data gradients (forked behind block 1's dX product, queued behind block 0's heads)
                 X1, sb1, sn1, stt1, dG1, dx_done = dt1
@@ -855,12 +888,11 @@ class SpectralHotPath(torch.autograd.Function):
                     # control words of the GRU's dW_hh product beside the recurrence: zeroed HERE, ahead of a side -> main edge
                     # the step has anyway (dt1_done), so that the side launch needs no parent on the main branch (inside a
                     # captured graph such a parent makes it wait for the whole recurrence: include/stemgnn_hip.h)
-                    if ctx.factored and bool(lib.stemgnn_gru_bwd_overlap_ok(B, N, N, W)):
-                        nctl = lib.stemgnn_gru_bwd_ctl_words(N)
-                        if state.gru_ctl is None or state.gru_ctl.numel() != nctl or state.gru_ctl.device != dev:
-                            state.gru_ctl = torch.zeros(nctl, device=dev, dtype=torch.int32)
-                        _lib.check(lib.stemgnn_fill_zero(state.gru_ctl.data_ptr(), 4 * nctl, side.cuda_stream), "fill_zero")
-                        state.gru_ctl_zeroed = True
+                    nctl = lib.stemgnn_gru_bwd_ctl_words(N)
+                    if state.gru_ctl is None or state.gru_ctl.numel() != nctl or state.gru_ctl.device != dev:
+                        state.gru_ctl = torch.zeros(nctl, device=dev, dtype=torch.int32)
+                    _lib.check(lib.stemgnn_fill_zero(state.gru_ctl.data_ptr(), 4 * nctl, side.cuda_stream), "fill_zero")
+                    state.gru_ctl_zeroed = True
                     dT1(side.cuda_stream)
                     dt1_done = torch.cuda.Event()
                     dt1_done.record(side)
@@ -877,15 +909,22 @@ class SpectralHotPath(torch.autograd.Function):
                 # block 1: only its data gradient (-> dbackcast) feeds block 0's backward
                 _lib.check(lib.stemgnn_gft_bwd(mul_L.data_ptr(), X.data_ptr(), sb, sn, stt, dG.data_ptr(),
                                                dbackcast.data_ptr(), None, 0, B, N, W, st), "gft_bwd dX")
-                dx_done = torch.cuda.Event()
-                dx_done.record(main)
+                dx_done = None
+                if legacy_dt1:
+                    dx_done = torch.cuda.Event()
+                    dx_done.record(main)
                 dt1 = (X, sb, sn, stt, dG, dx_done)
             else:
                 fork = torch.cuda.Event()                # every data-gradient chain is queued
                 fork.record(main)
-                main.wait_event(dt1_done)                # block 0's product accumulates onto block 1's
-                _lib.check(lib.stemgnn_gft_bwd(mul_L.data_ptr(), X.data_ptr(), sb, sn, stt, dG.data_ptr(), None,
-                                               dmul_L.data_ptr(), 1, B, N, W, st), "gft_bwd")
+                if legacy_dt1:
+                    main.wait_event(dt1_done)            # block 0's product accumulates onto block 1's
+                    _lib.check(lib.stemgnn_gft_bwd(mul_L.data_ptr(), X.data_ptr(), sb, sn, stt, dG.data_ptr(), None,
+                                                   dmul_L.data_ptr(), 1, B, N, W, st), "gft_bwd")
+                else:
+                    X1, sb1, sn1, stt1, dG1, _ = dt1
+                    _lib.check(lib.stemgnn_gft_bwd_dt2(X.data_ptr(), sb, sn, stt, dG.data_ptr(), X1.data_ptr(), sb1, sn1, stt1,
+                                                       dG1.data_ptr(), dmul_L.data_ptr(), B, N, W, st), "gft_bwd_dt2")
                 side.wait_event(fork)
                 with torch.cuda.stream(side):
                     sst = side.cuda_stream
@@ -896,6 +935,11 @@ class SpectralHotPath(torch.autograd.Function):
                         if state.side_probe is not None:
                             state.side_probe.append(lambda stream, w2=w2, pc=_wg_cu(ss, B, N): w2(stream, pc))
                             state.side_probe.append(u2)
+                    if tail_finish is not None:          # loss + fc gradients: ahead of the hook (fc is part of its range)
+                        tail_finish(sst)
+                        keep.append(tail_finish)         # its buffers stay alive until the join
+                        if state.side_probe is not None:
+                            state.side_probe.append(tail_finish)
                     if state.block_grads_hook is not None:
                         state.block_grads_hook()         # data-parallel: reduce the finished range under the GRU recurrence
                 keep.append(bufs)                        # alive until the join
