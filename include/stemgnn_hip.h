@@ -214,6 +214,11 @@ int stemgnn_gru_bwd_rank2_finish(const float* dkey, const float* dquery, const f
  * (host array). */
 int stemgnn_block_pack(const float* const* params_host, const float* tables, float* packed,
                        int W, int multi, void* stream);
+/* The pair panels, biases and the folded graph-conv weight only -- without the two fp32 stage streams of the fused fp32
+ * kernels (stemgnn_glu_fused_repack writes those).  For a caller whose GLU forward / data gradients run on the split-bf16
+ * kernels (stemgnn_glu_split_panels packs THEIR streams from the panels): nothing would read the fp32 streams. */
+int stemgnn_block_pack_panels(const float* const* params_host, const float* tables, float* packed, int W, int multi,
+                              void* stream);
 /* The GLU weights of `packed` once more as the stage stream of the fused three-layer forward (csrc/glu_fused.h), written
  * behind the panels inside the same buffer; stemgnn_block_pack calls it (exported for callers that fill the panels
  * themselves).  No-op for (W, multi) the fused kernel does not cover (padded channel count 4 W multi > 256). */

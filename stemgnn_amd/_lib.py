@@ -80,6 +80,7 @@ SIGNATURES = {
     "stemgnn_eval_out_doubles": (c_size_t, [c_int, c_int]),
     "stemgnn_eval_metrics": (c_int, [_P, _P, _P, _P, c_long, c_int, c_int, _P, _P, _P]),
     "stemgnn_block_pack": (c_int, [_PP, _P, _P, c_int, c_int, _P]),
+    "stemgnn_block_pack_panels": (c_int, [_PP, _P, _P, c_int, c_int, _P]),
     "stemgnn_block_unpack_grads": (c_int, [_P, c_int, _P, _PP, c_int, c_int, c_int, _P]),
     "stemgnn_gft_fwd": (c_int, [_P, _P, c_long, c_long, c_long, _P, c_int, c_int, c_int, _P]),
     "stemgnn_gft_bwd": (c_int, [_P, _P, c_long, c_long, c_long, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),

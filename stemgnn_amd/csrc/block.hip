@@ -658,8 +658,11 @@ extern "C" int stemgnn_glu_split_panels(const float* packed, float* split, int W
   unsigned short* base = reinterpret_cast<unsigned short*>(split);
   hipStream_t st = (hipStream_t)stream;
   const GbGeom gb = gb_geom(d);
-  const bool fused = splits == 2 && gb.ok && gq_geom(d).ok && gb_enabled();   // both fused forms read their own streams; nothing reads the planes
-  for (int r = 0; r < 2 && !fused; ++r)
+  // The per-layer plane sets are written ALWAYS (round 6; round 5 skipped them where both fused bf16 forms apply): the
+  // data-gradient entry falls back to the per-layer split kernels when its scratch is not 16-byte aligned or STEMGNN_GLU_FUSED
+  // is flipped between this call and the use (it is read per call), and those kernels must never read plane sets that were
+  // not written.  Four small launches on the side branch under the GRU forward: off the critical path.
+  for (int r = 0; r < 2; ++r)
     for (int l = 1; l < 3; ++l) {
       const int kin = sg_glu_kin(d, l), np = sg_glu_np(d, l, r);
       const size_t n = (size_t)g2s_pad32(kin) * g2s_pad32(np);

@@ -151,8 +151,8 @@ __global__ void sg_pack_kernel(SgBlockParams prm, const float* __restrict__ tab,
     }
 }
 
-extern "C" int stemgnn_block_pack(const float* const* params_host, const float* tables, float* packed, int W,
-                                  int multi, void* stream) {
+extern "C" int stemgnn_block_pack_panels(const float* const* params_host, const float* tables, float* packed, int W,
+                                         int multi, void* stream) {
   if (!params_host || !tables || !packed || W <= 0 || multi <= 0) return SG_EINVAL;
   SgBlockParams prm;
   for (int i = 0; i < SG_BLOCK_NPARAMS; ++i) prm.p[i] = params_host[i];
@@ -164,6 +164,12 @@ extern "C" int stemgnn_block_pack(const float* const* params_host, const float* 
   const unsigned blocks = (unsigned)((P.total + 255) / 256);
   hipLaunchKernelGGL(sg_pack_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, prm, tables, packed, d, P, T);
   SG_TRY(hipGetLastError());
+  return 0;
+}
+extern "C" int stemgnn_block_pack(const float* const* params_host, const float* tables, float* packed, int W,
+                                  int multi, void* stream) {
+  const int rc = stemgnn_block_pack_panels(params_host, tables, packed, W, multi, stream);
+  if (rc) return rc;
   return stemgnn_glu_fused_repack(packed, W, multi, stream);
 }
 

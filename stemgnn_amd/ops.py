@@ -180,6 +180,16 @@ def glu_splits():
     raise _lib.StemGNNHipError(f"STEMGNN_DTYPE={v!r}: expected f32, bf16x3 or bf16x2")
 
 
+def _pack_block(lib, parr, tables, pk, W, multi, splits, stream):
+    """Pack one block's weights for the arithmetic the GLU products will run in: exact fp32 -> panels + the fp32 stage streams of
+    the fused kernels (stemgnn_block_pack); split-bf16 -> the panels only (stemgnn_block_pack_panels; _split_panels packs the
+    bf16 streams from them and nothing reads the fp32 streams: two dead launches and ~35 MB of writes per step in round 5)."""
+    if splits:
+        _lib.check(lib.stemgnn_block_pack_panels(parr, tables.data_ptr(), pk.data_ptr(), W, multi, stream), "block_pack_panels")
+    else:
+        _lib.check(lib.stemgnn_block_pack(parr, tables.data_ptr(), pk.data_ptr(), W, multi, stream), "block_pack")
+
+
 def _split_panels(lib, pk, W, multi, splits, device, stream):
     sp = torch.empty(lib.stemgnn_glu_split_floats(W, multi, splits), device=device, dtype=torch.float32)
     _lib.check(lib.stemgnn_glu_split_panels(pk.data_ptr(), sp.data_ptr(), W, multi, splits, stream), "glu_split_panels")
@@ -646,7 +656,7 @@ def prepack_blocks(state, block_params, W, multi, device):
         parr = _lib.ptr_array(blk)
 
         def pack(stream, parr=parr, pk=pk, blk=blk):
-            _lib.check(lib.stemgnn_block_pack(parr, tables.data_ptr(), pk.data_ptr(), W, multi, stream), "block_pack")
+            _pack_block(lib, parr, tables, pk, W, multi, splits, stream)
         pack(side.cuda_stream)
         if state.side_probe is not None:
             state.side_probe.append(pack)
@@ -734,7 +744,7 @@ class SpectralHotPath(torch.autograd.Function):
                 sp = pre[3][1][s] if splits else None
             else:
                 pk = torch.empty(n_packed, device=dev, dtype=f32)
-                _lib.check(lib.stemgnn_block_pack(parr, tables.data_ptr(), pk.data_ptr(), W, multi, st), "block_pack")
+                _pack_block(lib, parr, tables, pk, W, multi, splits, st)
                 if splits:
                     sp = _split_panels(lib, pk, W, multi, splits, dev, st)
             _lib.check(lib.stemgnn_gft_fwd(mul_L.data_ptr(), X.data_ptr(), sb, sn, stt, sv.data_ptr(), B, N, W, st),
