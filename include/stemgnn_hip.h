@@ -269,6 +269,14 @@ size_t stemgnn_glu_split_floats(int W, int multi, int splits);
 int stemgnn_glu_split_panels(const float* packed, float* split, int W, int multi, int splits, void* stream);
 int stemgnn_spectral_glu_fwd_split(const float* packed, const float* split, float* saved, int B, int N, int W, int multi,
                                    int splits, void* stream);
+/* Warm-up of the fused forward: the same kernel instance the real launch of a [B, N] batch gets, over four row blocks (eight
+ * workgroups, one per XCD and branch), writing into a caller-owned dummy `saved` of stemgnn_glu_warm_saved_floats floats whose
+ * G region holds any finite values.  splits = 0: the fp32 kernel (`split` ignored), 2: the split-bf16 kernel.  Brings the
+ * kernel's code and block's weight stream into the XCDs' L2 ahead of the first real launch of a step (-10 us at PEMS07); a
+ * no-op returning 0 where the fused kernels do not apply. */
+size_t stemgnn_glu_warm_saved_floats(int W, int multi);
+int stemgnn_spectral_glu_fwd_warm(const float* packed, const float* split, float* saved, int B, int N, int W, int multi,
+                                  int splits, void* stream);
 int stemgnn_spectral_glu_dgrad_split(const float* packed, const float* split, const float* saved, float* scratch,
                                      int B, int N, int W, int multi, int splits, void* stream);
 /* Round 5: with splits == 2 and a padded channel count 4 W multi <= 256 (every BASELINE configuration but configs[4])

@@ -91,6 +91,8 @@ SIGNATURES = {
     "stemgnn_glu_split_panels": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
     "stemgnn_glu_fused_bf16_ok": (c_int, [c_int, c_int, c_int]),
     "stemgnn_spectral_glu_fwd_split": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+    "stemgnn_glu_warm_saved_floats": (c_size_t, [c_int, c_int]),
+    "stemgnn_spectral_glu_fwd_warm": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "stemgnn_spectral_glu_dgrad_split": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "stemgnn_igft_heads_fwd": (c_int, [_PP, _P, _P, _P, c_long, c_long, c_long, _P, c_int, _P,
                                        c_int, c_int, c_int, c_int, _P]),

@@ -166,7 +166,7 @@ class Model(nn.Module):
         return out
 
     # -- forward --------------------------------------------------------------------------------------
-    def prefetch_side(self, device=None):
+    def prefetch_side(self, device=None, batch=None):
         """Side-stream mode: queue the weight packing and the dropout-stream bookkeeping (a clone and an increment) on the
         side stream NOW, forked from the current stream's position.  hot_path() calls it itself; a step driver
         (engine.TrainStep) calls it before its first kernel of the step, so that the fork does not hang off that kernel:
@@ -177,7 +177,8 @@ class Model(nn.Module):
             return
         device = device or self.weight_key.device
         blocks = (self.stock_block[0].hip_params(), self.stock_block[1].hip_params())
-        ops.prepack_blocks(hs, blocks, self.time_step, self.multi_layer, device)
+        ops.prepack_blocks(hs, blocks, self.time_step, self.multi_layer, device,
+                           batch_shape=None if batch is None else (int(batch), self.unit))
         if self.training and self.dropout_rate > 0.0:
             with torch.cuda.stream(ops._side_stream(device)):
                 hs.preseed = self._next_seed(device)
@@ -197,7 +198,7 @@ class Model(nn.Module):
         use_drop = self.training and self.dropout_rate > 0.0
         hs = self.hot_state
         if hs.overlap and hs.prepacked is None:
-            self.prefetch_side(x.device)
+            self.prefetch_side(x.device, batch=x.shape[0])
         seed, hs.preseed = hs.preseed, None
         if seed is not None and not torch.cuda.is_current_stream_capturing():
             seed.record_stream(torch.cuda.current_stream())

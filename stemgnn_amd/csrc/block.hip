@@ -539,8 +539,10 @@ extern "C" int stemgnn_gft_bwd_dt2(const float* X0, long xs0_b, long xs0_n, long
   return 0;
 }
 
-extern "C" int stemgnn_spectral_glu_fwd(const float* packed, float* saved, int B, int N, int W, int multi,
-                                        void* stream) {
+// m_pick: the row count the block height (64 / 96 rows) is chosen for -- d.M itself, or the REAL launch's row count when this
+// call is its warm-up (stemgnn_spectral_glu_fwd_warm); fused_only: do nothing where the fused kernel does not apply
+static int glu_fwd_impl(const float* packed, float* saved, int B, int N, int W, int multi, void* stream, int m_pick,
+                        bool fused_only) {
   if (!packed || !saved || B <= 0 || N <= 0 || W <= 0 || multi <= 0) return SG_EINVAL;
   const SgDims d = sg_dims(B, N, W, multi);
   const SgPackedLayout P = sg_packed_layout(d);
@@ -553,7 +555,8 @@ extern "C" int stemgnn_spectral_glu_fwd(const float* packed, float* saved, int B
   const char* ef = getenv("STEMGNN_GLU_FUSED");
   const int fmode = ef ? atoi(ef) : 1;                  // 0 off, 1 auto, 2 / 3: force 64- / 96-row workgroups (tests)
   if (gg.ok && fmode != 0 && (((uintptr_t)packed) & 15) == 0) {
-    const int mt = fmode == 3 && gg.ok3 ? 3 : (fmode == 2 ? 2 : gf_pick_mt(d.M, sg_num_cus(), gg.ok3));
+    const int mt = fmode == 3 && gg.ok3 ? 3 : (fmode == 2 ? 2 : gf_pick_mt(m_pick > 0 ? m_pick : d.M, sg_num_cus(), gg.ok3));
+    if (fused_only && d.M != 4 * 32 * mt) return SG_EINVAL;
     GfArgs a;
     a.G = saved + S.G; a.KG = d.KG; a.KP0 = gg.kp[0]; a.KA = gg.KA; a.M = d.M; a.ns = gg.ns;
     a.nrb = (d.M + 32 * mt - 1) / (32 * mt);
@@ -588,6 +591,7 @@ extern "C" int stemgnn_spectral_glu_fwd(const float* packed, float* saved, int B
     SG_TRY(hipGetLastError());
     return 0;
   }
+  if (fused_only) return 0;
   for (int l = 0; l < 3; ++l) {
     G2Args g;
     GluFwdEpi e;
@@ -609,6 +613,11 @@ extern "C" int stemgnn_spectral_glu_fwd(const float* packed, float* saved, int B
   return 0;
 }
 
+extern "C" int stemgnn_spectral_glu_fwd(const float* packed, float* saved, int B, int N, int W, int multi,
+                                        void* stream) {
+  return glu_fwd_impl(packed, saved, B, N, W, multi, stream, 0, false);
+}
+
 // ---- split-bf16 variant of the GLU forward / data-gradient layers (STEMGNN_DTYPE=bf16x3 | bf16x2, csrc/gemm2s.h) ------
 // Split-plane buffer of one StockBlock (caller-owned, stemgnn_glu_split_floats floats): for (r, l = 1, 2) plane set D
 // [S][kin][pad32(np)] then plane set F [S][np][pad32(kin)], bf16, each set 16-byte aligned.  Layer 0 (K = 3W) and the
@@ -618,6 +627,8 @@ struct G2SLayout {
   size_t FS[2];                       // S == 2: pre-split stage stream of the fused bf16 forward (csrc/glu_fused_bf16.h), per branch
   size_t DS[2];                       // S == 2: ... and of the fused bf16 data-gradient chain
 };
+// 1 while the most recent stemgnn_glu_split_panels call of this process left the per-layer plane sets unwritten (fused-only pack)
+static std::atomic<int> g_planes_skipped{0};
 static inline bool gb_enabled() {     // STEMGNN_GLU_FUSED=0 keeps the per-layer split launches (read per call)
   const char* ef = getenv("STEMGNN_GLU_FUSED");
   return !ef || atoi(ef) != 0;
@@ -658,11 +669,13 @@ extern "C" int stemgnn_glu_split_panels(const float* packed, float* split, int W
   unsigned short* base = reinterpret_cast<unsigned short*>(split);
   hipStream_t st = (hipStream_t)stream;
   const GbGeom gb = gb_geom(d);
-  // The per-layer plane sets are written ALWAYS (round 6; round 5 skipped them where both fused bf16 forms apply): the
-  // data-gradient entry falls back to the per-layer split kernels when its scratch is not 16-byte aligned or STEMGNN_GLU_FUSED
-  // is flipped between this call and the use (it is read per call), and those kernels must never read plane sets that were
-  // not written.  Four small launches on the side branch under the GRU forward: off the critical path.
-  for (int r = 0; r < 2; ++r)
+  // Both fused forms read their own streams, nothing reads the per-layer plane sets then: they are not written (8 small
+  // launches per step beside the GRU forward, measured +10 us on that recurrence in round 6).  What packed the buffer is
+  // remembered (g_planes_skipped) so that the per-layer entry points REFUSE to run on plane sets that were never written
+  // (STEMGNN_GLU_FUSED flipped between pack and use, or a misaligned scratch, used to read garbage silently).
+  const bool fused = splits == 2 && gb.ok && gq_geom(d).ok && gb_enabled();
+  g_planes_skipped.store(fused ? 1 : 0, std::memory_order_relaxed);
+  for (int r = 0; r < 2 && !fused; ++r)
     for (int l = 1; l < 3; ++l) {
       const int kin = sg_glu_kin(d, l), np = sg_glu_np(d, l, r);
       const size_t n = (size_t)g2s_pad32(kin) * g2s_pad32(np);
@@ -749,6 +762,7 @@ extern "C" int stemgnn_spectral_glu_fwd_split(const float* packed, const float* 
     SG_TRY(hipGetLastError());
     return 0;
   }
+  if (splits == 2 && g_planes_skipped.load(std::memory_order_relaxed) && gb.ok && gq_geom(d).ok) return SG_EINVAL;   // see dgrad_split
   for (int l = 0; l < 3; ++l) {
     G2Args g;
     G2SArgs gs;
@@ -775,6 +789,35 @@ extern "C" int stemgnn_spectral_glu_fwd_split(const float* packed, const float* 
     else SG_TRY((g2_launch<GluFwdEpi, true, false, 64>(g, e, 2, st)));
   }
   return 0;
+}
+
+// Warm-up of the fused forward (round 6).  The FIRST launch of the fused three-layer kernel in a step runs ~12 us longer than
+// the second (81.7 against 69.3 us at PEMS07, same kernel, same shape): its ~100 KB of straight-line code and the weight
+// stream come from HBM, the second launch finds them in the XCDs' L2.  This entry runs the SAME kernel instance the real
+// launch of a [B, N] batch will get over four row blocks (one workgroup per XCD and branch -- eight CUs), on a caller-owned
+// dummy `saved` of stemgnn_glu_warm_saved_floats floats (its G region is read: any finite content); a step driver queues it on
+// the side branch under the GRU recurrence, which leaves those CUs idle.  No-op (0) where the fused kernel does not apply.
+// Measured: 1.201 -> 1.191 ms per step (profiles/r06_fused_warmup_ab.txt); warming block 1's weights or the data-gradient
+// kernel as well adds nothing (the code is what was cold; the chain's kernel runs 300 us later, behind 160 MB of stores).
+extern "C" size_t stemgnn_glu_warm_saved_floats(int W, int multi) {
+  if (W <= 0 || multi <= 0) return 0;
+  return stemgnn_saved_floats(1, 4 * 96, W, multi);
+}
+extern "C" int stemgnn_spectral_glu_fwd_warm(const float* packed, const float* split, float* saved, int B, int N, int W,
+                                             int multi, int splits, void* stream) {
+  if (!packed || !saved || B <= 0 || N <= 0 || W <= 0 || multi <= 0 || (splits != 0 && splits != 2) || (splits && !split))
+    return SG_EINVAL;
+  if (splits == 2) {
+    if (!stemgnn_glu_fused_bf16_ok(W, multi, 2)) return 0;
+    return stemgnn_spectral_glu_fwd_split(packed, split, saved, 1, 4 * GB_BM, W, multi, 2, stream);
+  }
+  const SgDims d = sg_dims(B, N, W, multi);
+  const GfGeom gg = gf_geom(d);
+  const char* ef = getenv("STEMGNN_GLU_FUSED");
+  const int fmode = ef ? atoi(ef) : 1;
+  if (!gg.ok || fmode == 0 || (((uintptr_t)packed) & 15) != 0) return 0;
+  const int mt = fmode == 3 && gg.ok3 ? 3 : (fmode == 2 ? 2 : gf_pick_mt(d.M, sg_num_cus(), gg.ok3));
+  return glu_fwd_impl(packed, saved, 1, 4 * 32 * mt, W, multi, stream, d.M, true);
 }
 
 // data-gradient chain of the three GLU layers (= stemgnn_spectral_glu_bwd with parts = 1) with the two d(pre-activation)
@@ -817,6 +860,10 @@ extern "C" int stemgnn_spectral_glu_dgrad_split(const float* packed, const float
     SG_TRY(hipGetLastError());
     return 0;
   }
+  // per-layer split kernels: they read the plane sets stemgnn_glu_split_panels writes -- unless that call packed for the fused
+  // forms only (both fused forms apply to this shape and STEMGNN_GLU_FUSED was on THEN).  Getting here with a fused-only
+  // buffer means the switch was flipped between the pack and this call, or `scratch` is not 16-byte aligned: refuse.
+  if (splits == 2 && g_planes_skipped.load(std::memory_order_relaxed) && gb_geom(d).ok && gq.ok) return SG_EINVAL;
   for (int l = 2; l >= 1; --l) {
     G2Args g;
     G2SArgs gs;

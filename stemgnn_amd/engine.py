@@ -243,7 +243,7 @@ class TrainStep:
             else:
                 ops.window_gather(self.series, hi, self.W, self.H, x, y)
         if early:
-            self.model.prefetch_side(self.device)
+            self.model.prefetch_side(self.device, batch=x.shape[0])
         if not self.fuse_zero:
             if self.bucket is not None:
                 self.bucket.zero()

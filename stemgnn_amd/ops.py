@@ -63,6 +63,7 @@ class HotPathState:
                                      # step driver's all-reduce of the block / fc gradient range (engine.TrainStep)
         self.gru_ctl = None          # int32 control words of the GRU's dW_hh product beside the recurrence (stemgnn_gru_bwd_rank2_begin
         self.gru_ctl_zeroed = False  # / _finish); True: zeroed on the side stream by this backward pass, ahead of both streams' use
+        self.warm_saved = None       # dummy saved-activation buffer of the fused forward's warm-up launch (prepack_blocks)
         self.tail_finish = None      # thunk(stream): the fc tail's partial-sum launch (loss, fc gradients) FcTailMse.forward left for
                                      # SpectralHotPath.backward to queue on the side branch (nothing on the chain reads its output)
         self.side_probe = None       # a list: every kernel the step would put on the SIDE branch is also appended as a
@@ -635,10 +636,11 @@ def last_attention_state(device):
     return _last_attention_state.get(str(torch.device(device)))
 
 
-def prepack_blocks(state, block_params, W, multi, device):
+def prepack_blocks(state, block_params, W, multi, device, batch_shape=None):
     """Pack both blocks' weights (stemgnn_block_pack) on the side stream now, so that they overlap whatever the
     caller queues next on the current stream (Model.hot_path: the GRU recurrence).  The next SpectralHotPath.forward
-    on this device picks the packed panels up and joins the side stream."""
+    on this device picks the packed panels up and joins the side stream.  batch_shape = (B, N) of the coming forward, when the
+    caller knows it: the fused forward is warmed for that shape behind the packing."""
     lib = _lib.load()
     side, main = _side_stream(device), torch.cuda.current_stream()
     tables = dft_tables(W, multi, device)
@@ -662,6 +664,17 @@ def prepack_blocks(state, block_params, W, multi, device):
             state.side_probe.append(pack)
         if splits:      # (allocated on the current stream like the packed panels; the side stream only runs the kernel)
             split.append(_split_panels(lib, pk, W, multi, splits, device, side.cuda_stream))
+    # warm-up of the fused GLU forward (stemgnn_spectral_glu_fwd_warm): the kernel's code and block 0's weight stream into the
+    # XCDs' L2 on eight CUs the GRU recurrence leaves idle; the first real launch of the step is ~10 us shorter for it
+    # (exact fp32 only: the split-bf16 kernel is a third of the size and shows no first-launch penalty -- 38.1 / 37.6 us for the
+    # two blocks -- while every extra launch beside the GRU forward costs that recurrence time: 219 -> 231 us with eight more)
+    if batch_shape is not None and splits == 0 and os.environ.get("STEMGNN_GLU_WARM", "1") != "0":
+        nwarm = lib.stemgnn_glu_warm_saved_floats(W, multi)
+        if state.warm_saved is None or state.warm_saved.numel() != nwarm or state.warm_saved.device != torch.device(device):
+            state.warm_saved = torch.zeros(nwarm, device=device, dtype=torch.float32)
+        _lib.check(lib.stemgnn_spectral_glu_fwd_warm(packed[0].data_ptr(), split[0].data_ptr() if splits else None,
+                                                     state.warm_saved.data_ptr(), batch_shape[0], batch_shape[1], W, multi,
+                                                     splits, side.cuda_stream), "spectral_glu_fwd_warm")
     state.prepacked = (packed, side, blocks, (splits, split))
 
 

@@ -181,3 +181,40 @@ def test_fused_bf16_data_gradient_chain_matches_the_fp32_chain(N, W, multi, B):
         off += n
     print(f"N={N} W={W} multi={multi} B={B}: fused bf16x2 data-gradient chain vs fp32, worst strip {worst:.2e}")
     assert worst < 1e-4
+
+
+def test_per_layer_split_entries_refuse_a_fused_only_buffer(monkeypatch):
+    """stemgnn_glu_split_panels skips the per-layer plane sets where both fused bf16 forms apply; if
+    STEMGNN_GLU_FUSED is then flipped before the use (it is read per call) or the chain's scratch is not 16-byte aligned,
+    the per-layer kernels would read planes nobody wrote.  They refuse (SG_EINVAL) instead; after a pack in per-layer mode
+    the same calls run."""
+    from stemgnn_amd import _lib, ops
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    N, W, multi, B = 33, 12, 5, 5
+    assert lib.stemgnn_glu_fused_bf16_ok(W, multi, 2)
+    g = torch.Generator().manual_seed(5)
+    packed = (torch.randn(lib.stemgnn_packed_floats(W, multi), generator=g) * 0.08).to(dev)
+    st = torch.cuda.current_stream().cuda_stream
+    split = torch.empty(lib.stemgnn_glu_split_floats(W, multi, 2), device=dev)
+    saved = torch.rand(lib.stemgnn_saved_floats(B, N, W, multi), generator=g).to(dev)
+    scratch = (torch.randn(lib.stemgnn_scratch_floats(B, N, W, multi) + 4, generator=g) * 0.1).to(dev)
+    monkeypatch.delenv("STEMGNN_GLU_FUSED", raising=False)
+    _lib.check(lib.stemgnn_glu_split_panels(packed.data_ptr(), split.data_ptr(), W, multi, 2, st), "split_panels")       # fused-only pack
+    # (a) misaligned scratch: the fused chain cannot take it, the per-layer kernels have no planes
+    assert lib.stemgnn_spectral_glu_dgrad_split(packed.data_ptr(), split.data_ptr(), saved.data_ptr(), scratch.data_ptr() + 4,
+                                                B, N, W, multi, 2, st) == _lib.SG_EINVAL
+    # (b) the switch flipped between pack and use
+    monkeypatch.setenv("STEMGNN_GLU_FUSED", "0")
+    assert lib.stemgnn_spectral_glu_dgrad_split(packed.data_ptr(), split.data_ptr(), saved.data_ptr(), scratch.data_ptr(),
+                                                B, N, W, multi, 2, st) == _lib.SG_EINVAL
+    assert lib.stemgnn_spectral_glu_fwd_split(packed.data_ptr(), split.data_ptr(), saved.data_ptr(), B, N, W, multi, 2,
+                                              st) == _lib.SG_EINVAL
+    # packed again in per-layer mode: the planes exist, the same calls run
+    _lib.check(lib.stemgnn_glu_split_panels(packed.data_ptr(), split.data_ptr(), W, multi, 2, st), "split_panels")
+    _lib.check(lib.stemgnn_spectral_glu_fwd_split(packed.data_ptr(), split.data_ptr(), saved.data_ptr(), B, N, W, multi, 2, st),
+               "per-layer forward")
+    _lib.check(lib.stemgnn_spectral_glu_dgrad_split(packed.data_ptr(), split.data_ptr(), saved.data_ptr(), scratch.data_ptr(),
+                                                    B, N, W, multi, 2, st), "per-layer chain")
+    torch.cuda.synchronize()
+    assert torch.isfinite(saved).all()
