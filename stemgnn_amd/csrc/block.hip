@@ -30,6 +30,23 @@
 // every output element, where the libm expf + IEEE divide (~50 VALU instructions) cost ~25 % of the whole GEMM
 __device__ __forceinline__ float sg_sigmoid(float v) { return __frcp_rn(1.f + __expf(-v)); }
 
+// x / d and x % d for a divisor fixed per launch (N, W: runtime values, so `/` compiles to the ~40-instruction software division;
+// the operand loaders of the small graph products decompose two or three indices PER ELEMENT and were VALU-bound on exactly
+// that, round 6).  q = mulhi(x, magic), magic = floor(2^32 / d) + 1: exact for 0 <= x with x * d < 2^32 (the launchers check).
+struct SgDiv {
+  unsigned d, magic;
+  __device__ __forceinline__ int div(int x) const { return d == 1u ? x : (int)__umulhi((unsigned)x, magic); }
+  __device__ __forceinline__ void divmod(int x, int& q, int& r) const { q = div(x); r = x - q * (int)d; }
+};
+static inline SgDiv sg_div(int d) {
+  SgDiv v;
+  v.d = (unsigned)d;
+  v.magic = d > 1 ? (unsigned)((1ull << 32) / (unsigned)d + 1ull) : 0u;
+  return v;
+}
+// the largest x the ops of a launch divide (row / column / reduction indices incl. the tile padding), against x * d < 2^32
+static inline bool sg_div_ok(long xmax, int d) { return d >= 1 && xmax >= 0 && (unsigned long long)xmax * (unsigned)d < (1ull << 32); }
+
 // generic strided view of the block input X[b, n, t]
 struct XView {
   const float* p;
@@ -50,17 +67,21 @@ struct GftFwdOp {
   XView X;
   float* G;
   int B, N, W;
+  SgDiv dN, dW;
   __device__ bool setup(int, int& M, int& Nn, int& K0, int& K1) const {
     M = 3 * N; Nn = B * W; K0 = 0; K1 = N;
     return true;
   }
   __device__ float a(int, int i, int k) const { return T[(size_t)i * N + k]; }
   __device__ float b(int, int k, int j) const {
-    const int bb = j / W;
-    return X.at(bb, k, j - bb * W);
+    int bb, t;
+    dW.divmod(j, bb, t);
+    return X.at(bb, k, t);
   }
   __device__ void epi(int, int i, int j, float v) const {
-    const int kq = i / N, n = i - kq * N, bb = j / W, t = j - bb * W;
+    int kq, n, bb, t;
+    dN.divmod(i, kq, n);
+    dW.divmod(j, bb, t);
     G[((size_t)bb * N + n) * (3 * W) + kq * W + t] = v;
   }
 };
@@ -72,18 +93,22 @@ struct GftBwdDxOp {
   float* dX;
   int B, N, W;
   size_t slab;
+  SgDiv dN, dW;
   __device__ bool setup(int, int& M, int& Nn, int& K0, int& K1) const {
     M = N; Nn = B * W; K0 = 0; K1 = 3 * N;
     return true;
   }
   __device__ float a(int, int i, int k) const { return T[(size_t)k * N + i]; }   // T_kq[n][m=i], k=(kq,n)
   __device__ float b(int, int k, int j) const {
-    const int kq = k / N, n = k - kq * N, bb = j / W, t = j - bb * W;
+    int kq, n, bb, t;
+    dN.divmod(k, kq, n);
+    dW.divmod(j, bb, t);
     const size_t o = ((size_t)bb * N + n) * (3 * W) + kq * W + t;
     return dG[o] + dG[o + slab];
   }
   __device__ void epi(int, int i, int j, float v) const {
-    const int bb = j / W, t = j - bb * W;
+    int bb, t;
+    dW.divmod(j, bb, t);
     dX[((size_t)bb * N + i) * W + t] = v;
   }
 };
@@ -95,18 +120,22 @@ struct GftBwdDtOp {
   float* dT;  // dmul_L slot 1
   int B, N, W, accumulate;
   size_t slab;
+  SgDiv dN, dW;
   __device__ bool setup(int, int& M, int& Nn, int& K0, int& K1) const {
     M = 3 * N; Nn = N; K0 = 0; K1 = B * W;
     return true;
   }
   __device__ float a(int, int i, int k) const {
-    const int kq = i / N, n = i - kq * N, bb = k / W, t = k - bb * W;
+    int kq, n, bb, t;
+    dN.divmod(i, kq, n);
+    dW.divmod(k, bb, t);
     const size_t o = ((size_t)bb * N + n) * (3 * W) + kq * W + t;
     return dG[o] + dG[o + slab];
   }
   __device__ float b(int, int k, int j) const {
-    const int bb = k / W;
-    return X.at(bb, j, k - bb * W);
+    int bb, t;
+    dW.divmod(k, bb, t);
+    return X.at(bb, j, t);
   }
   __device__ void epi(int, int i, int j, float v) const {
     float* o = dT + (size_t)i * N + j;
@@ -124,21 +153,25 @@ struct GftBwdDt2Op {
   float* dT;             // dmul_L slot 1
   int B, N, W;
   size_t slab;
+  SgDiv dN, dW;
   __device__ bool setup(int, int& M, int& Nn, int& K0, int& K1) const {
     M = 3 * N; Nn = N; K0 = 0; K1 = 2 * B * W;
     return true;
   }
   __device__ float a(int, int i, int k) const {
     const int blk = k >= B * W ? 1 : 0, kk = k - blk * B * W;
-    const int kq = i / N, n = i - kq * N, bb = kk / W, t = kk - bb * W;
+    int kq, n, bb, t;
+    dN.divmod(i, kq, n);
+    dW.divmod(kk, bb, t);
     const size_t o = ((size_t)bb * N + n) * (3 * W) + kq * W + t;
     const float* g = dG[blk];
     return g[o] + g[o + slab];
   }
   __device__ float b(int, int k, int j) const {
     const int blk = k >= B * W ? 1 : 0, kk = k - blk * B * W;
-    const int bb = kk / W;
-    return X[blk].at(bb, j, kk - bb * W);
+    int bb, t;
+    dW.divmod(kk, bb, t);
+    return X[blk].at(bb, j, t);
   }
   __device__ void epi(int, int i, int j, float v) const { dT[(size_t)i * N + j] = v; }
 };
@@ -492,7 +525,8 @@ static inline int split_chunk(int M, int S) { return ((M + S - 1) / S + 15) & ~1
 extern "C" int stemgnn_gft_fwd(const float* mul_L, const float* X, long xs_b, long xs_n, long xs_t,
                                float* G, int B, int N, int W, void* stream) {
   if (!mul_L || !X || !G || B <= 0 || N <= 0 || W <= 0) return SG_EINVAL;
-  GftFwdOp op{mul_L + (size_t)N * N, XView{X, xs_b, xs_n, xs_t, N}, G, B, N, W};
+  if (!sg_div_ok(3L * N + 64, N) || !sg_div_ok((long)B * W + 64, W)) return SG_EINVAL;
+  GftFwdOp op{mul_L + (size_t)N * N, XView{X, xs_b, xs_n, xs_t, N}, G, B, N, W, sg_div(N), sg_div(W)};
   hipStream_t st = (hipStream_t)stream;
   if (N <= 512) {       // latency-bound at small N: half as many load -> LDS -> MFMA rounds
     if (xs_n == 1) SG_TRY((sg_launch_gemm<GftFwdOp, 32, 32, true, true, false, 128, true>(op, 3 * N, B * W, 1, st)));
@@ -510,13 +544,15 @@ extern "C" int stemgnn_gft_bwd(const float* mul_L, const float* X, long xs_b, lo
   if (!mul_L || !X || !dG || (!dmul_L && !dX) || B <= 0 || N <= 0 || W <= 0) return SG_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   const bool bk128 = N <= 512;
+  if (!sg_div_ok(3L * N + 128, N) || !sg_div_ok((long)B * W + 128, W)) return SG_EINVAL;
   if (dX) {
-    GftBwdDxOp op{mul_L + (size_t)N * N, dG, dX, B, N, W, (size_t)B * N * 3 * W};
+    GftBwdDxOp op{mul_L + (size_t)N * N, dG, dX, B, N, W, (size_t)B * N * 3 * W, sg_div(N), sg_div(W)};
     if (bk128) SG_TRY((sg_launch_gemm<GftBwdDxOp, 32, 32, false, false, false, 128, true>(op, N, B * W, 1, st)));
     else SG_TRY((sg_launch_gemm<GftBwdDxOp, 32, 32, false, false, false, 64, true>(op, N, B * W, 1, st)));
   }
   if (!dmul_L) return 0;                         // data gradient only (the caller runs the dT product elsewhere)
-  GftBwdDtOp op{dG, XView{X, xs_b, xs_n, xs_t, N}, dmul_L + (size_t)N * N, B, N, W, accumulate, (size_t)B * N * 3 * W};
+  GftBwdDtOp op{dG, XView{X, xs_b, xs_n, xs_t, N}, dmul_L + (size_t)N * N, B, N, W, accumulate, (size_t)B * N * 3 * W, sg_div(N),
+                sg_div(W)};
   if (bk128) {
     if (xs_t == 1) SG_TRY((sg_launch_gemm<GftBwdDtOp, 32, 32, true, true, false, 128, true>(op, 3 * N, N, 1, st)));
     else SG_TRY((sg_launch_gemm<GftBwdDtOp, 32, 32, true, false, false, 128, true>(op, 3 * N, N, 1, st)));
@@ -532,8 +568,9 @@ extern "C" int stemgnn_gft_bwd_dt2(const float* X0, long xs0_b, long xs0_n, long
                                    void* stream) {
   if (!X0 || !dG0 || !X1 || !dG1 || !dmul_L || B <= 0 || N <= 0 || W <= 0) return SG_EINVAL;
   hipStream_t st = (hipStream_t)stream;
+  if (!sg_div_ok(3L * N + 128, N) || !sg_div_ok(2L * B * W + 128, W)) return SG_EINVAL;
   GftBwdDt2Op op{{dG0, dG1}, {XView{X0, xs0_b, xs0_n, xs0_t, N}, XView{X1, xs1_b, xs1_n, xs1_t, N}}, dmul_L + (size_t)N * N,
-                 B, N, W, (size_t)B * N * 3 * W};
+                 B, N, W, (size_t)B * N * 3 * W, sg_div(N), sg_div(W)};
   if (N <= 512) SG_TRY((sg_launch_gemm<GftBwdDt2Op, 32, 32, true, false, false, 128, true>(op, 3 * N, N, 1, st)));
   else SG_TRY((sg_launch_gemm<GftBwdDt2Op, 32, 32, true, false, false, 64, true>(op, 3 * N, N, 1, st)));
   return 0;
