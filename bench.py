@@ -45,9 +45,9 @@ WORKLOAD = dict(N=228, W=12, H=3, multi=5, B=32)      # PEMS07 shape, BASELINE.j
 DEFAULT_DTYPE = "f32"
 DTYPE_NOTE = {
     "f32": "exact fp32 (v_mfma_f32_32x32x2_f32 / 16x16x4_f32): the reference's arithmetic, the library default",
-    "bf16x2": "GLU forward + data-gradient products as split-bf16 (3 bf16 products per fp32 product, ~2^-16 relative) on "
-              "v_mfma_f32_32x32x16_bf16 with fp32 accumulation inside the fused kernels; weight gradients, GRU, attention, heads, "
-              "optimizer exact fp32; model-level error <= 3e-5 norm-relative against the 1e-4 parity bar",
+    "bf16x2": "GLU forward, data-gradient AND (round 6) weight-gradient products as split-bf16 (3 bf16 products per fp32 product, "
+              "~2^-16 relative) on v_mfma_f32_32x32x16_bf16 with fp32 accumulation; GRU, attention, graph products, heads' forward / "
+              "data gradients, optimizer exact fp32; model-level error <= 3e-5 norm-relative against the 1e-4 parity bar",
     "bf16x3": "GLU layers 1-2 forward + d(pre-activation) products as 6-term split-bf16 (fp32 class) on the per-layer kernels",
 }
 # per-GPU shards of the other BASELINE.json configs (global batch / 8 GPUs for configs[3], [4])
@@ -173,6 +173,11 @@ def time_gemm_families(cfg, iters=20):
         "glu_wgrad": (bwd(2), 1, "sg_wgrad_kernel (all six GLU weight-gradient products of a block in ONE launch: direct-to-LDS "
                                  "ring, in-kernel fixed-order split reduction -- no reduce kernel)"),
     }
+    wg_bf16 = bf16 and os.environ.get("STEMGNN_WGRAD_BF16", "1") != "0"
+    if wg_bf16:     # round 6: the weight gradients on the bf16 matrix pipe too (csrc/wgrad.h wg_stage_bf16)
+        fams["glu_wgrad"] = (bwd(6), 1, "sg_wgrad_kernel<split-bf16> (all six GLU weight-gradient products of a block in ONE launch; fp32 "
+                                        "operands split into bf16 hi / lo on the fly, a_hi b_hi + a_hi b_lo + a_lo b_hi on "
+                                        "v_mfma_f32_32x32x16_bf16, same ring and fixed-order split reduction)")
     out = {}
     for name, (fn, launches, kernel) in fams.items():
         for _ in range(3):
@@ -184,7 +189,7 @@ def time_gemm_families(cfg, iters=20):
         e1.record(st)
         e1.synchronize()
         out[name] = dict(us_per_call=e0.elapsed_time(e1) * 1e3 / iters, launches_per_call=launches, calls_per_step=2,
-                         kernel=kernel, bf16=bool(bf16 and name != "glu_wgrad"))
+                         kernel=kernel, bf16=bool(bf16 and (name != "glu_wgrad" or wg_bf16)))
     return out
 
 

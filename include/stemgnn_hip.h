@@ -253,7 +253,8 @@ int stemgnn_spectral_glu_fwd(const float* packed, float* saved, int B, int N, in
  * scratch.dG and the GLU weight-gradient partials in gradpart.
  * parts: bit 0 = data-gradient chain (layer 2 -> 1 -> 0 -> dG), bit 1 = the weight-gradient GEMMs.  The two parts
  * only share read-only inputs once the chain has run, so a caller may issue part 2 later or on another stream
- * (it is off the critical path of the backward pass); 3 = both, in order. */
+ * (it is off the critical path of the backward pass); 3 = both, in order.  bit 2 (with bit 1): the fused weight-gradient
+ * launch's products as three-term split-bf16 (see stemgnn_block_wgrad_split). */
 int stemgnn_spectral_glu_bwd(const float* packed, const float* saved, float* scratch, float* gradpart,
                              int nsplit, int parts, int B, int N, int W, int multi, void* stream);
 /* Split-bf16 arithmetic for the same layers (BASELINE.json configs[1] "bf16/fp32"; reference data and weights are fp32,
@@ -318,6 +319,13 @@ int stemgnn_block_wgrad(const float* const* params_host, const float* packed, co
                         const float* X, long xs_b, long xs_n, long xs_t, const float* dforecast, int has_bc,
                         float* scratch, float* gradpart, int nsplit, int cu_percent,
                         int B, int N, int W, int multi, void* stream);
+/* The same launch with the fused kernel's products as three-term split-bf16 (a_hi b_hi + a_hi b_lo + a_lo b_hi, fp32
+ * accumulation) on v_mfma_f32_32x32x16_bf16 when splits == 2 (STEMGNN_DTYPE=bf16x2; ~2^-16 relative per product); splits == 0
+ * is stemgnn_block_wgrad.  Reference: the weight gradients autograd forms for models/base_model.py:12-13, 66-72. */
+int stemgnn_block_wgrad_split(const float* const* params_host, const float* packed, const float* saved,
+                              const float* X, long xs_b, long xs_n, long xs_t, const float* dforecast, int has_bc,
+                              float* scratch, float* gradpart, int nsplit, int cu_percent, int B, int N, int W,
+                              int multi, int splits, void* stream);
 
 /* ---- callers on either side of the blocks, fused ------------------------------------------------
  * fc tail (models/base_model.py:97-101,174-179): fsum [B*N, W] (block forecast sum) ->

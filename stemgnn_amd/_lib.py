@@ -105,6 +105,8 @@ SIGNATURES = {
     "stemgnn_fc_tail_train_finish": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P]),
     "stemgnn_block_wgrad": (c_int, [_PP, _P, _P, _P, c_long, c_long, c_long, _P, c_int, _P, _P, c_int, c_int,
                                     c_int, c_int, c_int, c_int, _P]),
+    "stemgnn_block_wgrad_split": (c_int, [_PP, _P, _P, _P, c_long, c_long, c_long, _P, c_int, _P, _P, c_int, c_int,
+                                          c_int, c_int, c_int, c_int, c_int, _P]),
 }
 
 _lib = None

@@ -1049,7 +1049,8 @@ extern "C" int stemgnn_spectral_glu_bwd(const float* packed, const float* saved,
   }
   if (parts & 2) {
     if (fused) {
-      SG_TRY(wg_launch(wq, 6, d.M, gradpart + Gl.wg_ws, reinterpret_cast<unsigned*>(gradpart + Gl.wg_cnt), Gl.wg_smax, st));
+      SG_TRY(wg_launch(wq, 6, d.M, gradpart + Gl.wg_ws, reinterpret_cast<unsigned*>(gradpart + Gl.wg_cnt), Gl.wg_smax, st, true, 100,
+                       false, nullptr, nullptr, (parts & 4) != 0));
     } else if (nsplit > 1) {
       SgSlabRegions R;
       R.n = 0;
@@ -1258,10 +1259,10 @@ extern "C" int stemgnn_shortcut_dx(const float* scratch, const float* bs_w, floa
   return 0;
 }
 
-extern "C" int stemgnn_block_wgrad(const float* const* params_host, const float* packed, const float* saved,
-                                   const float* X, long xs_b, long xs_n, long xs_t, const float* dforecast, int has_bc,
-                                   float* scratch, float* gradpart, int nsplit, int cu_percent, int B, int N, int W,
-                                   int multi, void* stream) {
+static int block_wgrad_impl(const float* const* params_host, const float* packed, const float* saved,
+                            const float* X, long xs_b, long xs_n, long xs_t, const float* dforecast, int has_bc,
+                            float* scratch, float* gradpart, int nsplit, int cu_percent, int B, int N, int W,
+                            int multi, void* stream, int splits) {
   if (!params_host || !packed || !saved || !X || !dforecast || !scratch || !gradpart || nsplit <= 0 || B <= 0 || N <= 0 ||
       W <= 0 || multi <= 0)
     return SG_EINVAL;
@@ -1303,7 +1304,7 @@ extern "C" int stemgnn_block_wgrad(const float* const* params_host, const float*
   }
   (void)n_glu;
   SG_TRY(wg_launch(q, n, d.M, gradpart + Gl.wg_ws, reinterpret_cast<unsigned*>(gradpart + Gl.wg_cnt), Gl.wg_smax, st, true,
-                   cu_percent));
+                   cu_percent, false, nullptr, nullptr, splits == 2));
   if (has_bc) {  // BS: -dpB^T [X | 1] on the descriptor GEMM (X is a strided view), 32 tiny slabs + their reduce
     HeadsWgradOp op;
     const int huge = 1 << 30;
@@ -1318,4 +1319,24 @@ extern "C" int stemgnn_block_wgrad(const float* const* params_host, const float*
     SG_TRY(heads_reduce(d, Gl, gradpart, nsplit, 1, 16, st));
   }
   return 0;
+}
+
+extern "C" int stemgnn_block_wgrad(const float* const* params_host, const float* packed, const float* saved,
+                                   const float* X, long xs_b, long xs_n, long xs_t, const float* dforecast, int has_bc,
+                                   float* scratch, float* gradpart, int nsplit, int cu_percent, int B, int N, int W,
+                                   int multi, void* stream) {
+  return block_wgrad_impl(params_host, packed, saved, X, xs_b, xs_n, xs_t, dforecast, has_bc, scratch, gradpart, nsplit,
+                          cu_percent, B, N, W, multi, stream, 0);
+}
+// splits = 2 (STEMGNN_DTYPE=bf16x2): the fused launch's products -- the six GLU weight gradients and the heads' -- as
+// three-term split-bf16 on the bf16 matrix pipe (csrc/wgrad.h wg_stage_bf16; ~2^-16 relative per product, fp32 accumulation,
+// same fixed-order split reduction); 0: exact fp32 = stemgnn_block_wgrad.  The short-cut head's product (block 0) and the
+// slab fallback of shapes outside the fused kernel stay exact fp32.
+extern "C" int stemgnn_block_wgrad_split(const float* const* params_host, const float* packed, const float* saved,
+                                         const float* X, long xs_b, long xs_n, long xs_t, const float* dforecast, int has_bc,
+                                         float* scratch, float* gradpart, int nsplit, int cu_percent, int B, int N, int W,
+                                         int multi, int splits, void* stream) {
+  if (splits != 0 && splits != 2) return SG_EINVAL;
+  return block_wgrad_impl(params_host, packed, saved, X, xs_b, xs_n, xs_t, dforecast, has_bc, scratch, gradpart, nsplit,
+                          cu_percent, B, N, W, multi, stream, splits);
 }

@@ -229,6 +229,138 @@ __device__ __forceinline__ void wg_stage(const float* __restrict__ As, sg_f32x16
   cur.next_stage();
 }
 
+// ---- split-bf16 form of one stage (round 6, STEMGNN_DTYPE=bf16x2) ------------------------------------------------------
+// The same ring, the same K-major fp32 stage image, the same accumulators -- but the 16 rows of a stage are ONE k-step of
+// v_mfma_f32_32x32x16_bf16: every fp32 operand value is split on the fly into bf16 hi + lo (v_cvt_pk_bf16_f32, round to nearest)
+// and a product is a_hi b_hi + a_hi b_lo + a_lo b_hi (the lo x lo term, ~2^-16 of the product, is dropped): 12 MFMAs of 32
+// cycles per stage and wave instead of 32 of 64.  A lane of the bf16 MFMA holds 8 CONSECUTIVE k of one row / column
+// (k = 8 (lane / 32) ... + 7): eight ds_read_b64 per operand fetch {tile 0, tile 1} of rows 8 fk ... 8 fk + 7 at the lane's
+// column pair -- the interleaved-tile image of the fp32 path, unchanged.  The summation order over k inside a stage is the
+// matrix unit's; over the stages and the splits it is the fp32 kernel's: results stay bitwise reproducible launch to launch.
+typedef __bf16 wg_bf8 __attribute__((ext_vector_type(8)));
+typedef __bf16 wg_bf2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void wg_split_pair(float a, float b, unsigned& hi, unsigned& lo) {
+  wg_bf2 h;
+  h[0] = (__bf16)a; h[1] = (__bf16)b;
+  hi = __builtin_bit_cast(unsigned, h);
+  const float ra = a - __uint_as_float(hi << 16), rb = b - __uint_as_float(hi & 0xffff0000u);
+  wg_bf2 l;
+  l[0] = (__bf16)ra; l[1] = (__bf16)rb;
+  lo = __builtin_bit_cast(unsigned, l);
+}
+// eight values of one MFMA tile -> its hi and lo operand registers
+__device__ __forceinline__ void wg_split8(const float (&v)[8], wg_bf8& hi, wg_bf8& lo) {
+  unsigned h[4], l[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) wg_split_pair(v[2 * q], v[2 * q + 1], h[q], l[q]);
+  typedef unsigned wg_u4 __attribute__((ext_vector_type(4)));
+  hi = __builtin_bit_cast(wg_bf8, (wg_u4){h[0], h[1], h[2], h[3]});
+  lo = __builtin_bit_cast(wg_bf8, (wg_u4){l[0], l[1], l[2], l[3]});
+}
+// fragment reads through a __restrict__ parameter (alias-scope metadata: hipcc's waitcnt pass otherwise assumes an LDS read may
+// alias the LDS-DMA in flight and drains the ring ahead of every read -- csrc/glu_fused.h)
+template <int LD>
+__device__ __forceinline__ void wg_read8(const float* __restrict__ p, float (&t0)[8], float (&t1)[8]) {
+#pragma unroll
+  for (int kk = 0; kk < 8; ++kk) {
+    const float2 v = *reinterpret_cast<const float2*>(p + kk * LD);
+    t0[kk] = v.x; t1[kk] = v.y;
+  }
+}
+// the packed operands of one stage: [tile][hi, lo] for A and for B
+struct WgFragBf {
+  wg_bf8 ah[2], al[2], bh[2], bl[2];
+};
+// The split-bf16 K loop, software-pipelined over the stages: while the matrix unit works on stage t (12 MFMAs = 384 cycles) the
+// wave reads stage t+1's fragments from LDS and splits them (16 cvt pairs = ~100 VALU instructions) -- a first version that
+// did read -> split -> MFMA per stage in sequence measured 60 us per launch, the matrix unit idle for more than half of it.
+// Ring bookkeeping: stage t+1 must have LANDED before it is read, one iteration earlier than in the fp32 loop, so the counted
+// wait leaves STAGES-3 younger stages in flight; a stage's LDS buffer is free once every wave has its fragments in registers,
+// i.e. after the barrier of the NEXT iteration -- the refill target is the buffer of stage t-1 as before.
+template <int BK, int STAGES, bool ONES, int AW, int BW>
+__device__ __forceinline__ void wg_kloop_bf16(float* lds, sg_f32x16 (&acc)[2][2], WgCursor<BK, AW, BW>& cur, int nk, int aoff,
+                                              int boff, bool one0, bool one1, int fk) {
+  static_assert(BK == 16, "one bf16 k-step per stage");
+  static_assert(STAGES >= 4, "the pipelined loop keeps one stage in registers");
+  constexpr int STAGE = BK * (AW + BW);
+  constexpr int NI = WgCursor<BK, AW, BW>::NP;
+  static_assert(NI <= 5 && (STAGES - 2) * NI <= 63, "DMA pieces / vmcnt range");
+#pragma unroll
+  for (int p = 0; p < STAGES - 1; ++p) {
+    const bool fast = cur.fast();
+#pragma unroll
+    for (int q = 0; q < NI; ++q) cur.issue(q, lds + p * STAGE, fast);
+    cur.next_stage();
+  }
+  float xa[2][8], xb[2][8];
+  auto fetch = [&](const float* __restrict__ st) {
+    wg_read8<AW>(st + (8 * fk) * AW + aoff, xa[0], xa[1]);
+    wg_read8<BW>(st + BK * AW + (8 * fk) * BW + boff, xb[0], xb[1]);
+  };
+  auto ones = [&]() {
+    if (ONES) {
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk) { xb[0][kk] = one0 ? 1.f : xb[0][kk]; xb[1][kk] = one1 ? 1.f : xb[1][kk]; }
+    }
+  };
+  WgFragBf f;
+  // prologue: stage 0 into registers
+  wg_wait_vm<(STAGES - 2) * NI>();
+  __builtin_amdgcn_s_barrier();
+  fetch(lds);
+  ones();
+  wg_split8(xa[0], f.ah[0], f.al[0]); wg_split8(xa[1], f.ah[1], f.al[1]);
+  wg_split8(xb[0], f.bh[0], f.bl[0]); wg_split8(xb[1], f.bh[1], f.bl[1]);
+  int rnext = 1, wbuf = STAGES - 1;
+  for (int t = 0; t < nk; ++t) {
+    // stage t+1 has landed (everybody's pieces), and everybody holds stage t in registers: its buffer and stage t-1's are free
+    wg_wait_vm<(STAGES - 3) * NI>();
+    __builtin_amdgcn_s_barrier();
+    const bool fast = cur.fast();
+    float* stage_next = lds + wbuf * STAGE;
+    fetch(lds + rnext * STAGE);                       // (past the end of the range: a harmless re-read that is never multiplied)
+    WgFragBf n;
+    WG_SCHED();
+    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.al[0], f.bh[0], acc[0][0], 0, 0, 0);
+    if (0 < NI) cur.issue(0, stage_next, fast);
+    WG_SCHED();
+    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[0], f.bl[0], acc[0][0], 0, 0, 0);
+    if (1 < NI) cur.issue(1, stage_next, fast);
+    WG_SCHED();
+    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[0], f.bh[0], acc[0][0], 0, 0, 0);
+    if (2 < NI) cur.issue(2, stage_next, fast);
+    WG_SCHED();
+    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.al[0], f.bh[1], acc[0][1], 0, 0, 0);
+    if (3 < NI) cur.issue(3, stage_next, fast);
+    WG_SCHED();
+    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[0], f.bl[1], acc[0][1], 0, 0, 0);
+    if (4 < NI) cur.issue(4, stage_next, fast);
+    WG_SCHED();
+    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[0], f.bh[1], acc[0][1], 0, 0, 0);
+    ones();                                           // the LDS reads have landed by now (5 MFMAs = 160 cycles)
+    wg_split8(xa[0], n.ah[0], n.al[0]);
+    WG_SCHED();
+    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.al[1], f.bh[0], acc[1][0], 0, 0, 0);
+    wg_split8(xb[0], n.bh[0], n.bl[0]);
+    WG_SCHED();
+    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[1], f.bl[0], acc[1][0], 0, 0, 0);
+    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[1], f.bh[0], acc[1][0], 0, 0, 0);
+    wg_split8(xa[1], n.ah[1], n.al[1]);
+    WG_SCHED();
+    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.al[1], f.bh[1], acc[1][1], 0, 0, 0);
+    wg_split8(xb[1], n.bh[1], n.bl[1]);
+    WG_SCHED();
+    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[1], f.bl[1], acc[1][1], 0, 0, 0);
+    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[1], f.bh[1], acc[1][1], 0, 0, 0);
+    WG_SCHED();
+    f = n;
+    cur.next_stage();
+    rnext = rnext + 1 == STAGES ? 0 : rnext + 1;
+    wbuf = wbuf + 1 == STAGES ? 0 : wbuf + 1;
+  }
+  wg_wait_vm<0>();                                       // drain the run-ahead pieces before the LDS word is reused
+}
+
 // the K loop of one workgroup: STAGES-deep ring.  Stage t+STAGES-1 is requested from inside the MFMA stream of stage t; the
 // ring is ALWAYS kept full (stages past the end of the range are harmless re-reads that are never multiplied), so the
 // counted wait is the same constant in every iteration -- no tail cases.
@@ -355,7 +487,7 @@ __device__ __forceinline__ int wg_claim(const WgArgs& g, float* lds, int gi, int
 }
 
 // everything behind the block -> work-item mapping, for one tile shape (AW x BW: 128 x 128 or 256 x 64)
-template <int BK, int STAGES, int AW, int BW>
+template <int BK, int STAGES, int AW, int BW, bool SPLIT = false>
 __device__ __forceinline__ void wg_body(const WgArgs& g, float* lds, int gi, int s, int bx, int by) {
 #ifdef SG_WG_DEBUG
   const unsigned long long t_start = __builtin_amdgcn_s_memtime();
@@ -400,8 +532,13 @@ __device__ __forceinline__ void wg_body(const WgArgs& g, float* lds, int gi, int
   // does this wave's 64-column block contain the ones column?  (wave-uniform: the K loop is instantiated both ways)
   const int cw0 = n0 + wn * 64;
   const bool has_ones = ones_col >= cw0 && ones_col < cw0 + 64;
-  if (has_ones) wg_kloop<BK, STAGES, true, AW, BW>(lds, acc, cur, nk, aoff, boff, one0, one1, fk);
-  else wg_kloop<BK, STAGES, false, AW, BW>(lds, acc, cur, nk, aoff, boff, one0, one1, fk);
+  if constexpr (SPLIT) {
+    if (has_ones) wg_kloop_bf16<BK, STAGES, true, AW, BW>(lds, acc, cur, nk, aoff, boff, one0, one1, fk);
+    else wg_kloop_bf16<BK, STAGES, false, AW, BW>(lds, acc, cur, nk, aoff, boff, one0, one1, fk);
+  } else {
+    if (has_ones) wg_kloop<BK, STAGES, true, AW, BW>(lds, acc, cur, nk, aoff, boff, one0, one1, fk);
+    else wg_kloop<BK, STAGES, false, AW, BW>(lds, acc, cur, nk, aoff, boff, one0, one1, fk);
+  }
 #ifdef SG_WG_DEBUG
   if ((g.dbg & 16) && threadIdx.x == 0) {                // per-workgroup trace: placement and K-loop span (shader clocks)
     const unsigned long long t_end = __builtin_amdgcn_s_memtime();
@@ -501,7 +638,7 @@ __device__ __forceinline__ void wg_body(const WgArgs& g, float* lds, int gi, int
 }
 
 // PHASED: the instantiation for WgArgs::phase 1 / 2 (persistent loop, claims); the plain one keeps the straight-line code
-template <int BK, int STAGES, bool PHASED = false>
+template <int BK, int STAGES, bool PHASED = false, bool SPLIT = false>
 __global__ __launch_bounds__(256, 1) void sg_wgrad_kernel(const WgArgs g) {
   static_assert(BK == 16 || BK == 32, "BK");
   static_assert(STAGES >= 3 && STAGES <= 8, "STAGES");
@@ -592,8 +729,8 @@ __global__ __launch_bounds__(256, 1) void sg_wgrad_kernel(const WgArgs g) {
     }
     if (PHASED && g.phase == 2 && wg_claim(g, lds, gi, s, bx, by, false) != 1) return;
   }
-  if (g.g[gi].wide) wg_body<BK, STAGES_WIDE, 256, 64>(g, lds, gi, s, bx, by);
-  else wg_body<BK, STAGES, 128, 128>(g, lds, gi, s, bx, by);
+  if (g.g[gi].wide) wg_body<BK, STAGES_WIDE, 256, 64, SPLIT>(g, lds, gi, s, bx, by);
+  else wg_body<BK, STAGES, 128, 128, SPLIT>(g, lds, gi, s, bx, by);
   if (!PHASED) return;
   }
 }
@@ -678,9 +815,10 @@ struct WgTwoLevel {
 // beside it on another stream) -- fewer, longer splits, same results
 // flat: the work-list order for launches of many more tiles than CUs (`use_tab` = 2); the split count then balances the
 // LAST round (816 tiles on 256 CUs: 4 rounds of which the last is 19 % full -> 5 splits: 4080 items = 15.94 rounds of 1/5)
+// split_bf16: the products as three-term split-bf16 on the bf16 matrix pipe (wg_stage_bf16) -- plain launches only
 static inline hipError_t wg_launch(WgGemm* q, int n, int K, float* ws, unsigned* cnt, int smax_ws, hipStream_t st,
                                    bool zero_counters = true, int cu_percent = 100, bool flat = false,
-                                   const WgExtra* extra = nullptr, const WgTwoLevel* tl = nullptr) {
+                                   const WgExtra* extra = nullptr, const WgTwoLevel* tl = nullptr, bool split_bf16 = false) {
   if (n <= 0 || n > WG_MAXG || K <= 0) return hipErrorInvalidValue;
   const WgPlan p = wg_plan();
   WgArgs a;
@@ -785,7 +923,9 @@ static inline hipError_t wg_launch(WgGemm* q, int n, int K, float* ws, unsigned*
   int maxload = 0;
   for (int c = 0; c < 8; ++c) maxload = load[c] > maxload ? load[c] : maxload;
   a.nmain = a.use_tab ? 8 * maxload : 8 * ((groups + 7) / 8) * tmax;
+  if (split_bf16 && (tl || flat)) return hipErrorInvalidValue;
   if (a.phase == 2) hipLaunchKernelGGL((sg_wgrad_kernel<16, 6, true>), dim3(a.nmain + nextra), dim3(256), 0, st, a);
+  else if (split_bf16) hipLaunchKernelGGL((sg_wgrad_kernel<16, 6, false, true>), dim3(a.nmain + nextra), dim3(256), 0, st, a);
   else hipLaunchKernelGGL((sg_wgrad_kernel<16, 6>), dim3(a.nmain + nextra), dim3(256), 0, st, a);
   return hipGetLastError();
 }

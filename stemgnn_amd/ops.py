@@ -865,10 +865,11 @@ class SpectralHotPath(torch.autograd.Function):
                     B, N, W, multi, stream), "spectral_glu_bwd")
 
             def wgrad(stream, cu_percent):      # every weight gradient of the block (fused kernel + the BS head)
-                _lib.check(lib.stemgnn_block_wgrad(
+                # bf16x2: the fused launch's products as split-bf16 too (round 6, csrc/wgrad.h wg_stage_bf16)
+                _lib.check(lib.stemgnn_block_wgrad_split(
                     parr, packed[s].data_ptr(), saved[s].data_ptr(), X.data_ptr(), sb, sn, stt, dfsum.data_ptr(),
-                    int(has_bc), scratch.data_ptr(), gradpart.data_ptr(), nsplit, cu_percent, B, N, W, multi, stream),
-                    "block_wgrad")
+                    int(has_bc), scratch.data_ptr(), gradpart.data_ptr(), nsplit, cu_percent, B, N, W, multi,
+                    2 if splits == 2 and os.environ.get("STEMGNN_WGRAD_BF16", "1") != "0" else 0, stream), "block_wgrad")
 
             def unpack(stream):
                 _lib.check(lib.stemgnn_block_unpack_grads(

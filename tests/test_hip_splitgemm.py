@@ -218,3 +218,51 @@ def test_per_layer_split_entries_refuse_a_fused_only_buffer(monkeypatch):
                                                     B, N, W, multi, 2, st), "per-layer chain")
     torch.cuda.synchronize()
     assert torch.isfinite(saved).all()
+
+
+@pytest.mark.parametrize("N,W,multi,B", [(228, 12, 5, 32), (140, 12, 5, 7), (33, 12, 5, 5), (50, 8, 2, 9), (64, 16, 4, 4)])
+def test_split_bf16_weight_gradients_match_the_fp32_launch(N, W, multi, B):
+    """csrc/wgrad.h wg_stage_bf16 (round 6): the fused weight-gradient launch of a block -- six GLU products and the heads'
+    products -- as three-term split-bf16 on v_mfma_f32_32x32x16_bf16, through the C ABI on random saved / scratch buffers,
+    against the exact-fp32 launch on the same buffers: every parameter gradient (after stemgnn_block_unpack_grads) within 1e-4
+    norm-relative; two launches of the split form agree bit for bit (fixed-order split reduction); both tile shapes (the
+    256 x 64 one for the layer-0 products), ragged K ranges (M = B N not a multiple of 16) and the ones column (bias)."""
+    from stemgnn_amd import StockBlockLayer, _lib, ops
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    torch.manual_seed(N + W)
+    blk = StockBlockLayer(W, N, multi, stack_cnt=0).to(dev)
+    params = blk.hip_params()
+    parr = _lib.ptr_array(params)
+    tables = ops.dft_tables(W, multi, dev)
+    st = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator().manual_seed(N * 7 + W)
+    packed = torch.empty(lib.stemgnn_packed_floats(W, multi), device=dev)
+    _lib.check(lib.stemgnn_block_pack(parr, tables.data_ptr(), packed.data_ptr(), W, multi, st), "pack")
+    saved = torch.rand(lib.stemgnn_saved_floats(B, N, W, multi), generator=g).to(dev)
+    scratch = (torch.randn(lib.stemgnn_scratch_floats(B, N, W, multi), generator=g) * 0.1).to(dev)
+    X = torch.randn(B, N, W, generator=g).to(dev)
+    dfo = (torch.randn(B, N, W, generator=g) * 0.1).to(dev)
+    ns = ops._NSPLIT
+
+    def run(splits):
+        gradpart = torch.zeros(lib.stemgnn_gradpart_floats(W, multi, ns), device=dev)
+        _lib.check(lib.stemgnn_block_wgrad_split(parr, packed.data_ptr(), saved.data_ptr(), X.data_ptr(), N * W, W, 1,
+                                                 dfo.data_ptr(), 1, scratch.data_ptr(), gradpart.data_ptr(), ns, 100, B, N, W,
+                                                 multi, splits, st), "block_wgrad_split")
+        grads = [None if p is None else torch.zeros_like(p) for p in params]
+        _lib.check(lib.stemgnn_block_unpack_grads(gradpart.data_ptr(), ns, tables.data_ptr(), _lib.ptr_array(grads), W, multi, 1,
+                                                  st), "unpack")
+        torch.cuda.synchronize()
+        return grads
+    ref, got, again = run(0), run(2), run(2)
+    worst = 0.0
+    for i, (a, b, c) in enumerate(zip(ref, got, again)):
+        if a is None:
+            continue
+        assert torch.isfinite(b).all(), i
+        assert torch.equal(b, c), i                         # launch-to-launch determinism of the split form
+        if float(a.abs().max()) > 0:
+            worst = max(worst, relerr(b, a))
+    print(f"N={N} W={W} multi={multi} B={B}: split-bf16 weight gradients vs fp32, worst parameter {worst:.2e}")
+    assert 0 < worst < 1e-4
