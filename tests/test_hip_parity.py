@@ -505,3 +505,37 @@ def test_glu_module_standalone(lead, cin, cout):
         assert relerr(p.grad, ref_grads[k]) < 1e-5, k
     with pytest.raises(Exception):
         dev_glu(x.detach())                      # CPU tensor: no fallback
+
+
+@pytest.mark.parametrize("N,W,B", [(228, 12, 32), (33, 12, 5), (50, 8, 9), (19, 5, 3)])
+def test_both_blocks_dT_as_one_product_equals_the_two_products(N, W, B):
+    """Round 6: stemgnn_gft_bwd_dt2 -- d(mul_L)[1..3] of both blocks as ONE product whose reduction runs over block 0's (b, t)
+    range, then block 1's -- against the two accumulating stemgnn_gft_bwd calls it replaces and against fp64."""
+    from stemgnn_amd import _lib
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(N + B)
+    x0 = torch.randn(B, W, N, generator=g).to(dev)                  # block 0 reads the model input in place: strides (W N, 1, N)
+    x1 = torch.randn(B, N, W, generator=g).to(dev)                  # block 1 reads the backcast: strides (N W, W, 1)
+    dG = [(torch.randn(2, B * N, 3 * W, generator=g) * 0.1).to(dev) for _ in range(2)]      # two partial slabs per block
+    mul_L = torch.randn(4, N, N, generator=g).to(dev)
+    st = torch.cuda.current_stream().cuda_stream
+    two = torch.zeros(4, N, N, device=dev)
+    _lib.check(lib.stemgnn_gft_bwd(mul_L.data_ptr(), x1.data_ptr(), N * W, W, 1, dG[1].data_ptr(), None, two.data_ptr(), 0,
+                                   B, N, W, st), "dT block 1")
+    _lib.check(lib.stemgnn_gft_bwd(mul_L.data_ptr(), x0.data_ptr(), W * N, 1, N, dG[0].data_ptr(), None, two.data_ptr(), 1,
+                                   B, N, W, st), "dT block 0")
+    one = torch.zeros(4, N, N, device=dev)
+    _lib.check(lib.stemgnn_gft_bwd_dt2(x0.data_ptr(), W * N, 1, N, dG[0].data_ptr(), x1.data_ptr(), N * W, W, 1, dG[1].data_ptr(),
+                                       one.data_ptr(), B, N, W, st), "dT both")
+    torch.cuda.synchronize()
+    # fp64: dT_k[n][m] = sum_b sum_t dG[b,n,k,t] X[b,m,t]
+    X0 = x0.double().permute(0, 2, 1)                              # [B, N(m), W(t)]
+    X1 = x1.double()
+    ref = torch.zeros(4, N, N, dtype=torch.float64, device=dev)
+    for X, d in ((X0, dG[0]), (X1, dG[1])):
+        dsum = (d[0] + d[1]).double().view(B, N, 3, W)
+        ref[1:] += torch.einsum("bnkt,bmt->knm", dsum, X)
+    assert bool((one[0] == 0).all())
+    assert relerr(one[1:], ref[1:]) < 2e-6 and relerr(two[1:], ref[1:]) < 2e-6
+    assert relerr(one[1:], two[1:]) < 2e-6

@@ -195,3 +195,71 @@ def test_fused_train_tail_matches_separate_stages(B, N, W, H):
     out = torch.zeros((), device=DEV)
     l2 = ops.FcTailMse.apply(fsum, y, *prm, None, out, acc)
     assert float(out) == float(l2) and abs(float(acc) - float(l2)) < 1e-12
+
+
+@pytest.mark.parametrize("B,N,W,H", [(32, 228, 12, 3), (5, 33, 12, 1), (3, 50, 28, 28)])
+def test_fc_tail_train_in_two_calls_equals_the_one_call(B, N, W, H):
+    """Round 6: stemgnn_fc_tail_train_rows + _finish (the step queues `_finish` on the side branch: nothing on the backward's
+    chain reads the loss or the fc gradients) are the one call's two launches: bit-identical loss, loss accumulator, d(fsum) and
+    fc gradients, whichever stream `_finish` runs on."""
+    from stemgnn_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(B * 3 + H)
+    fsum, target = torch.randn(B, N, W, generator=g).cuda(), torch.randn(B, H, N, generator=g).cuda()
+    w0, b0 = (torch.randn(W, W, generator=g) * 0.3).cuda(), (torch.randn(W, generator=g) * 0.1).cuda()
+    w2, b2 = (torch.randn(H, W, generator=g) * 0.3).cuda(), (torch.randn(H, generator=g) * 0.1).cuda()
+    st = torch.cuda.current_stream().cuda_stream
+    side = torch.cuda.Stream()
+
+    def buffers():
+        return dict(scratch=torch.empty(lib.stemgnn_fc_tail_train_scratch_floats(B, N, W, H), device=DEV),
+                    loss=torch.zeros((), device=DEV), acc=torch.full((), 0.5, device=DEV, dtype=torch.float64),
+                    dfsum=torch.empty_like(fsum), dw0=torch.empty_like(w0), db0=torch.empty_like(b0),
+                    dw2=torch.empty_like(w2), db2=torch.empty_like(b2))
+    one, two = buffers(), buffers()
+    _lib.check(lib.stemgnn_fc_tail_train(fsum.data_ptr(), target.data_ptr(), w0.data_ptr(), b0.data_ptr(), w2.data_ptr(),
+                                         b2.data_ptr(), B, N, W, H, one["scratch"].data_ptr(), None, one["loss"].data_ptr(),
+                                         one["acc"].data_ptr(), one["dfsum"].data_ptr(), one["dw0"].data_ptr(),
+                                         one["db0"].data_ptr(), one["dw2"].data_ptr(), one["db2"].data_ptr(), st), "one call")
+    _lib.check(lib.stemgnn_fc_tail_train_rows(fsum.data_ptr(), target.data_ptr(), w0.data_ptr(), b0.data_ptr(), w2.data_ptr(),
+                                              b2.data_ptr(), B, N, W, H, two["scratch"].data_ptr(), None, two["dfsum"].data_ptr(),
+                                              st), "rows")
+    side.wait_stream(torch.cuda.current_stream())
+    _lib.check(lib.stemgnn_fc_tail_train_finish(two["scratch"].data_ptr(), B, N, W, H, two["loss"].data_ptr(), two["acc"].data_ptr(),
+                                                two["dw0"].data_ptr(), two["db0"].data_ptr(), two["dw2"].data_ptr(),
+                                                two["db2"].data_ptr(), side.cuda_stream), "finish")
+    torch.cuda.synchronize()
+    for k in ("loss", "acc", "dfsum", "dw0", "db0", "dw2", "db2"):
+        assert torch.equal(one[k], two[k]), k
+    assert float(one["loss"]) > 0 and abs(float(one["acc"]) - 0.5 - float(one["loss"])) < 1e-6
+    assert lib.stemgnn_fc_tail_train_finish(None, B, N, W, H, two["loss"].data_ptr(), None, two["dw0"].data_ptr(),
+                                            two["db0"].data_ptr(), two["dw2"].data_ptr(), two["db2"].data_ptr(), st) == _lib.SG_EINVAL
+
+
+@pytest.mark.parametrize("offset,nbytes", [(0, 4096), (4, 4), (4, 60), (12, 4096 + 8), (0, 16), (8, 1 << 20), (0, 0)])
+def test_fill_zero_is_a_kernel_with_exact_edges(offset, nbytes):
+    """Round 6: the step path zeroes through stemgnn_fill_zero / sg_zero_async (a fill KERNEL: this HIP runtime mis-replays
+    memset nodes of a captured graph).  Ragged heads / tails: exactly [offset, offset + nbytes) is cleared,
+    the neighbours keep their bytes -- eagerly and replayed from a hipGraph five times."""
+    from stemgnn_amd import _lib
+    lib = _lib.load()
+    buf = torch.full(((1 << 20) + 4096,), 7.0, device=DEV)
+    st = torch.cuda.current_stream()
+
+    def check():
+        torch.cuda.synchronize()
+        lo, hi = offset // 4, (offset + nbytes) // 4
+        assert bool((buf[:lo] == 7.0).all()) and bool((buf[hi:] == 7.0).all())
+        assert bool((buf[lo:hi] == 0.0).all())
+    _lib.check(lib.stemgnn_fill_zero(buf.data_ptr() + offset, nbytes, st.cuda_stream), "fill_zero")
+    check()
+    s = torch.cuda.Stream()
+    s.wait_stream(st)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(s):
+        with torch.cuda.graph(g, stream=s):
+            buf.fill_(7.0)                                                   # a kernel node, then the fill kernel
+            _lib.check(lib.stemgnn_fill_zero(buf.data_ptr() + offset, nbytes, torch.cuda.current_stream().cuda_stream), "fill_zero")
+    for _ in range(5):
+        g.replay()
+        check()
