@@ -22,8 +22,12 @@
 
 constexpr int ATTN_NBC = 8;     // batch chunks of the attention forward (more waves; partial sums reduced in fixed order)
 
-// ---- Philox4x32-10, one counter per attention element ---------------------------------------------
-__device__ __forceinline__ uint32_t sg_philox_u32(uint64_t seed, uint64_t offset, uint64_t idx) {
+// ---- Philox4x32-10 ------------------------------------------------------------------------------------
+// Round 6: ALL FOUR words of a Philox call are used (round 5 kept one and paid ten rounds per attention element: 13 us of the
+// step).  Element (row r = b N + i, column j) takes word (j >> 6) & 3 of counter r * NQ + (j >> 8) * 64 + (j & 63), NQ = 64 *
+// ceil(N / 256): the four columns j, j + 64, j + 128, j + 192 a lane of the attention kernels walks share one call.  The
+// forward, the backward and the mask export (stemgnn_dropout_mask, what the parity tests hand to the oracle) use this one map.
+__device__ __forceinline__ void sg_philox4(uint64_t seed, uint64_t offset, uint64_t idx, uint32_t (&w)[4]) {
   uint32_t c0 = (uint32_t)idx, c1 = (uint32_t)(idx >> 32), c2 = (uint32_t)offset, c3 = (uint32_t)(offset >> 32);
   uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
 #pragma unroll
@@ -33,11 +37,10 @@ __device__ __forceinline__ uint32_t sg_philox_u32(uint64_t seed, uint64_t offset
     c0 = hi1 ^ c1 ^ k0; c1 = lo1; c2 = hi0 ^ c3 ^ k1; c3 = lo0;
     k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
   }
-  return c0;
+  w[0] = c0; w[1] = c1; w[2] = c2; w[3] = c3;
 }
-__device__ __forceinline__ bool sg_keep(uint64_t seed, uint64_t offset, uint64_t idx, float p) {
-  return (float)sg_philox_u32(seed, offset, idx) * 2.3283064365386963e-10f >= p;
-}
+__device__ __forceinline__ int sg_drop_nq(int N) { return 64 * ((N + 255) >> 8); }
+__device__ __forceinline__ bool sg_keep_word(uint32_t w, float p) { return (float)w * 2.3283064365386963e-10f >= p; }
 
 __device__ __forceinline__ float sg_wave_sum(float v) {
 #pragma unroll
@@ -114,10 +117,19 @@ __global__ __launch_bounds__(256) void sg_attention_fwd_kernel(
     s = sg_wave_sum(s);
     if (lane == 0) rowsum[(size_t)b * N + i] = s;
     const float inv = 1.f / s;
-    for (int j = lane; j < N; j += 64) {
-      float p = expf(sg_lrelu(kv + q[j], alpha) - mx) * inv;
-      if (drop) p = sg_keep(seed, offset, ((uint64_t)b * N + i) * N + j, drop_p) ? p * keep_scale : 0.f;
-      acc[j] += p;
+    const uint64_t ctr0 = ((uint64_t)b * N + i) * sg_drop_nq(N) + lane;
+    for (int j0 = 0; j0 < N; j0 += 256) {
+      uint32_t w[4] = {0u, 0u, 0u, 0u};
+      if (drop) sg_philox4(seed, offset, ctr0 + (j0 >> 2), w);            // one call for the lane's four columns of this group
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int j = j0 + 64 * t + lane;
+        if (j < N) {
+          float p = expf(sg_lrelu(kv + q[j], alpha) - mx) * inv;
+          if (drop) p = sg_keep_word(w[t], drop_p) ? p * keep_scale : 0.f;
+          acc[j] += p;
+        }
+      }
     }
   }
   float* out = Apart + ((size_t)blockIdx.y * N + i) * N;
@@ -312,22 +324,35 @@ __global__ __launch_bounds__(256) void sg_attention_bwd_kernel(
     // one Philox per element instead of two); columns >= 256 are recomputed
     float pc[4], dc[4];
     float dot = 0.f;
+    const uint64_t ctr0 = ((uint64_t)b * N + i) * sg_drop_nq(N) + lane;
+    {
+      uint32_t w[4] = {0u, 0u, 0u, 0u};
+      if (drop) sg_philox4(seed, offset, ctr0, w);
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const int j = lane + 64 * t;
-      const int jj = j < N ? j : N - 1;
-      float p = expf(sg_lrelu(kv + q[jj], alpha) - mx) * inv;
-      float dp = dA[jj];
-      if (drop) dp = sg_keep(seed, offset, ((uint64_t)b * N + i) * N + jj, drop_p) ? dp * keep_scale : 0.f;
-      if (j >= N) { p = 0.f; dp = 0.f; }
-      pc[t] = p; dc[t] = dp;
-      dot += dp * p;
+      for (int t = 0; t < 4; ++t) {
+        const int j = lane + 64 * t;
+        const int jj = j < N ? j : N - 1;
+        float p = expf(sg_lrelu(kv + q[jj], alpha) - mx) * inv;
+        float dp = dA[jj];
+        if (drop) dp = sg_keep_word(w[t], drop_p) ? dp * keep_scale : 0.f;
+        if (j >= N) { p = 0.f; dp = 0.f; }
+        pc[t] = p; dc[t] = dp;
+        dot += dp * p;
+      }
     }
-    for (int j = lane + 256; j < N; j += 64) {
-      const float p = expf(sg_lrelu(kv + q[j], alpha) - mx) * inv;
-      float dp = dA[j];
-      if (drop) dp = sg_keep(seed, offset, ((uint64_t)b * N + i) * N + j, drop_p) ? dp * keep_scale : 0.f;
-      dot += dp * p;
+    for (int j0 = 256; j0 < N; j0 += 256) {
+      uint32_t w[4] = {0u, 0u, 0u, 0u};
+      if (drop) sg_philox4(seed, offset, ctr0 + (j0 >> 2), w);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int j = j0 + 64 * t + lane;
+        if (j < N) {
+          const float p = expf(sg_lrelu(kv + q[j], alpha) - mx) * inv;
+          float dp = dA[j];
+          if (drop) dp = sg_keep_word(w[t], drop_p) ? dp * keep_scale : 0.f;
+          dot += dp * p;
+        }
+      }
     }
     dot = sg_wave_sum(dot);
     float dk = 0.f;
@@ -342,15 +367,23 @@ __global__ __launch_bounds__(256) void sg_attention_bwd_kernel(
         dq[j] += dpre;
       }
     }
-    for (int j = lane + 256; j < N; j += 64) {
-      const float pre = kv + q[j];
-      const float p = expf(sg_lrelu(pre, alpha) - mx) * inv;
-      float dp = dA[j];
-      if (drop) dp = sg_keep(seed, offset, ((uint64_t)b * N + i) * N + j, drop_p) ? dp * keep_scale : 0.f;
-      const float de = p * (dp - dot);
-      const float dpre = pre > 0.f ? de : alpha * de;
-      dk += dpre;
-      dq[j] += dpre;
+    for (int j0 = 256; j0 < N; j0 += 256) {
+      uint32_t w[4] = {0u, 0u, 0u, 0u};
+      if (drop) sg_philox4(seed, offset, ctr0 + (j0 >> 2), w);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int j = j0 + 64 * t + lane;
+        if (j < N) {
+          const float pre = kv + q[j];
+          const float p = expf(sg_lrelu(pre, alpha) - mx) * inv;
+          float dp = dA[j];
+          if (drop) dp = sg_keep_word(w[t], drop_p) ? dp * keep_scale : 0.f;
+          const float de = p * (dp - dot);
+          const float dpre = pre > 0.f ? de : alpha * de;
+          dk += dpre;
+          dq[j] += dpre;
+        }
+      }
     }
     dk = sg_wave_sum(dk);
     if (lane == 0) dkey[(size_t)b * N + i] = dk;
@@ -430,10 +463,14 @@ __global__ __launch_bounds__(256) void sg_keyquery_wgrad_kernel(const float* __r
   }
 }
 
-__global__ void sg_dropout_mask_kernel(float drop_p, const uint64_t* __restrict__ seedp, size_t n, float* __restrict__ mask) {
+__global__ void sg_dropout_mask_kernel(float drop_p, const uint64_t* __restrict__ seedp, size_t n, int N, float* __restrict__ mask) {
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= n) return;
-  mask[idx] = sg_keep(seedp[0], seedp[1], idx, drop_p) ? 1.f : 0.f;
+  const size_t row = idx / (size_t)N;                  // b N + i
+  const int j = (int)(idx - row * (size_t)N);
+  uint32_t w[4];
+  sg_philox4(seedp[0], seedp[1], row * sg_drop_nq(N) + (uint64_t)((j >> 8) * 64 + (j & 63)), w);
+  mask[idx] = sg_keep_word(w[(j >> 6) & 3], drop_p) ? 1.f : 0.f;
 }
 
 // ---- Chebyshev basis on MFMA ----------------------------------------------------------------------------
@@ -620,7 +657,7 @@ extern "C" int stemgnn_dropout_mask(float drop_p, const uint64_t* seed, int B, i
   if (!seed || !mask || B <= 0 || N <= 0) return SG_EINVAL;
   const size_t n = (size_t)B * N * N;
   hipLaunchKernelGGL(sg_dropout_mask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                     drop_p, seed, n, mask);
+                     drop_p, seed, n, N, mask);
   SG_TRY(hipGetLastError());
   return 0;
 }

@@ -103,10 +103,12 @@ def test_oracle_parity_fwd_bwd(N, W, multi, H, B):
             assert relerr(p.grad, o_grads[k]) < TOL, k
 
 
-@pytest.mark.parametrize("N,W,multi,H,B,p", [(24, 12, 5, 3, 6, 0.5), (228, 12, 5, 3, 32, 0.5), (40, 6, 2, 2, 5, 0.2)])
+@pytest.mark.parametrize("N,W,multi,H,B,p", [(24, 12, 5, 3, 6, 0.5), (228, 12, 5, 3, 32, 0.5), (40, 6, 2, 2, 5, 0.2),
+                                             (300, 12, 5, 3, 4, 0.5), (64, 12, 5, 3, 3, 0.5)])
 def test_train_mode_dropout_matches_oracle_with_exported_mask(N, W, multi, H, B, p):
     """nn.Dropout's Bernoulli draw (models/base_model.py:161) cannot be RNG-matched; the kernels' Philox
-    mask is exported through the C ABI test hook and fed to the oracle instead."""
+    mask is exported through the C ABI test hook and fed to the oracle instead.  (Round 6: the four words of a Philox call
+    serve four columns 64 apart; N = 300 has a second, ragged column group, N = 64 exactly one word per lane.)"""
     from stemgnn_amd import ops
 
     sd = O.det_state_dict(N, W, multi, H, seed=5)
