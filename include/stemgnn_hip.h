@@ -171,12 +171,24 @@ int stemgnn_gru_bwd(const float* dh_all, const float* x, const float* w_hh, cons
 /* dwk[s] = sum_{b,i} dkey[b,i] h[s,b,i] (dwq likewise) from the factors a parts | 4 call of stemgnn_attn_laplacian_bwd left
  * in `attn_scratch`. */
 int stemgnn_keyquery_wgrad(const float* h, const float* attn_scratch, float* dwk, float* dwq, int B, int N, void* stream);
+/* parts bit 3 (value 8, with bit 2) of stemgnn_attn_laplacian_bwd leaves dquery as per-chunk partials; this sums them (same fixed
+ * order) into `out` [B, N], or into the scratch's own dquery slot when out == NULL.  stemgnn_keyquery_wgrad2: the key / query
+ * weight gradients from explicit dkey / dquery buffers. */
+int stemgnn_attn_dquery_reduce(float* attn_scratch, int B, int N, int nchunk, float* out, void* stream);
+int stemgnn_keyquery_wgrad2(const float* h, const float* dkey, const float* dquery, float* dwk, float* dwq, int B, int N,
+                            void* stream);
 /* stemgnn_gru_bwd with the output gradient given as the rank-2 form dh[s][b][i] = dkey[b][i] wk[s] + dquery[b][i] wq[s]
  * (dkey, dquery [B,Hd]; wk, wq [S]); only where stemgnn_gru_bwd_rank2_ok(B, Hd) (the wave-specialised per-row clusters). */
 int stemgnn_gru_bwd_rank2_ok(int B, int Hd);
 int stemgnn_gru_bwd_rank2(const float* dkey, const float* dquery, const float* wk, const float* wq, const float* x,
                           const float* w_hh, const float* h_ext, const float* reserve, int B, int S, int Hd, int W,
                           float* scratch, float* dw_ih, float* dw_hh, float* db_ih, float* db_hh, int* status, void* stream);
+/* The same with dquery still in the attention backward's per-chunk partials (stemgnn_attn_laplacian_bwd with parts bit 3 set):
+ * `dquery` [B, Hd] is followed by the partials [B][nchunk][Hd], as in the attention scratch; the chunk sum (fixed order: the
+ * bits of stemgnn_attn_laplacian_bwd's own reduction) runs inside the zero-fill launch ahead of the recurrence. */
+int stemgnn_gru_bwd_rank2_dq(const float* dkey, float* dquery, int nchunk, const float* wk, const float* wq, const float* x,
+                             const float* w_hh, const float* h_ext, const float* reserve, int B, int S, int Hd, int W,
+                             float* scratch, float* dw_ih, float* dw_hh, float* db_ih, float* db_hh, int* status, void* stream);
 /* stemgnn_gru_bwd_rank2 as two calls, with the dW_hh product running BESIDE the recurrence instead of behind it (round 5):
  *   _begin  (stream):              the fill of the control words, the fork point, the recurrence -- which now stores the gate
  *                                  gradients write-through and counts finished chunks of 4 time steps per workgroup;

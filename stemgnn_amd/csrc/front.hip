@@ -11,6 +11,7 @@
 #include <stdint.h>
 
 #include "../../include/stemgnn_hip.h"
+#include "dq_reduce.h"
 #include "gemm_core.h"
 #include "layout.h"
 
@@ -403,10 +404,7 @@ __global__ void sg_dquery_reduce_kernel(const float* __restrict__ dqpart, float*
   __builtin_amdgcn_s_setprio(SG_CHAIN_PRIO);      // see gemm_core.h: these run beside the weight-gradient launch
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (size_t)B * N) return;
-  const int b = (int)(idx / N), j = (int)(idx - (size_t)b * N);
-  float s = 0.f;
-  for (int c = 0; c < nchunk; ++c) s += dqpart[((size_t)b * nchunk + c) * N + j];
-  dquery[idx] = s;
+  sg_dquery_reduce_one(dqpart, dquery, N, nchunk, idx);
 }
 
 // dh[s,b,i] = dkey[b,i] wk[s] + dquery[b,i] wq[s];  dwk[s] = sum_{b,i} dkey h ; dwq likewise.  One WG per s.
@@ -614,6 +612,7 @@ extern "C" int stemgnn_attn_laplacian_bwd(const float* dL, const float* h, const
   hipLaunchKernelGGL(sg_attention_bwd_kernel, dim3(B, nchunk), dim3(256), lds, st, dAB, key, query, rowsum, alpha,
                      drop_p, training, seed, B, N, nchunk, dkey, dqpart);
   SG_TRY(hipGetLastError());
+  if ((parts & 8) && factored) return 0;        // the caller sums the partials itself (stemgnn_gru_bwd_rank2_dq / stemgnn_attn_dquery_reduce)
   {
     const size_t bn = (size_t)B * N;
     hipLaunchKernelGGL(sg_dquery_reduce_kernel, dim3((unsigned)((bn + 255) / 256)), dim3(256), 0, st, dqpart, dquery, B,
@@ -622,6 +621,27 @@ extern "C" int stemgnn_attn_laplacian_bwd(const float* dL, const float* h, const
   }
   if (factored) return 0;
   hipLaunchKernelGGL(sg_keyquery_bwd_kernel, dim3(N), dim3(256), 0, st, h, wk, wq, dkey, dquery, dh, dwk, dwq, B, N);
+  SG_TRY(hipGetLastError());
+  return 0;
+}
+
+// The chunk sum of the attention backward's dquery partials as a call of its own (parts bit 3 of stemgnn_attn_laplacian_bwd left
+// them unreduced): into `out` [B, N] (NULL: into the scratch's own dquery slot).  Same fixed order, same bits as the launch
+// inside stemgnn_attn_laplacian_bwd and as the GRU backward's fused fill (stemgnn_gru_bwd_rank2_dq).
+extern "C" int stemgnn_attn_dquery_reduce(float* attn_scratch, int B, int N, int nchunk, float* out, void* stream) {
+  if (!attn_scratch || B <= 0 || N <= 0 || nchunk <= 0) return SG_EINVAL;
+  float* dquery = attn_scratch + (size_t)N * N + (size_t)B * N;
+  const size_t bn = (size_t)B * N;
+  hipLaunchKernelGGL(sg_dquery_reduce_kernel, dim3((unsigned)((bn + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     dquery + bn, out ? out : dquery, B, N, nchunk);
+  SG_TRY(hipGetLastError());
+  return 0;
+}
+// key / query weight gradients from explicit dkey / dquery [B, N] buffers (stemgnn_keyquery_wgrad takes them from the scratch)
+extern "C" int stemgnn_keyquery_wgrad2(const float* h, const float* dkey, const float* dquery, float* dwk, float* dwq, int B,
+                                       int N, void* stream) {
+  if (!h || !dkey || !dquery || !dwk || !dwq || B <= 0 || N <= 0) return SG_EINVAL;
+  hipLaunchKernelGGL(sg_keyquery_wgrad_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, h, dkey, dquery, dwk, dwq, B, N);
   SG_TRY(hipGetLastError());
   return 0;
 }

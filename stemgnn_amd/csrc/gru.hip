@@ -28,6 +28,7 @@
 #include "../../include/stemgnn_hip.h"
 #include "gemm2.h"
 #include "wgrad.h"
+#include "dq_reduce.h"
 #include "gemm_core.h"
 #include "gru_wide.h"
 
@@ -1018,7 +1019,7 @@ extern "C" int stemgnn_gru_bwd_rank2_ok(int B, int Hd) {
 static int gru_bwd_impl(const float* dh_all, const float* dkey, const float* dquery, const float* wk, const float* wq,
                         const float* x, const float* w_hh, const float* h_ext, const float* reserve, int B, int S, int Hd,
                         int W, float* scratch, float* dw_ih, float* dw_hh, float* db_ih, float* db_hh, int* status,
-                        void* stream, int stages = 3, void* side = nullptr, unsigned* ctl = nullptr);
+                        void* stream, int stages = 3, void* side = nullptr, unsigned* ctl = nullptr, int dq_nchunk = 0);
 extern "C" int stemgnn_gru_bwd(const float* dh_all, const float* x, const float* w_hh, const float* h_ext,
                                const float* reserve, int B, int S, int Hd, int W, float* scratch, float* dw_ih,
                                float* dw_hh, float* db_ih, float* db_hh, int* status, void* stream) {
@@ -1033,6 +1034,32 @@ extern "C" int stemgnn_gru_bwd_rank2(const float* dkey, const float* dquery, con
   if (!dkey || !dquery || !wk || !wq || !stemgnn_gru_bwd_rank2_ok(B, Hd)) return SG_EINVAL;
   return gru_bwd_impl(nullptr, dkey, dquery, wk, wq, x, w_hh, h_ext, reserve, B, S, Hd, W, scratch, dw_ih, dw_hh, db_ih, db_hh,
                       status, stream);
+}
+// Round 6: the same call with dquery still in the attention backward's per-chunk partials (stemgnn_attn_laplacian_bwd, parts
+// bit 3; `dquery` [B, Hd] is followed by the partials [B][nchunk][Hd] as in the attention scratch): the chunk sum rides in the
+// zero-fill launch ahead of the recurrence instead of being a launch of its own on the step's critical chain (-9 us at PEMS07).
+__global__ __launch_bounds__(256) void sg_gru_fill_dq_kernel(uint32_t* __restrict__ p, size_t n16, unsigned nfill,
+                                                             const float* __restrict__ dqpart, float* __restrict__ dquery, int B,
+                                                             int N, int nchunk) {
+  if (blockIdx.x < nfill) {                      // zero fill of a 16-byte aligned range of n16 16-byte pieces
+    uint4* q = reinterpret_cast<uint4*>(p);
+    for (size_t k = (size_t)blockIdx.x * 256 + threadIdx.x; k < n16; k += (size_t)nfill * 256) q[k] = make_uint4(0u, 0u, 0u, 0u);
+    return;
+  }
+  const size_t idx = (size_t)(blockIdx.x - nfill) * 256 + threadIdx.x;
+  if (idx < (size_t)B * N) sg_dquery_reduce_one(dqpart, dquery, N, nchunk, idx);
+}
+__global__ void sg_gru_dq_reduce_kernel(const float* __restrict__ dqpart, float* __restrict__ dquery, int B, int N, int nchunk) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx < (size_t)B * N) sg_dquery_reduce_one(dqpart, dquery, N, nchunk, idx);
+}
+extern "C" int stemgnn_gru_bwd_rank2_dq(const float* dkey, float* dquery, int nchunk, const float* wk, const float* wq,
+                                        const float* x, const float* w_hh, const float* h_ext, const float* reserve, int B, int S,
+                                        int Hd, int W, float* scratch, float* dw_ih, float* dw_hh, float* db_ih, float* db_hh,
+                                        int* status, void* stream) {
+  if (!dkey || !dquery || nchunk <= 0 || !wk || !wq || !stemgnn_gru_bwd_rank2_ok(B, Hd)) return SG_EINVAL;
+  return gru_bwd_impl(nullptr, dkey, dquery, wk, wq, x, w_hh, h_ext, reserve, B, S, Hd, W, scratch, dw_ih, dw_hh, db_ih, db_hh,
+                      status, stream, 3, nullptr, nullptr, nchunk);
 }
 // ---- dW_hh beside the recurrence ------------------------------------------------------------------------------------------
 // The two-level K partition of the dW_hh launch (wgrad.h): a pure function of the shape, used by the plain launch too, so
@@ -1106,7 +1133,7 @@ extern "C" int stemgnn_gru_bwd_rank2_finish(const float* dkey, const float* dque
 static int gru_bwd_impl(const float* dh_all, const float* dkey, const float* dquery, const float* wk, const float* wq,
                         const float* x, const float* w_hh, const float* h_ext, const float* reserve, int B, int S, int Hd,
                         int W, float* scratch, float* dw_ih, float* dw_hh, float* db_ih, float* db_hh, int* status,
-                        void* stream, int stages, void* side, unsigned* ctl) {
+                        void* stream, int stages, void* side, unsigned* ctl, int dq_nchunk) {
   if ((!dh_all && !dkey) || !x || !w_hh || !h_ext || !reserve || !scratch || !dw_ih || !dw_hh || !db_ih || !db_hh || !status ||
       B <= 0 || S <= 0 || Hd <= 0 || W <= 0)
     return SG_EINVAL;
@@ -1121,6 +1148,15 @@ static int gru_bwd_impl(const float* dh_all, const float* dkey, const float* dqu
   bool fold_ih = false, hh_fused = false, cnt_zeroed = false, ih_reduced = false;
   const bool run_rec = (stages & 1) != 0, run_wg = (stages & 2) != 0;
   const bool split_call = stages != 3;                   // begin / finish: only where stemgnn_gru_bwd_overlap_ok (the callers check)
+  bool dq_pending = dq_nchunk > 0 && run_rec;            // dquery arrives as per-chunk partials: summed in the fill launch where
+  GruWide dq_probe;
+  if (dq_pending && !(P2 > 0 && gru_pick_wide(B, Hd, P2, &dq_probe) <= 0)) {   // the per-row clusters run, by a launch of its own elsewhere
+    float* dq = const_cast<float*>(dquery);
+    hipLaunchKernelGGL(sg_gru_dq_reduce_kernel, dim3((unsigned)(((size_t)B * Hd + 255) / 256)), dim3(256), 0, st,
+                       dq + (size_t)B * Hd, dq, B, Hd, dq_nchunk);
+    SG_TRY(hipGetLastError());
+    dq_pending = false;
+  }
   // control words of the overlapped dW_hh product (layout: gru_ovl_words)
   unsigned* ovl = ctl ? ctl : reinterpret_cast<unsigned*>(scratch + ((gru_bwd_scratch_base(B, S, Hd, W) + 3) & ~(size_t)3));
   unsigned* ovl_prog = ovl;
@@ -1145,7 +1181,19 @@ static int gru_bwd_impl(const float* dh_all, const float* dkey, const float* dqu
     // progress, the arrival counters of the fused dW_hh kernel, which otherwise costs a ~6 us fill node of its own on the
     // critical path between the recurrence and that kernel (every memset is a graph node with its own launch latency)
     const size_t fill_end = stemgnn_gru_bwd_scratch_floats(B, S, Hd, W) & ~(size_t)3;
-    if (run_rec) SG_TRY(sg_zero_async(xbuf, (fill_end - (size_t)(xtail - scratch)) * sizeof(float), st));
+    if (run_rec && dq_pending) {
+      // the fill and the chunk sum of dquery in ONE launch (dq_pending: the other paths sum with a launch of their own)
+      const size_t n16 = (fill_end - (size_t)(xtail - scratch)) / 4;
+      unsigned nfill = (unsigned)((n16 + 255) / 256);
+      if (nfill > 512) nfill = 512;
+      if (nfill < 1) nfill = 1;
+      const unsigned nred = (unsigned)(((size_t)B * Hd + 255) / 256);
+      float* dq = const_cast<float*>(dquery);
+      hipLaunchKernelGGL(sg_gru_fill_dq_kernel, dim3(nfill + nred), dim3(256), 0, st, reinterpret_cast<uint32_t*>(xbuf), n16, nfill,
+                         dq + (size_t)B * Hd, dq, B, Hd, dq_nchunk);
+      SG_TRY(hipGetLastError());
+      dq_pending = false;
+    } else if (run_rec) SG_TRY(sg_zero_async(xbuf, (fill_end - (size_t)(xtail - scratch)) * sizeof(float), st));
     cnt_zeroed = true;
     if (run_rec && split_call && !ctl) {                 // the fork point of the persistent dW_hh phase: behind the fill
       hipEvent_t ev = gru_fork_event();

@@ -325,11 +325,11 @@ class GruFront(torch.autograd.Function):
         if factors is not None:
             # SpectralHotPath.backward stopped at dkey | dquery: dh[s,b,i] = dkey[b,i] wk[s] + dquery[b,i] wq[s] is formed
             # inside the recurrence (the [N,B,N] gradient tensor is never written; `dh_all` is a zero-stride placeholder)
-            attn_scratch, fb, fn, wk, wq, after = factors
+            attn_scratch, fb, fn, wk, wq, after, dq_chunks = factors
             base = attn_scratch.data_ptr() + 4 * fn * fn
-            args = (base, base + 4 * fb * fn, wk.data_ptr(), wq.data_ptr(), x.data_ptr(), w_hh.data_ptr(), h_ext.data_ptr(),
-                    reserve.data_ptr(), B, S, Hd, W, scratch.data_ptr(), dw_ih.data_ptr(), dw_hh.data_ptr(), db_ih.data_ptr(),
-                    db_hh.data_ptr(), gru_status(dev).data_ptr())
+            tail = (x.data_ptr(), w_hh.data_ptr(), h_ext.data_ptr(), reserve.data_ptr(), B, S, Hd, W, scratch.data_ptr(),
+                    dw_ih.data_ptr(), dw_hh.data_ptr(), db_ih.data_ptr(), db_hh.data_ptr(), gru_status(dev).data_ptr())
+            args = (base, base + 4 * fb * fn, wk.data_ptr(), wq.data_ptr()) + tail
             # overlap mode: the dW_hh product runs on the side stream BESIDE the recurrence (persistent workgroups that follow
             # its progress counters) and only the last few time steps' share + the fixed-order sums stay behind it
             # (include/stemgnn_hip.h: stemgnn_gru_bwd_rank2_begin / _finish; same bits as the single call)
@@ -340,6 +340,10 @@ class GruFront(torch.autograd.Function):
             ctl = ctx.state.gru_ctl.data_ptr() if beside else None
             if beside:
                 _lib.check(lib.stemgnn_gru_bwd_rank2_begin(*args, ctl, _stream()), "gru_bwd_rank2_begin")
+            elif dq_chunks:
+                # dquery is still the attention backward's per-chunk partials: summed inside this call's zero-fill launch
+                _lib.check(lib.stemgnn_gru_bwd_rank2_dq(base, base + 4 * fb * fn, dq_chunks, wk.data_ptr(), wq.data_ptr(), *tail,
+                                                        _stream()), "gru_bwd_rank2_dq")
             else:
                 _lib.check(lib.stemgnn_gru_bwd_rank2(*args, _stream()), "gru_bwd_rank2")
             if after is not None:
@@ -986,12 +990,16 @@ class SpectralHotPath(torch.autograd.Function):
         # exact mode: d(loss_global)/dA = mean over ranks of the local dA, and the flat gradient bucket is AVERAGED later,
         # so every rank back-propagates the rank-mean of dA / B through its own samples
         exact = state.exact_group
+        # round 6: with the factored form on the side-stream schedule the chunk sum of dquery is not a launch of its own on the
+        # chain -- the GRU backward's zero-fill launch carries it (stemgnn_gru_bwd_rank2_dq), the key / query weight gradients
+        # on the side branch sum their own copy (same fixed order, same bits)
+        dq_parts = bool(factored and overlap and kq_direct and not legacy_dt1)
         for part in ((3,) if exact is None else (1, 2)):
             _lib.check(lib.stemgnn_attn_laplacian_bwd(
                 dL.data_ptr(), h.data_ptr(), wk.data_ptr(), wq.data_ptr(), alpha, drop_p, int(training),
                 seed.data_ptr() if use_drop else None, B, N, attn_saved.data_ptr(), attn_scratch.data_ptr(), _NCHUNK,
                 None if factored else dh.data_ptr(), dwk.data_ptr(), dwq.data_ptr(),
-                part | (4 if factored and part != 1 else 0), st), "attn_laplacian_bwd")
+                part | ((4 | (8 if dq_parts else 0)) if factored and part != 1 else 0), st), "attn_laplacian_bwd")
             if exact is not None and part == 1:
                 _all_reduce_mean(attn_scratch[:N * N], exact)
         if factored:
@@ -1000,8 +1008,15 @@ class SpectralHotPath(torch.autograd.Function):
                 kq_ready = torch.cuda.Event()                         # queued by GruFront.backward BEHIND its own launches
                 kq_ready.record(main)                                 # (capture order, see above)
                 pend, hh, kdwk, kdwq = state.pending, h, dwk, dwq
+                dq2 = torch.empty(B, N, device=dev, dtype=f32) if dq_parts else None
 
                 def kq_wgrad(stream):
+                    if dq2 is not None:
+                        _lib.check(lib.stemgnn_attn_dquery_reduce(attn_scratch.data_ptr(), B, N, _NCHUNK, dq2.data_ptr(), stream),
+                                   "attn_dquery_reduce")
+                        _lib.check(lib.stemgnn_keyquery_wgrad2(hh.data_ptr(), attn_scratch.data_ptr() + 4 * N * N, dq2.data_ptr(),
+                                                               kdwk.data_ptr(), kdwq.data_ptr(), B, N, stream), "keyquery_wgrad2")
+                        return
                     _lib.check(lib.stemgnn_keyquery_wgrad(hh.data_ptr(), attn_scratch.data_ptr(), kdwk.data_ptr(),
                                                           kdwq.data_ptr(), B, N, stream), "keyquery_wgrad")
 
@@ -1009,10 +1024,10 @@ class SpectralHotPath(torch.autograd.Function):
                     side.wait_event(kq_ready)
                     with torch.cuda.stream(side):
                         kq_wgrad(side.cuda_stream)
-                    pend[1][0].append((attn_scratch, hh))
+                    pend[1][0].append((attn_scratch, hh, dq2))
                 if state.side_probe is not None:
                     state.side_probe.append(kq_wgrad)
-            state.dh_factors = (attn_scratch, B, N, wk, wq, after)
+            state.dh_factors = (attn_scratch, B, N, wk, wq, after, _NCHUNK if dq_parts else 0)
             if after is None:
                 _lib.check(lib.stemgnn_keyquery_wgrad(h.data_ptr(), attn_scratch.data_ptr(), dwk.data_ptr(), dwq.data_ptr(),
                                                       B, N, st), "keyquery_wgrad")
