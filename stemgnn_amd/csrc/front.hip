@@ -271,6 +271,46 @@ __global__ __launch_bounds__(256) void sg_laplacian_bwd_kernel(const float* __re
   const float sq = sqrtf(di);
   const float dhi = 1.f / (sq + 1e-7f);
   float dd = 0.f;
+  const float invB = 1.f / (float)B;
+  if (N <= 256) {
+    // round 6: every load of the row -- dL and A along the row and down the column, the degrees -- is issued BEFORE the first
+    // use and kept in registers for the second pass (the two passes re-read the same elements; as two loops of four dependent
+    // rounds each the kernel was ~8 L2 round trips long: 11.8 us for 0.4 MB).  Same operations in the same order.
+    float a_ij[4], a_ji[4], l_ij[4], l_ji[4], dg[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int j = lane + 64 * t, jj = j < N ? j : N - 1;
+      l_ij[t] = dL[(size_t)i * N + jj]; l_ji[t] = dL[(size_t)jj * N + i];
+      dg[t] = deg[jj];
+      a_ij[t] = with_degree ? A[(size_t)i * N + jj] : 0.f;
+      a_ji[t] = with_degree ? A[(size_t)jj * N + i] : 0.f;
+    }
+    if (with_degree) {
+      float ddh = 0.f;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int j = lane + 64 * t;
+        if (j < N) {
+          const float s = 0.5f * (a_ij[t] + a_ji[t]);
+          const float qv = (i == j ? di : 0.f) - s;
+          const float dhj = 1.f / (sqrtf(dg[t]) + 1e-7f);
+          ddh += (l_ij[t] + l_ji[t]) * qv * dhj;
+        }
+      }
+      ddh = sg_wave_sum(ddh);
+      dd = -ddh * dhi * dhi / (2.f * sq) + dL[(size_t)i * N + i] * dhi * dhi;
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int j = lane + 64 * t;
+      if (j < N) {
+        const float dhj = 1.f / (sqrtf(dg[t]) + 1e-7f);
+        const float dq = (l_ij[t] + l_ji[t]) * dhi * dhj;
+        dAB[(size_t)i * N + j] = (dd - 0.5f * dq) * invB;
+      }
+    }
+    return;
+  }
   if (with_degree) {
     float ddh = 0.f;
     for (int j = lane; j < N; j += 64) {
@@ -282,7 +322,6 @@ __global__ __launch_bounds__(256) void sg_laplacian_bwd_kernel(const float* __re
     ddh = sg_wave_sum(ddh);
     dd = -ddh * dhi * dhi / (2.f * sq) + dL[(size_t)i * N + i] * dhi * dhi;
   }
-  const float invB = 1.f / (float)B;
   for (int j = lane; j < N; j += 64) {
     const float dhj = 1.f / (sqrtf(deg[j]) + 1e-7f);
     const float dq = (dL[(size_t)i * N + j] + dL[(size_t)j * N + i]) * dhi * dhj;
