@@ -60,8 +60,8 @@ OTHER_CONFIGS = [
 FP32_MFMA_PEAK_TFLOPS = 157.3                          # MI355X_MICROARCH.md: v_mfma_f32_* dense peak
 BF16_MFMA_PEAK_TFLOPS = 2500.0                         # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16 dense peak (2 495 measured)
 # HBM bytes / MFMA utilisation per family from the committed PMC passes, one file per arithmetic of the GLU products
-TRAFFIC_FILES = {"bf16x2": os.path.join(ROOT, "profiles", "r05_pmc_traffic_bf16x2.json")}
-TRAFFIC_FILE_F32 = os.path.join(ROOT, "profiles", "r05_pmc_traffic.json")
+TRAFFIC_FILES = {"bf16x2": os.path.join(ROOT, "profiles", "r06_pmc_traffic_bf16x2.json")}
+TRAFFIC_FILE_F32 = os.path.join(ROOT, "profiles", "r06_pmc_traffic.json")
 
 
 def _self_launch(args):
@@ -241,6 +241,27 @@ def step_roofline(cfg, ms_per_step):
             "note": "algorithmic FLOPs of SURVEY 8d (F_step = 3 F_fwd, GRU excluded) / measured step time / fp32 MFMA peak"}
 
 
+def rocprof_static_us():
+    """Average launch durations (us) of the step's big kernels from the committed rocprofv3 --kernel-trace --stats summary of the
+    ISOLATED timing loops (profiles/r06_kernel_stats_isolated*.txt, tools/gpu_job.sh prof_iso): constants, labelled as such --
+    the live HIP-event figures beside them must agree."""
+    name = "r06_kernel_stats_isolated_bf16x2.txt" if os.environ.get("STEMGNN_DTYPE") == "bf16x2" else "r06_kernel_stats_isolated.txt"
+    path = os.path.join(ROOT, "profiles", name)
+    out = {"source": "profiles/" + name}
+    if not os.path.isfile(path):
+        return out
+    for ln in open(path):
+        parts = ln.split()
+        if len(parts) < 7 or parts[1] != "us/step":
+            continue
+        kernel = " ".join(parts[6:])
+        for key in ("gru_fwd_cluster4_kernel", "gru_bwd_cluster4_kernel", "sg_glu_fused_fwd", "sg_glu_fused_dgrad",
+                    "sg_wgrad_kernel<16, 6, false, true>", "sg_wgrad_kernel<16, 6, false, false>", "GruGiOp"):
+            if key in kernel and key not in out:
+                out[key] = float(parts[2])
+    return out
+
+
 def roofline_objects(cfg):
     fams = time_gemm_families(cfg)
     alg, exe = glu_flops(cfg)
@@ -287,6 +308,9 @@ def roofline_objects(cfg):
                       "frac_executed": fl[name] / s / 1e12 / FP32_MFMA_PEAK_TFLOPS, "avg_launch_us": us / launches,
                       "vs_fp32_mfma_peak": fl[name] / s / 1e12 / FP32_MFMA_PEAK_TFLOPS, "launches_per_step": launches,
                       "sum_us_per_step": us, "flops_algorithmic": fl[name], "flops_executed": fl[name], "traffic": None,
+                      "traffic_static_pmc": traffic.get("kernels", {}).get(name),       # the recurrence kernel alone
+                      "mfma_util_static_pmc": traffic.get("mfma_util", {}).get(name),
+                      "traffic_static_pmc_source": traffic.get("source"),
                       "us_per_recurrence_step": us / cfg["N"]}
     # critical-path time per step: the GLU forward and data-gradient launches and every GRU launch sit on the chain; the GLU
     # weight-gradient launches run on the side branch beside the backward chain / under the GRU recurrence
@@ -296,6 +320,8 @@ def roofline_objects(cfg):
     dominant = max(rows, key=lambda k: rows[k]["critical_us_per_step"])
     main = dict(rows[dominant])
     main["family"] = dominant
+    if cfg == WORKLOAD:
+        main["rocprof_isolated_avg_us_static"] = rocprof_static_us()
     main["why"] = ("the kernel family with the largest time on the step's CRITICAL PATH (each family timed live in isolation through "
                    "the C ABI, HIP events on the launch stream; frac = algorithmic FLOPs / time / fp32 MFMA peak); the MFMA GEMM "
                    "families are in roofline_families, the largest of them by summed GPU time in `roofline_mfma`")
