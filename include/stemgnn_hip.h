@@ -185,8 +185,10 @@ int stemgnn_gru_bwd_rank2(const float* dkey, const float* dquery, const float* w
                           float* scratch, float* dw_ih, float* dw_hh, float* db_ih, float* db_hh, int* status, void* stream);
 /* The same with dquery still in the attention backward's per-chunk partials (stemgnn_attn_laplacian_bwd with parts bit 3 set):
  * `dquery` [B, Hd] is followed by the partials [B][nchunk][Hd], as in the attention scratch; the chunk sum (fixed order: the
- * bits of stemgnn_attn_laplacian_bwd's own reduction) runs inside the zero-fill launch ahead of the recurrence. */
-int stemgnn_gru_bwd_rank2_dq(const float* dkey, float* dquery, int nchunk, const float* wk, const float* wq, const float* x,
+ * bits of stemgnn_attn_laplacian_bwd's own reduction) runs inside the zero-fill launch ahead of the recurrence.
+ * flags bit 0: the dW_hh product as three-term split-bf16 on the bf16 matrix pipe (STEMGNN_DTYPE=bf16x2; ~2^-16 relative per
+ * product, fp32 accumulation, same fixed-order split reduction); 0: exact fp32. */
+int stemgnn_gru_bwd_rank2_dq(const float* dkey, float* dquery, int nchunk, int flags, const float* wk, const float* wq, const float* x,
                              const float* w_hh, const float* h_ext, const float* reserve, int B, int S, int Hd, int W,
                              float* scratch, float* dw_ih, float* dw_hh, float* db_ih, float* db_hh, int* status, void* stream);
 /* stemgnn_gru_bwd_rank2 as two calls, with the dW_hh product running BESIDE the recurrence instead of behind it (round 5):

@@ -57,7 +57,7 @@ SIGNATURES = {
     "stemgnn_gru_bwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P]),
     "stemgnn_gru_bwd_rank2_ok": (c_int, [c_int, c_int]),
     "stemgnn_gru_bwd_rank2": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P]),
-    "stemgnn_gru_bwd_rank2_dq": (c_int, [_P, _P, c_int, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P]),
+    "stemgnn_gru_bwd_rank2_dq": (c_int, [_P, _P, c_int, c_int, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P]),
     "stemgnn_gru_bwd_overlap_ok": (c_int, [c_int, c_int, c_int, c_int]),
     "stemgnn_gru_bwd_ctl_words": (c_size_t, [c_int]),
     "stemgnn_gru_bwd_rank2_begin": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P]),

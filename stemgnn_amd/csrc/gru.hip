@@ -1019,7 +1019,8 @@ extern "C" int stemgnn_gru_bwd_rank2_ok(int B, int Hd) {
 static int gru_bwd_impl(const float* dh_all, const float* dkey, const float* dquery, const float* wk, const float* wq,
                         const float* x, const float* w_hh, const float* h_ext, const float* reserve, int B, int S, int Hd,
                         int W, float* scratch, float* dw_ih, float* dw_hh, float* db_ih, float* db_hh, int* status,
-                        void* stream, int stages = 3, void* side = nullptr, unsigned* ctl = nullptr, int dq_nchunk = 0);
+                        void* stream, int stages = 3, void* side = nullptr, unsigned* ctl = nullptr, int dq_nchunk = 0,
+                        int wg_split = 0);
 extern "C" int stemgnn_gru_bwd(const float* dh_all, const float* x, const float* w_hh, const float* h_ext,
                                const float* reserve, int B, int S, int Hd, int W, float* scratch, float* dw_ih,
                                float* dw_hh, float* db_ih, float* db_hh, int* status, void* stream) {
@@ -1053,13 +1054,13 @@ __global__ void sg_gru_dq_reduce_kernel(const float* __restrict__ dqpart, float*
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx < (size_t)B * N) sg_dquery_reduce_one(dqpart, dquery, N, nchunk, idx);
 }
-extern "C" int stemgnn_gru_bwd_rank2_dq(const float* dkey, float* dquery, int nchunk, const float* wk, const float* wq,
+extern "C" int stemgnn_gru_bwd_rank2_dq(const float* dkey, float* dquery, int nchunk, int flags, const float* wk, const float* wq,
                                         const float* x, const float* w_hh, const float* h_ext, const float* reserve, int B, int S,
                                         int Hd, int W, float* scratch, float* dw_ih, float* dw_hh, float* db_ih, float* db_hh,
                                         int* status, void* stream) {
-  if (!dkey || !dquery || nchunk <= 0 || !wk || !wq || !stemgnn_gru_bwd_rank2_ok(B, Hd)) return SG_EINVAL;
+  if (!dkey || !dquery || nchunk <= 0 || (flags & ~1) || !wk || !wq || !stemgnn_gru_bwd_rank2_ok(B, Hd)) return SG_EINVAL;
   return gru_bwd_impl(nullptr, dkey, dquery, wk, wq, x, w_hh, h_ext, reserve, B, S, Hd, W, scratch, dw_ih, dw_hh, db_ih, db_hh,
-                      status, stream, 3, nullptr, nullptr, nchunk);
+                      status, stream, 3, nullptr, nullptr, nchunk, flags & 1);
 }
 // ---- dW_hh beside the recurrence ------------------------------------------------------------------------------------------
 // The two-level K partition of the dW_hh launch (wgrad.h): a pure function of the shape, used by the plain launch too, so
@@ -1133,7 +1134,7 @@ extern "C" int stemgnn_gru_bwd_rank2_finish(const float* dkey, const float* dque
 static int gru_bwd_impl(const float* dh_all, const float* dkey, const float* dquery, const float* wk, const float* wq,
                         const float* x, const float* w_hh, const float* h_ext, const float* reserve, int B, int S, int Hd,
                         int W, float* scratch, float* dw_ih, float* dw_hh, float* db_ih, float* db_hh, int* status,
-                        void* stream, int stages, void* side, unsigned* ctl, int dq_nchunk) {
+                        void* stream, int stages, void* side, unsigned* ctl, int dq_nchunk, int wg_split) {
   if ((!dh_all && !dkey) || !x || !w_hh || !h_ext || !reserve || !scratch || !dw_ih || !dw_hh || !db_ih || !db_hh || !status ||
       B <= 0 || S <= 0 || Hd <= 0 || W <= 0)
     return SG_EINVAL;
@@ -1328,7 +1329,9 @@ static int gru_bwd_impl(const float* dh_all, const float* dkey, const float* dqu
           tl.phase = 2;
           SG_TRY(wg_launch(q, 2, S * B, p_hh, cnt, smax, st, false, 100, false, exr, &tl));
         } else {
-          SG_TRY(wg_launch(q, 2, S * B, p_hh, cnt, smax, st, !cnt_zeroed, 100, false, exr, two ? &tl : nullptr));
+          // wg_split (stemgnn_gru_bwd_rank2_dq, flags bit 0): dW_hh as three-term split-bf16 on the bf16 matrix pipe
+          // (wgrad.h wg_kloop_bf16) -- the plain launch only
+          SG_TRY(wg_launch(q, 2, S * B, p_hh, cnt, smax, st, !cnt_zeroed, 100, false, exr, two ? &tl : nullptr, wg_split && !two));
         }
         hh_fused = true;
         ih_reduced = exr != nullptr;

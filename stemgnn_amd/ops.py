@@ -342,8 +342,10 @@ class GruFront(torch.autograd.Function):
                 _lib.check(lib.stemgnn_gru_bwd_rank2_begin(*args, ctl, _stream()), "gru_bwd_rank2_begin")
             elif dq_chunks:
                 # dquery is still the attention backward's per-chunk partials: summed inside this call's zero-fill launch
-                _lib.check(lib.stemgnn_gru_bwd_rank2_dq(base, base + 4 * fb * fn, dq_chunks, wk.data_ptr(), wq.data_ptr(), *tail,
-                                                        _stream()), "gru_bwd_rank2_dq")
+                # (bf16x2: the dW_hh product on the bf16 matrix pipe as well, like the blocks' weight gradients)
+                wg_split = 1 if glu_splits() == 2 and os.environ.get("STEMGNN_WGRAD_BF16", "1") != "0" else 0
+                _lib.check(lib.stemgnn_gru_bwd_rank2_dq(base, base + 4 * fb * fn, dq_chunks, wg_split, wk.data_ptr(), wq.data_ptr(),
+                                                        *tail, _stream()), "gru_bwd_rank2_dq")
             else:
                 _lib.check(lib.stemgnn_gru_bwd_rank2(*args, _stream()), "gru_bwd_rank2")
             if after is not None:
