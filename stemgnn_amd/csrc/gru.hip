@@ -1331,7 +1331,13 @@ static int gru_bwd_impl(const float* dh_all, const float* dkey, const float* dqu
         } else {
           // wg_split (stemgnn_gru_bwd_rank2_dq, flags bit 0): dW_hh as three-term split-bf16 on the bf16 matrix pipe
           // (wgrad.h wg_kloop_bf16) -- the plain launch only
-          SG_TRY(wg_launch(q, 2, S * B, p_hh, cnt, smax, st, !cnt_zeroed, 100, false, exr, two ? &tl : nullptr, wg_split && !two));
+          // parallel final sum (wgrad.h WgArgs::cnt2) where the fill ahead of the recurrence has zeroed the group counters (the
+          // per-row clusters) and the launch fits the chip in one round; STEMGNN_WHH_PARSUM=0 keeps the last-arriver sum
+          static const int parsum_env = !(getenv("STEMGNN_WHH_PARSUM") && atoi(getenv("STEMGNN_WHH_PARSUM")) == 0);
+          // (wg_splits never makes more workgroups than CUs, one per CU: the tile's S workgroups are co-resident)
+          unsigned* cnt2 = (parsum_env && !two && cnt_zeroed) ? ovl_cntA : nullptr;
+          SG_TRY(wg_launch(q, 2, S * B, p_hh, cnt, smax, st, !cnt_zeroed, 100, false, exr, two ? &tl : nullptr, wg_split && !two,
+                           cnt2, status));
         }
         hh_fused = true;
         ih_reduced = exr != nullptr;

@@ -103,6 +103,15 @@ struct WgArgs {
   unsigned timeout;
   unsigned* claim;
   unsigned* qhead;
+  // ---- parallel final sum (round 6: the GRU's dW_hh, the one weight-gradient launch on the step's critical tail) --------------
+  // cnt2 != nullptr (plain launches whose workgroups are all co-resident: one per CU): instead of the LAST arriver of a tile
+  // summing all S partial tiles alone (21 x 64 KB through one CU: ~13 us of the 50 us launch), EVERY split's workgroup waits
+  // for the tile's S arrivals (bounded spin) and sums ITS 1/S of the tile's elements over the S partials -- the same slot
+  // order per element, i.e. the same bits -- and stores them.  cnt2: a second counter per tile (zero at launch): the last
+  // workgroup to finish re-arms both.  psum_status: set to 1 if the bounded wait ran out (never expected; the results are
+  // incomplete then and the caller's status word says so).
+  unsigned* cnt2;
+  int* psum_status;
 };
 #ifdef SG_WG_DEBUG
 #define WG_DBG(g, bit) ((g).dbg & (bit))
@@ -554,6 +563,71 @@ __device__ __forceinline__ void wg_body(const WgArgs& g, float* lds, int gi, int
 
   // ---- epilogue ------------------------------------------------------------------------------------------------------
   const int S = g.S;
+  if (S > 1 && g.cnt2 != nullptr && g.SB == 0) {
+    // ---- parallel final sum: see WgArgs::cnt2 ---------------------------------------------------------------------------
+    const int tile = G.tile0 + by * G.nx + bx;
+    float* wsl = g.ws + (size_t)tile * S * WG_TILE_FLOATS;
+    wg_store_partial(wsl + (size_t)s * WG_TILE_FLOATS + wave * 4096 + lane * 4, acc);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wave drains its write-through stores
+    __syncthreads();
+    volatile int* flag = reinterpret_cast<volatile int*>(lds);
+    if (tid == 0) {
+      __hip_atomic_fetch_add(&g.cnt[tile], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      unsigned spins = 0;
+      int ok = 1;
+      while (__hip_atomic_load(&g.cnt[tile], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)S) {
+        if (++spins > (1u << 22)) { ok = 0; break; }
+        __builtin_amdgcn_s_sleep(2);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // the other splits' write-through partials: ONE invalidate, plain loads
+      flag[0] = ok;
+    }
+    __syncthreads();
+    const int ok = flag[0];
+    if (!ok) {
+      if (tid == 0 && g.psum_status) *g.psum_status = 1;
+      return;
+    }
+    float* __restrict__ out = G.out;
+    float* __restrict__ out_bias = G.out_bias;
+    const int ldo = G.ldo;
+    const int nstore = out_bias ? ncolB : Nj;
+    const int per = (4096 + S - 1) / S;                     // float4 elements of the tile image per split
+    const int e1 = min(4096, (s + 1) * per);
+    for (int e = s * per + tid; e < e1; e += 256) {
+      const float* rd = wsl + (size_t)e * 4;
+      wg_f4 sum = *reinterpret_cast<const wg_f4*>(rd);
+      for (int ss = 1; ss < S; ss += 8) {                   // eight partials in flight (the ragged last batch too: loads from
+        wg_f4 v[8];                                         // a clamped slot, adds guarded), added in slot order
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const wg_f4*>(rd + (size_t)(ss + u < S ? ss + u : S - 1) * WG_TILE_FLOATS);
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (ss + u < S) sum += v[u];
+      }
+      // image index -> (wave, MFMA tile (i, j), register group q, lane): float index = wave 4096 + ((i 2 + j) 4 + q) 256 + lane 4
+      const int wv = e >> 10, ijq = (e >> 6) & 15, ln = e & 63;
+      const int ti = ijq >> 3, tj = (ijq >> 2) & 1, q4 = ijq & 3;
+      const int wmm = WIDE ? wv : wv >> 1, wnn = WIDE ? 0 : wv & 1;
+      const int col = n0 + wnn * 64 + 2 * (ln & 31) + tj;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        const int row = m0 + wmm * 64 + 2 * g2_row_of(4 * q4 + w, ln) + ti;
+        if (row >= Mi) continue;
+        if (col < nstore) out[(size_t)row * ldo + col] = sum[w];
+        if (out_bias && col == ones_col) out_bias[row] = sum[w];
+      }
+    }
+    __syncthreads();
+    if (tid == 0) {                                        // the last workgroup to finish re-arms the tile's counters
+      const unsigned d = __hip_atomic_fetch_add(&g.cnt2[tile], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (d == (unsigned)S - 1) {
+        __hip_atomic_store(&g.cnt[tile], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&g.cnt2[tile], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    return;
+  }
   if (S > 1) {
     const int SB = g.SB;
     const int tile = G.tile0 + by * G.nx + bx;
@@ -659,8 +733,18 @@ __global__ __launch_bounds__(256, 1) void sg_wgrad_kernel(const WgArgs g) {
     const size_t idx = (size_t)(blockIdx.x - g.nmain) * 256 + threadIdx.x;
     const size_t slab = (size_t)g.ex.rows * (g.ex.cols + 1);
     if (idx >= slab) return;
+    // sixteen slabs in flight, added in slab order: as a `sum += load` loop of runtime length the 32 batch-row slabs were 32
+    // dependent L2 round trips (~20 us), run AFTER the GEMM's workgroups had left their CUs -- the tail of the whole launch
     float sum = 0.f;
-    for (int z = 0; z < g.ex.nsplit; ++z) sum += g.ex.part[(size_t)z * slab + idx];
+    int z = 0;
+    for (; z + 16 <= g.ex.nsplit; z += 16) {
+      float v[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) v[u] = g.ex.part[(size_t)(z + u) * slab + idx];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) sum += v[u];
+    }
+    for (; z < g.ex.nsplit; ++z) sum += g.ex.part[(size_t)z * slab + idx];
     const int j = (int)(idx / (g.ex.cols + 1)), k = (int)(idx - (size_t)j * (g.ex.cols + 1));
     if (k < g.ex.cols) g.ex.out_w[(size_t)j * g.ex.cols + k] = sum;
     else g.ex.out_b[j] = sum;
@@ -818,7 +902,8 @@ struct WgTwoLevel {
 // split_bf16: the products as three-term split-bf16 on the bf16 matrix pipe (wg_stage_bf16) -- plain launches only
 static inline hipError_t wg_launch(WgGemm* q, int n, int K, float* ws, unsigned* cnt, int smax_ws, hipStream_t st,
                                    bool zero_counters = true, int cu_percent = 100, bool flat = false,
-                                   const WgExtra* extra = nullptr, const WgTwoLevel* tl = nullptr, bool split_bf16 = false) {
+                                   const WgExtra* extra = nullptr, const WgTwoLevel* tl = nullptr, bool split_bf16 = false,
+                                   unsigned* cnt2 = nullptr, int* psum_status = nullptr) {
   if (n <= 0 || n > WG_MAXG || K <= 0) return hipErrorInvalidValue;
   const WgPlan p = wg_plan();
   WgArgs a;
@@ -856,6 +941,7 @@ static inline hipError_t wg_launch(WgGemm* q, int n, int K, float* ws, unsigned*
   a.S = (KT + a.ktps - 1) / a.ktps;              // no empty split
   a.SB = a.ktpsB = a.kB = 0; a.cntA = nullptr; a.phase = 0; a.prog = nullptr; a.prog_ts = a.prog_rows = 1; a.prog_need = 0;
   a.timeout = 0; a.claim = a.qhead = nullptr;
+  a.cnt2 = (!tl && !flat) ? cnt2 : nullptr; a.psum_status = psum_status;
   if (tl) {
     // the same S workgroups per tile as the uniform partition would use: SB short splits over the late rows, the rest
     // over the others (a pure function of the shape: every phase and the plain launch derive the SAME partition)
