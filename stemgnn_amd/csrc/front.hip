@@ -108,6 +108,55 @@ __global__ __launch_bounds__(256) void sg_attention_fwd_kernel(
   uint64_t seed = 0, offset = 0;
   if (drop) { seed = seedp[0]; offset = seedp[1]; }
   const float keep_scale = drop ? 1.f / (1.f - drop_p) : 1.f;
+  if (N <= 256) {
+    // round 6: a lane's four columns (64 apart) stay in registers over the chunk's batches -- the exponentials of the first pass
+    // are the second pass's (one expf per element instead of two), the running batch sum needs no LDS read-modify-write, and
+    // the four query values of a batch are requested together.  Same operations on the same values in the same order.
+    float ar[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int b = b0; b < b1; ++b) {
+      const float kv = key[(size_t)b * N + i];
+      const float mx = sg_lrelu(kv + qmax[b - b0], alpha);    // leaky-relu is monotone: row max is at max_j query
+      const float* q = query + (size_t)b * N;
+      float qv[4], e[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int j = lane + 64 * t;
+        qv[t] = q[j < N ? j : N - 1];
+      }
+      float s = 0.f;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        e[t] = lane + 64 * t < N ? expf(sg_lrelu(kv + qv[t], alpha) - mx) : 0.f;
+        if (lane + 64 * t < N) s += e[t];
+      }
+      s = sg_wave_sum(s);
+      if (lane == 0) rowsum[(size_t)b * N + i] = s;
+      const float inv = 1.f / s;
+      uint32_t w[4] = {0u, 0u, 0u, 0u};
+      if (drop) sg_philox4(seed, offset, ((uint64_t)b * N + i) * sg_drop_nq(N) + lane, w);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        if (lane + 64 * t < N) {
+          float p = e[t] * inv;
+          if (drop) p = sg_keep_word(w[t], drop_p) ? p * keep_scale : 0.f;
+          ar[t] += p;
+        }
+      }
+    }
+    float* out = Apart + ((size_t)blockIdx.y * N + i) * N;
+    float d = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int j = lane + 64 * t;
+      if (j < N) {
+        out[j] = ar[t];
+        d += ar[t];
+      }
+    }
+    d = sg_wave_sum(d);                               // this chunk's share of the degree of row i (times B)
+    if (lane == 0) degpart[(size_t)blockIdx.y * N + i] = d;
+    return;
+  }
   for (int j = lane; j < N; j += 64) acc[j] = 0.f;
   for (int b = b0; b < b1; ++b) {
     const float kv = key[(size_t)b * N + i];
@@ -355,6 +404,7 @@ __global__ __launch_bounds__(256) void sg_attention_bwd_kernel(
   const float keep_scale = drop ? 1.f / (1.f - drop_p) : 1.f;
   const int rows = (N + nchunk - 1) / nchunk;
   const int i_end = min(N, (chunk + 1) * rows);
+  float dqr[4] = {0.f, 0.f, 0.f, 0.f};                   // round 6: the first four column groups' dquery sums stay in registers
   for (int i = chunk * rows + wave; i < i_end; i += 4) {
     const float kv = key[(size_t)b * N + i];
     const float mx = sg_lrelu(kv + qmax, alpha);
@@ -404,7 +454,7 @@ __global__ __launch_bounds__(256) void sg_attention_bwd_kernel(
         const float de = pc[t] * (dc[t] - dot);
         const float dpre = pre > 0.f ? de : alpha * de;
         dk += dpre;
-        dq[j] += dpre;
+        dqr[t] += dpre;
       }
     }
     for (int j0 = 256; j0 < N; j0 += 256) {
@@ -427,6 +477,11 @@ __global__ __launch_bounds__(256) void sg_attention_bwd_kernel(
     }
     dk = sg_wave_sum(dk);
     if (lane == 0) dkey[(size_t)b * N + i] = dk;
+  }
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int j = lane + 64 * t;
+    if (j < N) dq[j] = dqr[t];                           // (zero-initialised above; the columns >= 256 accumulate in LDS)
   }
   __syncthreads();
   float* out = dqpart + ((size_t)b * nchunk + chunk) * N;
