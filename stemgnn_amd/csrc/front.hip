@@ -405,10 +405,32 @@ __global__ __launch_bounds__(256) void sg_attention_bwd_kernel(
   const int rows = (N + nchunk - 1) / nchunk;
   const int i_end = min(N, (chunk + 1) * rows);
   float dqr[4] = {0.f, 0.f, 0.f, 0.f};                   // round 6: the first four column groups' dquery sums stay in registers
+  // round 6: the loads of a wave's NEXT row (key, row sum, the first 4 x 64 columns of dA) are requested before the current
+  // row is worked on, and the query values of those columns are loaded once for all rows: a row was a chain of ~1 us of L2
+  // latency + two wave reductions, four rows in sequence per wave
+  float qv[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int j = lane + 64 * t;
+    qv[t] = q[j < N ? j : N - 1];
+  }
+  float n_kv = 0.f, n_rs = 1.f, n_dA[4] = {0.f, 0.f, 0.f, 0.f};
+  auto fetch_row = [&](int i) {
+    n_kv = key[(size_t)b * N + i];
+    n_rs = rowsum[(size_t)b * N + i];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int j = lane + 64 * t;
+      n_dA[t] = dAB[(size_t)i * N + (j < N ? j : N - 1)];
+    }
+  };
+  if (chunk * rows + wave < i_end) fetch_row(chunk * rows + wave);
   for (int i = chunk * rows + wave; i < i_end; i += 4) {
-    const float kv = key[(size_t)b * N + i];
+    const float kv = n_kv;
     const float mx = sg_lrelu(kv + qmax, alpha);
-    const float inv = 1.f / rowsum[(size_t)b * N + i];
+    const float inv = 1.f / n_rs;
+    const float dA4[4] = {n_dA[0], n_dA[1], n_dA[2], n_dA[3]};
+    if (i + 4 < i_end) fetch_row(i + 4);
     const float* dA = dAB + (size_t)i * N;
     // pass 1: p and the (dropout-masked) dp of the first 4 x 64 columns stay in registers for pass 2 (one exp and
     // one Philox per element instead of two); columns >= 256 are recomputed
@@ -421,9 +443,8 @@ __global__ __launch_bounds__(256) void sg_attention_bwd_kernel(
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         const int j = lane + 64 * t;
-        const int jj = j < N ? j : N - 1;
-        float p = expf(sg_lrelu(kv + q[jj], alpha) - mx) * inv;
-        float dp = dA[jj];
+        float p = expf(sg_lrelu(kv + qv[t], alpha) - mx) * inv;
+        float dp = dA4[t];
         if (drop) dp = sg_keep_word(w[t], drop_p) ? dp * keep_scale : 0.f;
         if (j >= N) { p = 0.f; dp = 0.f; }
         pc[t] = p; dc[t] = dp;
@@ -450,7 +471,7 @@ __global__ __launch_bounds__(256) void sg_attention_bwd_kernel(
     for (int t = 0; t < 4; ++t) {
       const int j = lane + 64 * t;
       if (j < N) {
-        const float pre = kv + q[j];
+        const float pre = kv + qv[t];
         const float de = pc[t] * (dc[t] - dot);
         const float dpre = pre > 0.f ? de : alpha * de;
         dk += dpre;
