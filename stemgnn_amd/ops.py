@@ -670,6 +670,16 @@ def prepack_blocks(state, block_params, W, multi, device, batch_shape=None):
             state.side_probe.append(pack)
         if splits:      # (allocated on the current stream like the packed panels; the side stream only runs the kernel)
             split.append(_split_panels(lib, pk, W, multi, splits, device, side.cuda_stream))
+    # control words of the GRU's dW_hh product beside the backward recurrence (opt-in, STEMGNN_GRU_WHH_OVERLAP=1): zeroed HERE,
+    # on the side branch under the GRU forward -- ordered ahead of the recurrence through the join that precedes the attention
+    # kernels, and ahead of the side launch that reads them by stream order (round 6: the backward's schedule has no side ->
+    # main edge ahead of the recurrence any more)
+    if batch_shape is not None and bool(lib.stemgnn_gru_bwd_overlap_ok(batch_shape[0], batch_shape[1], batch_shape[1], W)):
+        nctl = lib.stemgnn_gru_bwd_ctl_words(batch_shape[1])
+        if state.gru_ctl is None or state.gru_ctl.numel() != nctl or state.gru_ctl.device != torch.device(device):
+            state.gru_ctl = torch.zeros(nctl, device=device, dtype=torch.int32)
+        _lib.check(lib.stemgnn_fill_zero(state.gru_ctl.data_ptr(), 4 * nctl, side.cuda_stream), "fill_zero")
+        state.gru_ctl_zeroed = True
     # warm-up of the fused GLU forward (stemgnn_spectral_glu_fwd_warm): the kernel's code and block 0's weight stream into the
     # XCDs' L2 on eight CUs the GRU recurrence leaves idle; the first real launch of the step is ~10 us shorter for it
     # (exact fp32 only: the split-bf16 kernel is a third of the size and shows no first-launch penalty -- 38.1 / 37.6 us for the
@@ -893,12 +903,10 @@ class SpectralHotPath(torch.autograd.Function):
         # Capture order matters inside the hipGraph step: at a fork the FIRST captured successor of a node stays on its
         # queue, every later one moves to another queue behind a cross-queue edge (~10 us).  So at every fork the main
         # stream's next kernel (the critical chain) is queued before the side stream's work that forks at the same node.
-        # Block 1's share of d(mul_L): round 6 -- ONE product for both blocks behind block 0's data-gradient chain
-        # (stemgnn_gft_bwd_dt2, K = the two blocks' (b, t) ranges back to back) instead of block 1's product on the side branch +
-        # block 0's accumulating product on the chain: the fork behind block 1's dX product and the join ahead of block 0's
-        # product were ~15 us of cross-queue latency on the critical chain.  The round-4 form stays where the side branch needs
-        # its edge into the chain anyway (the opt-in dW_hh product beside the recurrence zeroes its control words there).
-        legacy_dt1 = overlap and ctx.factored and bool(lib.stemgnn_gru_bwd_overlap_ok(B, N, N, W))
+        # Both blocks' shares of d(mul_L): round 6 -- ONE product behind block 0's data-gradient chain (stemgnn_gft_bwd_dt2, K =
+        # the two blocks' (b, t) ranges back to back) instead of block 1's product on the side branch + block 0's accumulating
+        # product on the chain: the fork behind block 1's dX product and the join ahead of block 0's product were ~15 us of
+        # cross-queue latency on the critical chain.
         dt1 = None
         for s in (1, 0):
             scratch = bufs[s][0]
@@ -906,28 +914,6 @@ class SpectralHotPath(torch.autograd.Function):
             X, sb, sn, stt = xviews[s]
             heads, glu, wgrad, unpack = stage_fns(s)
             heads(st)
-            if dt1 is not None and legacy_dt1:
-                # block 1's share of d(mul_L) is needed by the Chebyshev backward only, 100+ us later -> side stream, beside
-                # block 0's heads / GLU data gradients (forked behind block 1's dX product, queued behind block 0's heads)
-                X1, sb1, sn1, stt1, dG1, dx_done = dt1
-                side.wait_event(dx_done)
-                def dT1(stream, X1=X1, sb1=sb1, sn1=sn1, stt1=stt1, dG1=dG1):
-                    _lib.check(lib.stemgnn_gft_bwd(mul_L.data_ptr(), X1.data_ptr(), sb1, sn1, stt1, dG1.data_ptr(), None,
-                                                   dmul_L.data_ptr(), 0, B, N, W, stream), "gft_bwd dT")
-                with torch.cuda.stream(side):
-                    # control words of the GRU's dW_hh product beside the recurrence: zeroed HERE, ahead of a side -> main edge
-                    # the step has anyway (dt1_done), so that the side launch needs no parent on the main branch (inside a
-                    # captured graph such a parent makes it wait for the whole recurrence: include/stemgnn_hip.h)
-                    nctl = lib.stemgnn_gru_bwd_ctl_words(N)
-                    if state.gru_ctl is None or state.gru_ctl.numel() != nctl or state.gru_ctl.device != dev:
-                        state.gru_ctl = torch.zeros(nctl, device=dev, dtype=torch.int32)
-                    _lib.check(lib.stemgnn_fill_zero(state.gru_ctl.data_ptr(), 4 * nctl, side.cuda_stream), "fill_zero")
-                    state.gru_ctl_zeroed = True
-                    dT1(side.cuda_stream)
-                    dt1_done = torch.cuda.Event()
-                    dt1_done.record(side)
-                if state.side_probe is not None:
-                    state.side_probe.append(dT1)
             glu(st)
             if not overlap:
                 wgrad(st, 100)
@@ -939,22 +925,13 @@ class SpectralHotPath(torch.autograd.Function):
                 # block 1: only its data gradient (-> dbackcast) feeds block 0's backward
                 _lib.check(lib.stemgnn_gft_bwd(mul_L.data_ptr(), X.data_ptr(), sb, sn, stt, dG.data_ptr(),
                                                dbackcast.data_ptr(), None, 0, B, N, W, st), "gft_bwd dX")
-                dx_done = None
-                if legacy_dt1:
-                    dx_done = torch.cuda.Event()
-                    dx_done.record(main)
-                dt1 = (X, sb, sn, stt, dG, dx_done)
+                dt1 = (X, sb, sn, stt, dG)
             else:
                 fork = torch.cuda.Event()                # every data-gradient chain is queued
                 fork.record(main)
-                if legacy_dt1:
-                    main.wait_event(dt1_done)            # block 0's product accumulates onto block 1's
-                    _lib.check(lib.stemgnn_gft_bwd(mul_L.data_ptr(), X.data_ptr(), sb, sn, stt, dG.data_ptr(), None,
-                                                   dmul_L.data_ptr(), 1, B, N, W, st), "gft_bwd")
-                else:
-                    X1, sb1, sn1, stt1, dG1, _ = dt1
-                    _lib.check(lib.stemgnn_gft_bwd_dt2(X.data_ptr(), sb, sn, stt, dG.data_ptr(), X1.data_ptr(), sb1, sn1, stt1,
-                                                       dG1.data_ptr(), dmul_L.data_ptr(), B, N, W, st), "gft_bwd_dt2")
+                X1, sb1, sn1, stt1, dG1 = dt1
+                _lib.check(lib.stemgnn_gft_bwd_dt2(X.data_ptr(), sb, sn, stt, dG.data_ptr(), X1.data_ptr(), sb1, sn1, stt1,
+                                                   dG1.data_ptr(), dmul_L.data_ptr(), B, N, W, st), "gft_bwd_dt2")
                 side.wait_event(fork)
                 with torch.cuda.stream(side):
                     sst = side.cuda_stream
@@ -995,7 +972,8 @@ class SpectralHotPath(torch.autograd.Function):
         # round 6: with the factored form on the side-stream schedule the chunk sum of dquery is not a launch of its own on the
         # chain -- the GRU backward's zero-fill launch carries it (stemgnn_gru_bwd_rank2_dq), the key / query weight gradients
         # on the side branch sum their own copy (same fixed order, same bits)
-        dq_parts = bool(factored and overlap and kq_direct and not legacy_dt1)
+        follower = bool(overlap and ctx.factored and state.gru_ctl_zeroed and lib.stemgnn_gru_bwd_overlap_ok(B, N, N, W))
+        dq_parts = bool(factored and overlap and kq_direct and not follower)      # (the follower's _begin call takes dquery reduced)
         for part in ((3,) if exact is None else (1, 2)):
             _lib.check(lib.stemgnn_attn_laplacian_bwd(
                 dL.data_ptr(), h.data_ptr(), wk.data_ptr(), wq.data_ptr(), alpha, drop_p, int(training),
