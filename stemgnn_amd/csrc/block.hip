@@ -1165,9 +1165,23 @@ extern "C" int stemgnn_igft_heads_bwd(const float* const* params_host, const flo
       a.dpF = dpF; a.dpB = dpB; a.dig = dig;
       a.M = d.M; a.W = W; a.Wm = d.Wm; a.WmP = d.WmP; a.KF = d.KF; a.has_bc = has_bc;
       a.ldi = d.WmP + 1; a.ldw = ((W + 3) & ~3) + 1;
-      static SgDynLds lds_guard;
-      SG_TRY(sg_ensure_dyn_lds((const void*)sg_heads_bwd_kernel, hb, lds_guard));
-      hipLaunchKernelGGL(sg_heads_bwd_kernel, dim3((d.M + HD_RB - 1) / HD_RB), dim3(256), hb, st, a);
+      // the d(pre-activation) phase's column tiles over 16 waves (one tile each), 8 (two) or 4 (four: rounds 3-5): the
+      // kernel is one workgroup per CU and latency-bound, a wave's epilogue loads / stores are what shrinks
+      // (2 launches per step: 53.2 / 44.1 / 40.9 us at 4 / 8 / 16 waves); STEMGNN_HEADS_BWD_WAVES = 4 | 8 | 16
+      static const int waves_env = getenv("STEMGNN_HEADS_BWD_WAVES") ? atoi(getenv("STEMGNN_HEADS_BWD_WAVES")) : 16;
+      if (waves_env == 16 && d.KF > 128) {
+        static SgDynLds lds_guard16;
+        SG_TRY(sg_ensure_dyn_lds((const void*)sg_heads_bwd_kernel<16>, hb, lds_guard16));
+        hipLaunchKernelGGL(sg_heads_bwd_kernel<16>, dim3((d.M + HD_RB - 1) / HD_RB), dim3(1024), hb, st, a);
+      } else if (waves_env == 8 && d.KF > 128) {
+        static SgDynLds lds_guard8;
+        SG_TRY(sg_ensure_dyn_lds((const void*)sg_heads_bwd_kernel<8>, hb, lds_guard8));
+        hipLaunchKernelGGL(sg_heads_bwd_kernel<8>, dim3((d.M + HD_RB - 1) / HD_RB), dim3(512), hb, st, a);
+      } else {
+        static SgDynLds lds_guard;
+        SG_TRY(sg_ensure_dyn_lds((const void*)sg_heads_bwd_kernel<4>, hb, lds_guard));
+        hipLaunchKernelGGL(sg_heads_bwd_kernel<4>, dim3((d.M + HD_RB - 1) / HD_RB), dim3(256), hb, st, a);
+      }
       SG_TRY(hipGetLastError());
       fused_data = true;
     }

@@ -244,8 +244,8 @@ __device__ __forceinline__ void hd_gemm_tiles(const float* __restrict__ Al, int 
                                               hd_f4 (&c)[TJ][2]) {
   const float* a0p = Al + i * lda + kq;
   const float* a1p = a0p + 16 * lda;
-  float b[TJ][8], nb[TJ][8];
   const int nb8 = (K + 31) >> 5;                           // batches of 8 k-steps (the last may be partial: Bf returns 0s)
+  float b[TJ][8], nb[TJ][8];
 #pragma unroll
   for (int t = 0; t < TJ; ++t)
 #pragma unroll
@@ -276,7 +276,12 @@ __device__ __forceinline__ void hd_gemm_tiles(const float* __restrict__ Al, int 
   }
 }
 
-__global__ __launch_bounds__(256) void sg_heads_bwd_kernel(const HeadsBwdArgs g) {
+// NW waves per workgroup: 4, 8 or 16 (four, two, one column tile of the last phase per wave: the loads and stores of its
+// epilogue per wave shrink with it; the extra waves idle through the two narrow phases).  Every tile is computed by the same
+// code in every form: same bits.
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void sg_heads_bwd_kernel(const HeadsBwdArgs g) {
+  constexpr int NT = NW * 64;
   extern __shared__ __attribute__((aligned(16))) float hd_lds[];
   float* dpFs = hd_lds;                                  // [32][ldi]
   float* digs = dpFs + HD_RB * g.ldi;                    // [32][ldi]
@@ -288,7 +293,7 @@ __global__ __launch_bounds__(256) void sg_heads_bwd_kernel(const HeadsBwdArgs g)
   const int Wmp4 = (Wm + 3) & ~3, W4 = (W + 3) & ~3;
 
   // ---- stage dforecast rows and dpB = dbc bc (1 - bc) (also written out); zero the k padding ---------------------------
-  for (int e = tid; e < HD_RB * W4; e += 256) {
+  for (int e = tid; e < HD_RB * W4; e += NT) {
     const int row = e / W4, t = e - row * W4;
     const int m = m0 + row < M ? m0 + row : M - 1;
     const size_t o = (size_t)m * W + (t < W ? t : 0);
@@ -302,7 +307,7 @@ __global__ __launch_bounds__(256) void sg_heads_bwd_kernel(const HeadsBwdArgs g)
     dfos[row * ldw + t] = t < W ? df : 0.f;
     dpBs[row * ldw + t] = t < W ? pb : 0.f;
   }
-  for (int e = tid; e < HD_RB * 4; e += 256) {
+  for (int e = tid; e < HD_RB * 4; e += NT) {
     const int row = e >> 2, k = Wm + (e & 3);
     if (k < ldi) { dpFs[row * ldi + k] = 0.f; digs[row * ldi + k] = 0.f; }
   }
@@ -311,7 +316,7 @@ __global__ __launch_bounds__(256) void sg_heads_bwd_kernel(const HeadsBwdArgs g)
   const int j = lane & 15, kq = lane >> 4;
   const int nct = (Wm + 15) >> 4;
   // ---- dpF = (dfo FR) fs (1 - fs):  B(k, col) = FRw[k][col] ------------------------------------------------------------
-  for (int ct = wave; ct < nct; ct += 4) {
+  for (int ct = wave; ct < nct; ct += NW) {
     hd_f4 c[1][2] = {{{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}};
     const int col = ct * 16 + j, cc = col < Wm ? col : Wm - 1;
     const float* fr = g.FRw + cc;
@@ -340,7 +345,7 @@ __global__ __launch_bounds__(256) void sg_heads_bwd_kernel(const HeadsBwdArgs g)
   }
   __syncthreads();
   // ---- dig = dpF F + dpB BC:  B(k, col) = Fw[k][col] / BCw[k][col] -----------------------------------------------------
-  for (int ct = wave; ct < nct; ct += 4) {
+  for (int ct = wave; ct < nct; ct += NW) {
     hd_f4 c[1][2] = {{{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}};
     const int col = ct * 16 + j, cc = col < Wm ? col : Wm - 1;
     const float* fw = g.Fw + cc;
@@ -363,21 +368,22 @@ __global__ __launch_bounds__(256) void sg_heads_bwd_kernel(const HeadsBwdArgs g)
   __syncthreads();
   // ---- d(last GLU out)[row][kk] = sum_o dig[row][o] Wfold[kk][o]  ->  d(pre-activation), four column tiles per pass ---
   const int nkt = (KF + 15) >> 4;
-  for (int ct0 = wave * 4; ct0 < nkt; ct0 += 16) {
-    hd_f4 c[4][2];
+  constexpr int TJ = 16 / NW;                            // 16 column tiles per pass in every form
+  for (int ct0 = wave * TJ; ct0 < nkt; ct0 += TJ * NW) {
+    hd_f4 c[TJ][2];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) { c[t][0] = (hd_f4){0.f, 0.f, 0.f, 0.f}; c[t][1] = c[t][0]; }
-    const float* wr[4];
+    for (int t = 0; t < TJ; ++t) { c[t][0] = (hd_f4){0.f, 0.f, 0.f, 0.f}; c[t][1] = c[t][0]; }
+    const float* wr[TJ];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
+    for (int t = 0; t < TJ; ++t) {
       const int kk = (ct0 + t) * 16 + j;
       wr[t] = g.wfold + (size_t)(kk < KF ? kk : KF - 1) * WmP;
     }
-    hd_gemm_tiles<4>(digs, ldi, Wmp4, [&](int k, int t) { return wr[t][k < Wm ? k : Wm - 1]; }, kq, j, c);
+    hd_gemm_tiles<TJ>(digs, ldi, Wmp4, [&](int k, int t) { return wr[t][k < Wm ? k : Wm - 1]; }, kq, j, c);
     // GLU backward of the last layer.  All out / gate values of the pass are requested up front from clamped (always
     // valid) indices -- a branch around a load makes hipcc wait for every element in turn -- only the stores are guarded.
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
+    for (int t = 0; t < TJ; ++t) {
       const int kk = (ct0 + t) * 16 + j;
       const int kc = kk < KF ? kk : KF - 1;
       const int r = kc >= g.cp2[0];
