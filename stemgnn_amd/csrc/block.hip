@@ -1091,9 +1091,17 @@ extern "C" int stemgnn_igft_heads_fwd(const float* const* params_host, const flo
     a.ig = saved + S.ig; a.fs = saved + S.fs; a.forecast = forecast; a.backcast = backcast;
     a.M = d.M; a.W = W; a.Wm = d.Wm; a.WmP = d.WmP; a.KF = d.KF; a.accumulate = accumulate; a.has_bc = has_bc;
     a.lda = hd_lda(d.KF); a.ldi = d.WmP + 1;
-    static SgDynLds lds_guard;
-    SG_TRY(sg_ensure_dyn_lds((const void*)sg_heads_fwd_kernel, hd_bytes, lds_guard));
-    hipLaunchKernelGGL(sg_heads_fwd_kernel, dim3((d.M + HD_RB - 1) / HD_RB), dim3(256), hd_bytes, st, a);
+    // eight waves, one 16-row tile each (heads.h); STEMGNN_HEADS_FWD_WAVES=4: both row tiles per wave (rounds 3-5)
+    static const int waves_env = getenv("STEMGNN_HEADS_FWD_WAVES") ? atoi(getenv("STEMGNN_HEADS_FWD_WAVES")) : 8;
+    if (waves_env == 8) {
+      static SgDynLds lds_guard8;
+      SG_TRY(sg_ensure_dyn_lds((const void*)sg_heads_fwd_kernel<8>, hd_bytes, lds_guard8));
+      hipLaunchKernelGGL(sg_heads_fwd_kernel<8>, dim3((d.M + HD_RB - 1) / HD_RB), dim3(512), hd_bytes, st, a);
+    } else {
+      static SgDynLds lds_guard;
+      SG_TRY(sg_ensure_dyn_lds((const void*)sg_heads_fwd_kernel<4>, hd_bytes, lds_guard));
+      hipLaunchKernelGGL(sg_heads_fwd_kernel<4>, dim3((d.M + HD_RB - 1) / HD_RB), dim3(256), hd_bytes, st, a);
+    }
     SG_TRY(hipGetLastError());
     return 0;
   }

@@ -77,9 +77,45 @@ __device__ __forceinline__ void hd_gemm_tile(const float* __restrict__ Al, int l
     }
 }
 
+// one 16-row tile of the same product (the eight-wave forward: a wave owns one row tile of a column tile); the k order and the
+// accumulator of an output element are those of hd_gemm_tile: same bits
+template <class BF>
+__device__ __forceinline__ void hd_gemm_tile1(const float* __restrict__ Al, int lda, int K, BF Bf, int j, int kq, int i,
+                                              hd_f4& c0) {
+  const float* a0p = Al + i * lda + kq;
+  float b[8], nb[8];
+  const int nfull = K >> 5;
+  if (nfull > 0) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) b[u] = Bf(4 * u + kq, j);
+  }
+  for (int t = 0; t < nfull; ++t) {
+    const int k0 = t << 5;
+    if (t + 1 < nfull) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) nb[u] = Bf(k0 + 32 + 4 * u + kq, j);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0p[k0 + 4 * u], b[u], c0, 0, 0, 0);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) b[u] = nb[u];
+  }
+  const int ktail = nfull << 5, nrem = (K - ktail) >> 2;
+#pragma unroll
+  for (int u = 0; u < 8; ++u) b[u] = u < nrem ? Bf(ktail + 4 * u + kq, j) : 0.f;
+#pragma unroll
+  for (int u = 0; u < 8; ++u)
+    if (u < nrem) c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0p[ktail + 4 * u], b[u], c0, 0, 0, 0);
+}
+
 __device__ __forceinline__ float hd_sigmoid(float v) { return __frcp_rn(1.f + __expf(-v)); }
 
-__global__ __launch_bounds__(256) void sg_heads_fwd_kernel(const HeadsFwdArgs g) {
+// NW = 4: a wave owns both 16-row tiles of its column tiles (rounds 3-5).  NW = 8: one row tile each -- half the MFMA chain
+// and half the epilogue stores per wave in every phase of this one-workgroup-per-CU, latency-bound kernel.
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void sg_heads_fwd_kernel(const HeadsFwdArgs g) {
+  constexpr int NT = NW * 64;
+  constexpr bool SPLIT = NW == 8;
   extern __shared__ __attribute__((aligned(16))) float hd_lds[];
   float* As = hd_lds;                                  // [32][lda]   [Re3 | Im3] rows (k >= KF up to the pad: zero)
   float* igs = As + HD_RB * g.lda;                     // [32][ldi]
@@ -96,11 +132,11 @@ __global__ __launch_bounds__(256) void sg_heads_fwd_kernel(const HeadsFwdArgs g)
     const int cpr = KFp >> 2;                              // chunks per row
     const int nch = HD_RB * cpr;
     const int c0n = g.cp2[0] >> 2;
-    for (int base = 0; base < nch; base += 256 * 8) {
+    for (int base = 0; base < nch; base += NT * 8) {
       float4 v[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
-        const int e = base + u * 256 + tid;
+        const int e = base + u * NT + tid;
         const int ee = e < nch ? e : nch - 1;
         const int row = ee / cpr, c = ee - row * cpr;
         const int m = m0 + row < M ? m0 + row : M - 1;
@@ -111,7 +147,7 @@ __global__ __launch_bounds__(256) void sg_heads_fwd_kernel(const HeadsFwdArgs g)
       }
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
-        const int e = base + u * 256 + tid;
+        const int e = base + u * NT + tid;
         if (e < nch) {
           const int row = e / cpr, c = e - row * cpr;
           float* d = As + row * lda + 4 * c;               // lda is even: 8-byte aligned
@@ -123,14 +159,14 @@ __global__ __launch_bounds__(256) void sg_heads_fwd_kernel(const HeadsFwdArgs g)
     }
   }
   const int xs = W4 + 1;
-  for (int e = tid; e < HD_RB * W4; e += 256) {
+  for (int e = tid; e < HD_RB * W4; e += NT) {
     const int row = e / W4, t = e - row * W4;
     const int m = m0 + row < M ? m0 + row : M - 1;
     const int b = m / g.X.N;
     Xs[row * xs + t] = (t < W && g.has_bc) ? g.X.p[b * g.X.sb + (m - b * g.X.N) * g.X.sn + (t < W ? t : 0) * g.X.st] : 0.f;
   }
   // zero the padding columns of ig / fs rows that later K loops read (k in [Wm, Wmp4))
-  for (int e = tid; e < HD_RB * 4; e += 256) {
+  for (int e = tid; e < HD_RB * 4; e += NT) {
     const int row = e >> 2, k = Wm + (e & 3);
     if (k < ldi) { igs[row * ldi + k] = 0.f; fss[row * ldi + k] = 0.f; }
   }
@@ -138,76 +174,101 @@ __global__ __launch_bounds__(256) void sg_heads_fwd_kernel(const HeadsFwdArgs g)
 
   const int j = lane & 15, kq = lane >> 4;             // fragment column / k within the k-step; D rows = 4 kq + reg
   const int nct = (Wm + 15) >> 4;
+  const int cw = SPLIT ? (wave & 3) : wave;            // column-tile lane of the wave / its row tile (SPLIT)
+  const int rh = SPLIT ? (wave >> 2) : 0;
   // ---- ig = [Re3 | Im3] Wfold ------------------------------------------------------------------------------------------
-  for (int ct = wave; ct < nct; ct += 4) {
+  for (int ct = cw; ct < nct; ct += 4) {
     hd_f4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0;
     const float* wf = g.wfold + ct * 16;
     const int WmP = g.WmP;
-    hd_gemm_tile(As, lda, KFp, [&](int k, int jj) { return wf[(size_t)(k < KF ? k : KF - 1) * WmP + jj]; }, j, kq, j, c0, c1);
+    auto Bf = [&](int k, int jj) { return wf[(size_t)(k < KF ? k : KF - 1) * WmP + jj]; };
+    if constexpr (SPLIT) hd_gemm_tile1(As + rh * 16 * lda, lda, KFp, Bf, j, kq, j, c0);
+    else hd_gemm_tile(As, lda, KFp, Bf, j, kq, j, c0, c1);
     const int col = ct * 16 + j;
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
-      const int r0 = kq * 4 + reg, r1 = 16 + r0;
+      const int r0 = rh * 16 + kq * 4 + reg, r1 = 16 + r0;
       if (col < Wm) {
         igs[r0 * ldi + col] = c0[reg];
-        igs[r1 * ldi + col] = c1[reg];
         if (m0 + r0 < M) g.ig[(size_t)(m0 + r0) * Wm + col] = c0[reg];
-        if (m0 + r1 < M) g.ig[(size_t)(m0 + r1) * Wm + col] = c1[reg];
+        if constexpr (!SPLIT) {
+          igs[r1 * ldi + col] = c1[reg];
+          if (m0 + r1 < M) g.ig[(size_t)(m0 + r1) * Wm + col] = c1[reg];
+        }
       }
     }
   }
   __syncthreads();
   // ---- fs = sigmoid(ig F^T + Fb) -------------------------------------------------------------------------------------
-  for (int ct = wave; ct < nct; ct += 4) {
+  for (int ct = cw; ct < nct; ct += 4) {
     hd_f4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0;
     const int col = ct * 16 + j;
     const float* fr = g.Fw + (size_t)(col < Wm ? col : Wm - 1) * Wm;
-    hd_gemm_tile(igs, ldi, Wmp4, [&](int k, int) { return fr[k < Wm ? k : Wm - 1]; }, j, kq, j, c0, c1);
+    auto Bf = [&](int k, int) { return fr[k < Wm ? k : Wm - 1]; };
+    if constexpr (SPLIT) hd_gemm_tile1(igs + rh * 16 * ldi, ldi, Wmp4, Bf, j, kq, j, c0);
+    else hd_gemm_tile(igs, ldi, Wmp4, Bf, j, kq, j, c0, c1);
     const float bias = g.Fb[col < Wm ? col : Wm - 1];
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
-      const int r0 = kq * 4 + reg, r1 = 16 + r0;
+      const int r0 = rh * 16 + kq * 4 + reg, r1 = 16 + r0;
       if (col < Wm) {
-        const float s0 = hd_sigmoid(c0[reg] + bias), s1 = hd_sigmoid(c1[reg] + bias);
+        const float s0 = hd_sigmoid(c0[reg] + bias);
         fss[r0 * ldi + col] = s0;
-        fss[r1 * ldi + col] = s1;
         if (m0 + r0 < M) g.fs[(size_t)(m0 + r0) * Wm + col] = s0;
-        if (m0 + r1 < M) g.fs[(size_t)(m0 + r1) * Wm + col] = s1;
+        if constexpr (!SPLIT) {
+          const float s1 = hd_sigmoid(c1[reg] + bias);
+          fss[r1 * ldi + col] = s1;
+          if (m0 + r1 < M) g.fs[(size_t)(m0 + r1) * Wm + col] = s1;
+        }
       }
     }
   }
   __syncthreads();
   // ---- forecast (column tiles over W) on the even waves, backcast on the odd ones ---------------------------------------
   const int nwt = (W + 15) >> 4;
-  for (int ct = wave >> 1; ct < nwt; ct += 2) {
+  const int rh3 = SPLIT ? ((wave >> 1) & 1) : 0;         // SPLIT: wave = 4 * (column tile parity) + 2 * (row tile) + (backcast)
+  for (int ct = SPLIT ? (wave >> 2) : (wave >> 1); ct < nwt; ct += 2) {
     const int col = ct * 16 + j;
     const int cc = col < W ? col : W - 1;
     hd_f4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0;
     if ((wave & 1) == 0) {
       const float* fr = g.FRw + (size_t)cc * Wm;
-      hd_gemm_tile(fss, ldi, Wmp4, [&](int k, int) { return fr[k < Wm ? k : Wm - 1]; }, j, kq, j, c0, c1);
+      auto Bf = [&](int k, int) { return fr[k < Wm ? k : Wm - 1]; };
+      if constexpr (SPLIT) hd_gemm_tile1(fss + rh3 * 16 * ldi, ldi, Wmp4, Bf, j, kq, j, c0);
+      else hd_gemm_tile(fss, ldi, Wmp4, Bf, j, kq, j, c0, c1);
       const float bias = g.FRb[cc];
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg) {
-        const int r0 = kq * 4 + reg, r1 = 16 + r0;
+        const int r0 = rh3 * 16 + kq * 4 + reg, r1 = 16 + r0;
         if (col < W) {
           if (m0 + r0 < M) { float* o = g.forecast + (size_t)(m0 + r0) * W + col; *o = (g.accumulate ? *o : 0.f) + c0[reg] + bias; }
-          if (m0 + r1 < M) { float* o = g.forecast + (size_t)(m0 + r1) * W + col; *o = (g.accumulate ? *o : 0.f) + c1[reg] + bias; }
+          if constexpr (!SPLIT) {
+            if (m0 + r1 < M) { float* o = g.forecast + (size_t)(m0 + r1) * W + col; *o = (g.accumulate ? *o : 0.f) + c1[reg] + bias; }
+          }
         }
       }
     } else if (g.has_bc) {
       const float* bcr = g.BCw + (size_t)cc * Wm;
-      hd_gemm_tile(igs, ldi, Wmp4, [&](int k, int) { return bcr[k < Wm ? k : Wm - 1]; }, j, kq, j, c0, c1);
+      auto Bc = [&](int k, int) { return bcr[k < Wm ? k : Wm - 1]; };
       hd_f4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = d0;
       const float* bsr = g.BSw + (size_t)cc * W;
-      hd_gemm_tile(Xs, xs, W4, [&](int k, int) { return bsr[k < W ? k : W - 1]; }, j, kq, j, d0, d1);
+      auto Bs = [&](int k, int) { return bsr[k < W ? k : W - 1]; };
+      if constexpr (SPLIT) {
+        hd_gemm_tile1(igs + rh3 * 16 * ldi, ldi, Wmp4, Bc, j, kq, j, c0);
+        hd_gemm_tile1(Xs + rh3 * 16 * xs, xs, W4, Bs, j, kq, j, d0);
+      } else {
+        hd_gemm_tile(igs, ldi, Wmp4, Bc, j, kq, j, c0, c1);
+        hd_gemm_tile(Xs, xs, W4, Bs, j, kq, j, d0, d1);
+      }
       const float bias = g.BCb[cc] - g.BSb[cc];
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg) {
-        const int r0 = kq * 4 + reg, r1 = 16 + r0;
+        const int r0 = rh3 * 16 + kq * 4 + reg, r1 = 16 + r0;
         if (col < W) {
           if (m0 + r0 < M) g.backcast[(size_t)(m0 + r0) * W + col] = hd_sigmoid(c0[reg] - d0[reg] + bias);
-          if (m0 + r1 < M) g.backcast[(size_t)(m0 + r1) * W + col] = hd_sigmoid(c1[reg] - d1[reg] + bias);
+          if constexpr (!SPLIT) {
+            if (m0 + r1 < M) g.backcast[(size_t)(m0 + r1) * W + col] = hd_sigmoid(c1[reg] - d1[reg] + bias);
+          }
         }
       }
     }
