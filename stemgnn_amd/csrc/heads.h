@@ -353,6 +353,37 @@ __global__ __launch_bounds__(NW * 64) void sg_heads_bwd_kernel(const HeadsBwdArg
   const int M = g.M, W = g.W, Wm = g.Wm, KF = g.KF, ldi = g.ldi, ldw = g.ldw, WmP = g.WmP;
   const int Wmp4 = (Wm + 3) & ~3, W4 = (W + 3) & ~3;
 
+  const int j = lane & 15, kq = lane >> 4;
+  // The saved out / gate values of the last GLU layer that the closing phase multiplies with (14 MB per launch from HBM, no
+  // dependence on anything computed here) are requested FIRST when that phase is a single pass (every wave's column tiles
+  // are known now): their latency runs under the three phases before it.  Clamped (always valid) indices, no branches
+  // around the loads.
+  const int nkt = (KF + 15) >> 4;
+  constexpr int TJ = 16 / NW;                            // 16 column tiles per pass in every form
+  const bool hoist = nkt <= 16;
+  float gt[TJ][2][4], yv[TJ][2][4];
+  auto load_saved = [&](int ct0) {
+#pragma unroll
+    for (int t = 0; t < TJ; ++t) {
+      const int kk = (ct0 + t) * 16 + j;
+      const int kc = kk < KF ? kk : KF - 1;
+      const int r = kc >= g.cp2[0];
+      const int cch = kc - (r ? g.cp2[0] : 0), cp = g.cp2[r];
+      const float* pg = g.gate2[r] + cch;
+      const float* py = g.out2[r] + cch;
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int mm = m0 + h * 16 + kq * 4 + reg;
+          const size_t o = (size_t)(mm < M ? mm : M - 1) * cp;
+          gt[t][h][reg] = pg[o];
+          yv[t][h][reg] = py[o];
+        }
+    }
+  };
+  if (hoist) load_saved(wave * TJ);
+
   // ---- stage dforecast rows and dpB = dbc bc (1 - bc) (also written out); zero the k padding ---------------------------
   for (int e = tid; e < HD_RB * W4; e += NT) {
     const int row = e / W4, t = e - row * W4;
@@ -374,7 +405,6 @@ __global__ __launch_bounds__(NW * 64) void sg_heads_bwd_kernel(const HeadsBwdArg
   }
   __syncthreads();
 
-  const int j = lane & 15, kq = lane >> 4;
   const int nct = (Wm + 15) >> 4;
   // ---- dpF = (dfo FR) fs (1 - fs):  B(k, col) = FRw[k][col] ------------------------------------------------------------
   for (int ct = wave; ct < nct; ct += NW) {
@@ -428,8 +458,6 @@ __global__ __launch_bounds__(NW * 64) void sg_heads_bwd_kernel(const HeadsBwdArg
   }
   __syncthreads();
   // ---- d(last GLU out)[row][kk] = sum_o dig[row][o] Wfold[kk][o]  ->  d(pre-activation), four column tiles per pass ---
-  const int nkt = (KF + 15) >> 4;
-  constexpr int TJ = 16 / NW;                            // 16 column tiles per pass in every form
   for (int ct0 = wave * TJ; ct0 < nkt; ct0 += TJ * NW) {
     hd_f4 c[TJ][2];
 #pragma unroll
@@ -441,8 +469,9 @@ __global__ __launch_bounds__(NW * 64) void sg_heads_bwd_kernel(const HeadsBwdArg
       wr[t] = g.wfold + (size_t)(kk < KF ? kk : KF - 1) * WmP;
     }
     hd_gemm_tiles<TJ>(digs, ldi, Wmp4, [&](int k, int t) { return wr[t][k < Wm ? k : Wm - 1]; }, kq, j, c);
-    // GLU backward of the last layer.  All out / gate values of the pass are requested up front from clamped (always
-    // valid) indices -- a branch around a load makes hipcc wait for every element in turn -- only the stores are guarded.
+    // GLU backward of the last layer (several passes: the pass's out / gate values are requested here, all up front -- only
+    // the stores are guarded)
+    if (!hoist) load_saved(ct0);
 #pragma unroll
     for (int t = 0; t < TJ; ++t) {
       const int kk = (ct0 + t) * 16 + j;
@@ -450,18 +479,6 @@ __global__ __launch_bounds__(NW * 64) void sg_heads_bwd_kernel(const HeadsBwdArg
       const int r = kc >= g.cp2[0];
       const int cch = kc - (r ? g.cp2[0] : 0), cp = g.cp2[r];
       const int q = ((cch >> 4) << 5) + (cch & 15);
-      const float* pg = g.gate2[r] + cch;
-      const float* py = g.out2[r] + cch;
-      float gt[2][4], yv[2][4];
-#pragma unroll
-      for (int reg = 0; reg < 4; ++reg)
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const int mm = m0 + h * 16 + kq * 4 + reg;
-          const size_t o = (size_t)(mm < M ? mm : M - 1) * cp;
-          gt[h][reg] = pg[o];
-          yv[h][reg] = py[o];
-        }
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg)
 #pragma unroll
@@ -470,8 +487,8 @@ __global__ __launch_bounds__(NW * 64) void sg_heads_bwd_kernel(const HeadsBwdArg
           const float v = c[t][h][reg];
           if (m < M && kk < KF) {
             float* dp = g.dpre2[r] + (size_t)m * 2 * cp + q;
-            dp[0] = v * gt[h][reg];
-            dp[16] = v * yv[h][reg] * (1.f - gt[h][reg]);
+            dp[0] = v * gt[t][h][reg];
+            dp[16] = v * yv[t][h][reg] * (1.f - gt[t][h][reg]);
           }
         }
     }

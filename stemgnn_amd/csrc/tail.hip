@@ -196,6 +196,11 @@ extern "C" int stemgnn_fc_tail_bwd(const float* dforecast, const float* fsum, co
 }
 
 // ---- training tail in two launches (round 3) ------------------------------------------------------------------------
+// Round 6: 32-row blocks, eight threads per row (228 workgroups at PEMS07 instead of 114 on the 256 CUs; every per-thread loop of
+// this latency-bound kernel -- its launch sits on the step's critical chain -- is half as long; twice the partial blocks go to
+// the second launch, which is off the chain).
+constexpr int TRAIN_RB = 32;
+constexpr int TRAIN_RQ = 256 / TRAIN_RB;
 // fc forward -> MSE(reduction = 'mean') -> d(loss)/d(forecast) -> fc backward, per 64-row block, in ONE kernel: the loss
 // gradient 2 (f - y) / n needs no global quantity, so nothing forces the five launches of the separate stages
 // (fc fwd, MSE, MSE bwd, fc bwd, reduce: 40 us at PEMS07).  Second launch: fixed-order sum of the per-block weight-gradient
@@ -213,22 +218,22 @@ __global__ __launch_bounds__(256) void sg_fc_tail_train_kernel(const float* __re
   float* sw2 = sb0 + W;
   float* sb2 = sw2 + H * W;
   float* sx = sb2 + H;                     // [RB][W+1]
-  float* sdz = sx + TAIL_RB * (W + 1);     // [RB][W+1]   z, then dz
-  float* sa = sdz + TAIL_RB * (W + 1);     // [RB][W+1]
-  float* sdy = sa + TAIL_RB * (W + 1);     // [RB][H+1]
-  float* sred = sdy + TAIL_RB * (H + 1);   // [256]
-  const int tid = threadIdx.x, r = tid & 63, q = tid >> 6;
-  const int M = B * N, m0 = blockIdx.x * TAIL_RB, m = m0 + r;
+  float* sdz = sx + TRAIN_RB * (W + 1);     // [RB][W+1]   z, then dz
+  float* sa = sdz + TRAIN_RB * (W + 1);     // [RB][W+1]
+  float* sdy = sa + TRAIN_RB * (W + 1);     // [RB][H+1]
+  float* sred = sdy + TRAIN_RB * (H + 1);   // [256]
+  const int tid = threadIdx.x, r = tid % TRAIN_RB, q = tid / TRAIN_RB;
+  const int M = B * N, m0 = blockIdx.x * TRAIN_RB, m = m0 + r;
   for (int i = tid; i < W * W; i += 256) sw0[i] = w0[i];
   for (int i = tid; i < W; i += 256) sb0[i] = b0[i];
   for (int i = tid; i < H * W; i += 256) sw2[i] = w2[i];
   for (int i = tid; i < H; i += 256) sb2[i] = b2[i];
-  for (int i = tid; i < TAIL_RB * W; i += 256) {
+  for (int i = tid; i < TRAIN_RB * W; i += 256) {
     const int rr = i / W, t = i - rr * W;
     sx[rr * (W + 1) + t] = m0 + rr < M ? fsum[(size_t)m0 * W + i] : 0.f;
   }
   __syncthreads();
-  for (int t = q; t < W; t += 4) {
+  for (int t = q; t < W; t += TRAIN_RQ) {
     float z = sb0[t];
     for (int u = 0; u < W; ++u) z = fmaf(sx[r * (W + 1) + u], sw0[t * W + u], z);
     sdz[r * (W + 1) + t] = z;
@@ -239,7 +244,7 @@ __global__ __launch_bounds__(256) void sg_fc_tail_train_kernel(const float* __re
   {
     const int mc = m < M ? m : 0, b = mc / N, n = mc - b * N;
     const float scale = 2.f / ((float)B * (float)H * (float)N);
-    for (int h = q; h < H; h += 4) {
+    for (int h = q; h < H; h += TRAIN_RQ) {
       float y = sb2[h];
       for (int t = 0; t < W; ++t) y = fmaf(sa[r * (W + 1) + t], sw2[h * W + t], y);
       const size_t o = ((size_t)b * H + h) * N + n;
@@ -251,7 +256,7 @@ __global__ __launch_bounds__(256) void sg_fc_tail_train_kernel(const float* __re
   }
   sred[tid] = sq;
   __syncthreads();
-  for (int t = q; t < W; t += 4) {
+  for (int t = q; t < W; t += TRAIN_RQ) {
     const float z = sdz[r * (W + 1) + t];
     float da = 0.f;
     for (int h = 0; h < H; ++h) da = fmaf(sdy[r * (H + 1) + h], sw2[h * W + t], da);
@@ -259,7 +264,7 @@ __global__ __launch_bounds__(256) void sg_fc_tail_train_kernel(const float* __re
   }
   __syncthreads();
   if (m < M)
-    for (int u = q; u < W; u += 4) {
+    for (int u = q; u < W; u += TRAIN_RQ) {
       float d = 0.f;
       for (int t = 0; t < W; ++t) d = fmaf(sdz[r * (W + 1) + t], sw0[t * W + u], d);
       dfsum[(size_t)m * W + u] = d;
@@ -268,16 +273,16 @@ __global__ __launch_bounds__(256) void sg_fc_tail_train_kernel(const float* __re
     float sum = 0.f;
     if (e < W * W) {
       const int t = e / W, u = e - t * W;
-      for (int rr = 0; rr < TAIL_RB; ++rr) sum = fmaf(sdz[rr * (W + 1) + t], sx[rr * (W + 1) + u], sum);
+      for (int rr = 0; rr < TRAIN_RB; ++rr) sum = fmaf(sdz[rr * (W + 1) + t], sx[rr * (W + 1) + u], sum);
     } else if (e < W * W + W) {
       const int t = e - W * W;
-      for (int rr = 0; rr < TAIL_RB; ++rr) sum += sdz[rr * (W + 1) + t];
+      for (int rr = 0; rr < TRAIN_RB; ++rr) sum += sdz[rr * (W + 1) + t];
     } else if (e < W * W + W + H * W) {
       const int qq = e - W * W - W, h = qq / W, t = qq - h * W;
-      for (int rr = 0; rr < TAIL_RB; ++rr) sum = fmaf(sdy[rr * (H + 1) + h], sa[rr * (W + 1) + t], sum);
+      for (int rr = 0; rr < TRAIN_RB; ++rr) sum = fmaf(sdy[rr * (H + 1) + h], sa[rr * (W + 1) + t], sum);
     } else if (e < nacc) {
       const int h = e - W * W - W - H * W;
-      for (int rr = 0; rr < TAIL_RB; ++rr) sum += sdy[rr * (H + 1) + h];
+      for (int rr = 0; rr < TRAIN_RB; ++rr) sum += sdy[rr * (H + 1) + h];
     } else {
       for (int i = 0; i < 256; ++i) sum += sred[i];                      // fixed order
     }
@@ -295,7 +300,17 @@ __global__ __launch_bounds__(256) void sg_fc_tail_train_reduce_kernel(const floa
   const int i = blockIdx.x * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
   float s = 0.f;
   if (i <= nacc)
-    for (int b = q; b < nblocks; b += 4) s += partial[(size_t)b * (nacc + 1) + i];
+    for (int b = q; b < nblocks; b += 32) {                // eight loads in flight, added in block order (same bits as one by one)
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int bb = b + 4 * u;
+        const float x = partial[(size_t)(bb < nblocks ? bb : nblocks - 1) * (nacc + 1) + i];
+        v[u] = bb < nblocks ? x : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
   red[q][threadIdx.x & 63] = s;
   __syncthreads();
   if (q != 0 || i > nacc) return;
@@ -312,10 +327,10 @@ __global__ __launch_bounds__(256) void sg_fc_tail_train_reduce_kernel(const floa
 }
 
 static size_t fc_tail_train_lds(int W, int H) {
-  return (size_t)(W * W + W + H * W + H + TAIL_RB * (3 * (W + 1) + H + 1) + 256) * sizeof(float);
+  return (size_t)(W * W + W + H * W + H + TRAIN_RB * (3 * (W + 1) + H + 1) + 256) * sizeof(float);
 }
 extern "C" size_t stemgnn_fc_tail_train_scratch_floats(int B, int N, int W, int H) {
-  return (size_t)((B * N + TAIL_RB - 1) / TAIL_RB) * (W * W + W + H * W + H + 1);
+  return (size_t)((B * N + TRAIN_RB - 1) / TRAIN_RB) * (W * W + W + H * W + H + 1);
 }
 static int fc_tail_train_impl(const float* fsum, const float* target, const float* w0, const float* b0, const float* w2,
                               const float* b2, int B, int N, int W, int H, float* scratch, float* forecast, float* loss,
@@ -326,7 +341,7 @@ static int fc_tail_train_impl(const float* fsum, const float* target, const floa
   if ((parts & 2) && (!loss || !dw0 || !db0 || !dw2 || !db2)) return SG_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   const int nacc = W * W + W + H * W + H;
-  const int nblocks = (B * N + TAIL_RB - 1) / TAIL_RB;
+  const int nblocks = (B * N + TRAIN_RB - 1) / TRAIN_RB;
   if (parts & 1) {
     const size_t lds = fc_tail_train_lds(W, H);
     static SgDynLds lds_guard;
