@@ -383,6 +383,22 @@ __global__ __launch_bounds__(NW * 64) void sg_heads_bwd_kernel(const HeadsBwdArg
     }
   };
   if (hoist) load_saved(wave * TJ);
+  // likewise the saved fs values of the first phase's column tile (one pass: Wm <= 16 NW)
+  const int nct = (Wm + 15) >> 4;
+  const bool hoist_fs = nct <= NW;
+  float sv[2][4];
+  auto load_fs = [&](int ct) {
+    const int col = ct * 16 + j, cc = col < Wm ? col : Wm - 1;
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int r = h * 16 + kq * 4 + reg;
+        const int m = m0 + r < M ? m0 + r : M - 1;
+        sv[h][reg] = g.fs[(size_t)m * Wm + cc];
+      }
+  };
+  if (hoist_fs) load_fs(wave < nct ? wave : nct - 1);
 
   // ---- stage dforecast rows and dpB = dbc bc (1 - bc) (also written out); zero the k padding ---------------------------
   for (int e = tid; e < HD_RB * W4; e += NT) {
@@ -405,22 +421,13 @@ __global__ __launch_bounds__(NW * 64) void sg_heads_bwd_kernel(const HeadsBwdArg
   }
   __syncthreads();
 
-  const int nct = (Wm + 15) >> 4;
   // ---- dpF = (dfo FR) fs (1 - fs):  B(k, col) = FRw[k][col] ------------------------------------------------------------
   for (int ct = wave; ct < nct; ct += NW) {
     hd_f4 c[1][2] = {{{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}};
     const int col = ct * 16 + j, cc = col < Wm ? col : Wm - 1;
     const float* fr = g.FRw + cc;
     hd_gemm_tiles<1>(dfos, ldw, W4, [&](int k, int) { return fr[(size_t)(k < W ? k : W - 1) * Wm]; }, kq, j, c);
-    float sv[2][4];                                        // saved fs values: unconditional loads from clamped indices
-#pragma unroll
-    for (int reg = 0; reg < 4; ++reg)
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int r = h * 16 + kq * 4 + reg;
-        const int m = m0 + r < M ? m0 + r : M - 1;
-        sv[h][reg] = g.fs[(size_t)m * Wm + cc];
-      }
+    if (!hoist_fs) load_fs(ct);                            // saved fs values: unconditional loads from clamped indices
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg)
 #pragma unroll
