@@ -771,8 +771,19 @@ __global__ void gru_reduce_grad_kernel(const GruReduceJobs J) {
   const size_t slab = (size_t)rows * (cols + 1);
   if (idx >= slab) return;
   const float* part = J.part[job];
+  // eight loads in flight, added in slab order (a `s += load` loop of run-time length is one dependent round trip per slab)
   float s = 0.f;
-  for (int z = 0; z < nsplit; ++z) s += part[(size_t)z * slab + idx];
+  for (int z = 0; z < nsplit; z += 8) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int zz = z + u;
+      const float x = part[(size_t)(zz < nsplit ? zz : 0) * slab + idx];
+      v[u] = zz < nsplit ? x : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += v[u];
+  }
   const int j = (int)(idx / (cols + 1)), k = (int)(idx - (size_t)j * (cols + 1));
   if (k < cols) J.out_w[job][(size_t)j * cols + k] = s;
   else J.out_b[job][j] = s;

@@ -18,8 +18,20 @@ static __global__ void sg_reduce_splits_kernel(float* __restrict__ part, SgSlabR
   while (g + 1 < R.n && idx >= R.prefix[g + 1]) ++g;
   const size_t e = idx - R.prefix[g];
   float* base = part + R.off[g] + e;
+  // eight loads in flight, added in split order: a `s += load` loop of run-time length is one L2 / HBM round trip per split
+  const size_t slab = R.slab[g];
   float s = base[0];
-  for (int k = 1; k < nsplit; ++k) s += base[(size_t)k * R.slab[g]];
+  for (int k = 1; k < nsplit; k += 8) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int kk = k + u;
+      const float x = base[(size_t)(kk < nsplit ? kk : 0) * slab];
+      v[u] = kk < nsplit ? x : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += v[u];
+  }
   base[0] = s;
 }
 
