@@ -256,7 +256,7 @@ def rocprof_static_us():
             continue
         kernel = " ".join(parts[6:])
         for key in ("gru_fwd_cluster4_kernel", "gru_bwd_cluster4_kernel", "sg_glu_fused_fwd", "sg_glu_fused_dgrad",
-                    "sg_wgrad_kernel<16, 6, false, true>", "sg_wgrad_kernel<16, 6, false, false>", "GruGiOp"):
+                    "sg_wgrad_kernel<16, 6, false, true>", "sg_wgrad_kernel<16, 6, false, false>", "GruGiOp", "gru_gi_stream_kernel"):
             if key in kernel and key not in out:
                 out[key] = float(parts[2])
     return out
@@ -297,7 +297,7 @@ def roofline_objects(cfg):
     gru = time_gru(cfg)
     fl = step_flops(cfg)
     for name, us, launches, kernel in (
-            ("gru_fwd", gru["fwd_us"], 2, "sg_gemm<GruGiOp> (input projection) + gru_fwd_cluster4_kernel / gru_fwd_wide_kernel "
+            ("gru_fwd", gru["fwd_us"], 2, "gru_gi_stream_kernel / sg_gemm<GruGiOp> (input projection) + gru_fwd_cluster4_kernel / gru_fwd_wide_kernel "
                                           "(persistent recurrence, W_hh resident in registers, one exchange per step)"),
             ("gru_bwd", gru["bwd_incl_weight_grads_us"], 3, "zero-fill kernel + gru_bwd_cluster4_kernel / gru_bwd_wide_kernel "
                                                             "(persistent recurrence) + sg_wgrad_kernel (dW_hh, dW_ih sum)")):

@@ -70,6 +70,73 @@ struct GruGiOp {
   __device__ void epi(int, int i, int j, float v) const { gi[(size_t)i * 3 * Hd + j] = v + b_ih[j]; }
 };
 
+// The same projection as a streaming kernel (round 6): with K = W = 12 the product is 20 MB of stores and 60 MFLOP at PEMS07 --
+// an output-bound outer-product-like op, not a GEMM.  A thread owns FOUR consecutive output columns (its 4 x W weights and
+// bias stay in registers), a workgroup 16 consecutive (s, b) rows whose W input values sit in LDS (broadcast reads); every
+// output leaves as one 16-byte store, a wave writes 1 KB contiguous.  The MFMA tile kernel above wrote the same 20 MB as
+// single dwords in 64-byte runs: 17.9 us against ~5 for the bytes.  (Round 3's streaming attempt kept the weights in LDS
+// and stored dwords: 25 us.)  Same zeroing chores as GruGiOp::setup.  Accumulation: k ascending with fma, bias last.
+constexpr int GI_RB = 16, GI_NT = 192;
+template <int W>
+__global__ __launch_bounds__(GI_NT) void gru_gi_stream_kernel(const float* __restrict__ x, const float* __restrict__ w_ih,
+                                                              const float* __restrict__ b_ih, float* __restrict__ gi, int B,
+                                                              int S, int Hd, unsigned* __restrict__ za,
+                                                              unsigned* __restrict__ zb, unsigned na, unsigned nb) {
+  __shared__ float xs[GI_RB][W];
+  const int tid = threadIdx.x;
+  const int M = S * B, H3 = 3 * Hd, ncg = H3 >> 2;
+  const int i0 = blockIdx.x * GI_RB;
+  const int cg = blockIdx.y * GI_NT + tid;
+  const bool live = cg < ncg;
+  const int cgc = live ? cg : ncg - 1;
+  // weights of the thread's four columns: rows 4 cg .. 4 cg + 3 of W_ih [3 Hd x W] = 4 W contiguous floats (16-byte aligned)
+  float wf[4 * W];                                                 // wf[c * W + k] = W_ih[4 cg + c][k]
+  {
+    const float* wp = w_ih + (size_t)4 * cgc * W;
+    if ((reinterpret_cast<uintptr_t>(w_ih) & 15) == 0) {           // (uniform) parameters inside a flat bucket may sit on any word
+#pragma unroll
+      for (int q = 0; q < W; ++q) {
+        const float4 v = reinterpret_cast<const float4*>(wp)[q];
+        wf[4 * q] = v.x; wf[4 * q + 1] = v.y; wf[4 * q + 2] = v.z; wf[4 * q + 3] = v.w;
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4 * W; ++q) wf[q] = wp[q];
+    }
+  }
+  float4 bias;
+  bias.x = b_ih[4 * cgc]; bias.y = b_ih[4 * cgc + 1]; bias.z = b_ih[4 * cgc + 2]; bias.w = b_ih[4 * cgc + 3];
+  for (int e = tid; e < GI_RB * W; e += GI_NT) {
+    const int r = e / W, k = e - r * W;
+    const int i = i0 + r < M ? i0 + r : M - 1;
+    const int sI = i / B, b = i - sI * B;
+    xs[r][k] = x[((size_t)b * W + k) * S + sI];
+  }
+  if (na + nb) {
+    const unsigned nwg = gridDim.x * gridDim.y, id = blockIdx.y * gridDim.x + blockIdx.x;
+    const unsigned per = (na + nb + nwg - 1) / nwg, hi = min(na + nb, (id + 1) * per);
+    for (unsigned i = id * per + tid; i < hi; i += GI_NT) {
+      if (i < na) za[i] = 0u;
+      else zb[i - na] = 0u;
+    }
+  }
+  __syncthreads();
+#pragma unroll 4
+  for (int r = 0; r < GI_RB; ++r) {
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+    for (int k = 0; k < W; ++k) {
+      const float xv = xs[r][k];
+      a0 = fmaf(xv, wf[k], a0);
+      a1 = fmaf(xv, wf[W + k], a1);
+      a2 = fmaf(xv, wf[2 * W + k], a2);
+      a3 = fmaf(xv, wf[3 * W + k], a3);
+    }
+    if (live && i0 + r < M)
+      *reinterpret_cast<float4*>(gi + (size_t)(i0 + r) * H3 + 4 * cg) = make_float4(a0 + bias.x, a1 + bias.y, a2 + bias.z, a3 + bias.w);
+  }
+}
+
 __global__ void gru_transpose_kernel(const float* __restrict__ w, float* __restrict__ wT, int rows, int cols) {
   __shared__ float t[32][33];
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
@@ -923,14 +990,22 @@ extern "C" int stemgnn_gru_fwd(const float* x, const float* w_ih, const float* w
   if (!use_wide && P2 > 0) {
     // per-row clusters: slab 0 (h_{-1} = 0) and the exchange granules (tags := 0 every launch) are zeroed ahead of the
     // recurrence INSIDE the projection GEMM's launch (GruGiOp::setup: every workgroup clears a share) instead of fill
-    // nodes / a zeroing kernel of their own (each costs ~5 us of launch latency on the step's critical path).  (A
-    // streaming input-projection kernel that also did the zeroing was measured not faster in round 3 -- 25 us against
-    // 20 + 5 -- and removed in round 4.)
+    // nodes / a zeroing kernel of their own (each costs ~5 us of launch latency on the step's critical path).  (Round 3's
+    // streaming input-projection kernel -- weights in LDS, dword stores -- measured 25 us against 20 + 5 and was removed;
+    // round 6's gru_gi_stream_kernel -- weights in registers, 16-byte stores -- takes 10.6 against the GEMM's 17.9 and does
+    // the same zeroing.)
     zn0 = (size_t)B * Hd; zn1 = ((size_t)2 * B * Hd + (size_t)8 * B) * 2;                   // in 4-byte words
   } else {
     SG_TRY(sg_zero_async(h_ext, (size_t)B * Hd * sizeof(float), st));    // slab 0: h_{-1} = 0
   }
-  {
+  static const int gi_stream = !(getenv("STEMGNN_GRU_GI_STREAM") && atoi(getenv("STEMGNN_GRU_GI_STREAM")) == 0);
+  if (gi_stream && !use_wide && W == 12 && (Hd & 3) == 0 && (reinterpret_cast<uintptr_t>(gi) & 15) == 0) {
+    const int ncg = 3 * Hd / 4;
+    hipLaunchKernelGGL(gru_gi_stream_kernel<12>, dim3((S * B + GI_RB - 1) / GI_RB, (ncg + GI_NT - 1) / GI_NT), dim3(GI_NT), 0,
+                       st, x, w_ih, b_ih, gi, B, S, Hd, reinterpret_cast<unsigned*>(h_ext), reinterpret_cast<unsigned*>(xbuf2),
+                       (unsigned)zn0, (unsigned)zn1);
+    SG_TRY(hipGetLastError());
+  } else {
     GruGiOp op{x, w_ih, b_ih, gi, B, S, Hd, W, reinterpret_cast<unsigned*>(h_ext), reinterpret_cast<unsigned*>(xbuf2),
                (unsigned)zn0, (unsigned)zn1};
     SG_TRY((sg_launch_gemm<GruGiOp, 64, 64, true, true, false>(op, S * B, 3 * Hd, 1, st)));
